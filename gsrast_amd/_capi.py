@@ -1,0 +1,116 @@
+"""ctypes binding of include/gsrast_amd.h (the C ABI of libgsrast_amd.so).
+
+There is no fallback: if the HIP library has not been built, importing the product path
+raises. Field order and types below mirror the header exactly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgsrast_amd.so")
+
+GSR_OK = 0
+GSR_ERR_INVALID_ARG = 1
+GSR_ERR_ALLOC = 2
+GSR_ERR_HIP = 3
+GSR_ERR_NO_DEVICE = 4
+GSR_ERR_TOO_LARGE = 5
+
+GSR_FLAG_PROFILE = 0x1
+GSR_FLAG_COUNT_STAGED = 0x2
+GSR_NUM_STAGES = 6
+STAGE_NAMES = ("preprocess", "scan", "duplicate", "sort", "ranges", "blend")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class GeometryState(C.Structure):
+    _fields_ = [("tiles_touched", C.c_void_p), ("scan_size", C.c_size_t), ("num_rendered", C.c_uint32),
+                ("scanning_space", C.c_void_p), ("depths", C.c_void_p), ("clamped", C.c_void_p),
+                ("internal_radii", C.c_void_p), ("means2D", C.c_void_p), ("cov3D", C.c_void_p),
+                ("conic_opacity", C.c_void_p), ("rgb", C.c_void_p), ("point_offsets", C.c_void_p)]
+
+
+class ImageState(C.Structure):
+    _fields_ = [("ranges", C.c_void_p), ("n_contrib", C.c_void_p), ("accum_alpha", C.c_void_p)]
+
+
+class BinningState(C.Structure):
+    _fields_ = [("keys_unsorted", C.c_void_p), ("keys", C.c_void_p), ("values_unsorted", C.c_void_p),
+                ("values", C.c_void_p), ("sorting_size", C.c_size_t), ("sorting_space", C.c_void_p)]
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("flags", C.c_uint32),
+        ("geometry_alloc", ALLOC_FN), ("geometry_user", C.c_void_p),
+        ("binning_alloc", ALLOC_FN), ("binning_user", C.c_void_p),
+        ("image_alloc", ALLOC_FN), ("image_user", C.c_void_p),
+        ("num_gaussians", C.c_int32), ("sh_dims", C.c_int32), ("M", C.c_int32),
+        ("background", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("scale_modifier", C.c_float),
+        ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("view_matrix", C.c_void_p),
+        ("proj_matrix", C.c_void_p), ("cam_pos", C.c_void_p), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+        ("prefiltered", C.c_int32), ("out_color", C.c_void_p), ("radii", C.c_void_p), ("rects", C.c_void_p),
+        ("box_min", C.c_void_p), ("box_max", C.c_void_p),
+        ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
+        ("num_rendered", C.c_uint32), ("records_staged", C.c_uint64),
+        ("stage_ms", C.c_float * GSR_NUM_STAGES),
+    ]
+
+
+# name -> (restype, argtypes); this is also the list the symbol test checks against the header.
+SIGNATURES = {
+    "gsr_geometry_from_chunk": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(GeometryState)]),
+    "gsr_image_from_chunk": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(ImageState)]),
+    "gsr_binning_from_chunk": (C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(BinningState)]),
+    "gsr_required_geometry": (C.c_size_t, [C.c_int]),
+    "gsr_required_image": (C.c_size_t, [C.c_int]),
+    "gsr_required_binning": (C.c_size_t, [C.c_size_t]),
+    "gsr_forward": (C.c_int, [C.POINTER(ForwardArgs)]),
+    "gsr_last_error": (C.c_int, []),
+    "gsr_error_string": (C.c_char_p, [C.c_int]),
+    "gsr_last_hip_error": (C.c_char_p, []),
+    "gsr_higher_msb": (C.c_uint32, [C.c_uint32]),
+    "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),
+    "gsr_inclusive_scan_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "gsr_sort_temp_bytes": (C.c_size_t, [C.c_size_t]),
+    "gsr_sort_pairs_u64_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                         C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class GsrError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        L = lib()
+        msg = L.gsr_error_string(code).decode()
+        hip = L.gsr_last_hip_error().decode()
+        super().__init__(f"{where}: {msg} (code {code})" + (f" [{hip}]" if hip else ""))
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Loads libgsrast_amd.so. Raises if it has not been built: there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP library first (python -m gsrast_amd.build). "
+                "gsrast_amd has no CPU or PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int, where: str) -> None:
+    if code != GSR_OK:
+        raise GsrError(code, where)

@@ -1,0 +1,144 @@
+// Per-tile front-to-back alpha blend. One 16x16 screen tile per 256-lane workgroup
+// (4 wave64, each wave a 16x4 pixel strip), Gaussian records pulled from HBM in batches
+// of 256 into LDS and composited with per-wave early-outs decided by wave64 __ballot.
+//
+// Semantics follow reference apps/gsrast/gscuda/GSCuda.cu:543-677 (renderCUDA):
+//   integer pixel centres (no +0.5), power = -0.5(A dx^2 + C dy^2) - B dx dy, skip power > 0,
+//   alpha = min(0.99, opacity * exp(power)), skip alpha < 1/255, stop when T(1-alpha) < 0.001,
+//   C += rgb * alpha * T, out = C + T * background, finalT, nContrib = index (1-based) of the
+//   last contributing record. The batch size (256) and the "whole tile done" test at the top
+//   of each batch are the reference's, so the number of records staged (R_f) is identical.
+// Differences that do not change any pixel: a wave whose 64 pixels are all done skips the
+// batch's arithmetic; a record no lane of the wave can see (power > 0 or below the 1/255
+// cut for every lane) is skipped after the power evaluation by one ballot.
+#include "gsr_common.hpp"
+
+namespace gsr {
+namespace {
+
+constexpr int kBatch = 256;
+
+// exp(power) >= 1/255 needs power >= -ln(255) = -5.5413; anything below -5.56 fails the
+// alpha >= 1/255 test for every opacity <= 1 with a 1.9 % margin, far outside rounding.
+constexpr float kPowerFloor = -5.56f;
+
+struct BlendParams {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float2* means2D;
+    const float* colors;           // vec3, 12-byte stride
+    const float4* conic_opacity;
+    float* final_t;
+    uint32_t* n_contrib;
+    const float* background;
+    float* out_color;
+    unsigned long long* staged_counter;
+    FrameDims dims;
+    int num_tiles;                 // tiles in [row_begin,row_end)
+};
+
+// Blocks b and b+8 share an XCD (and its L2). Give every XCD one contiguous run of tiles so
+// the Gaussians neighbouring tiles share are gathered through one L2.
+__device__ __forceinline__ int xcd_tile_of_block(int b, int n) {
+    const int q = n / 8, r = n % 8, x = b % 8, k = b / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__global__ __launch_bounds__(256) void blend_kernel(const BlendParams p) {
+    __shared__ float2 s_xy[kBatch];
+    __shared__ float4 s_co[kBatch];
+    __shared__ float4 s_rgb[kBatch];
+
+    const int tile_local = xcd_tile_of_block(blockIdx.x, p.num_tiles);
+    const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
+    const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
+    const int px = tx * kTile + (threadIdx.x & 15), py = ty * kTile + (threadIdx.x >> 4);
+    const bool inside = px < p.dims.width && py < p.dims.height;
+    const float fx = (float)px, fy = (float)py;
+
+    const uint2 range = p.ranges[tile];
+    const int rounds = (int)((range.y - range.x + kBatch - 1) / kBatch);
+    int work = (int)(range.y - range.x);
+
+    bool done = !inside;
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    uint32_t last = 0;
+    unsigned long long staged = 0;
+
+    for (int i = 0; i < rounds; ++i, work -= kBatch) {
+        if (__syncthreads_count(done) == kBatch) break;
+        const int cnt = min(kBatch, work);
+        if ((int)threadIdx.x < cnt) {
+            const uint32_t id = p.point_list[range.x + (uint32_t)(i * kBatch) + threadIdx.x];
+            s_xy[threadIdx.x] = p.means2D[id];
+            s_co[threadIdx.x] = p.conic_opacity[id];
+            const float* c = p.colors + 3 * (size_t)id;
+            s_rgb[threadIdx.x] = make_float4(c[0], c[1], c[2], 0.0f);
+        }
+        staged += (unsigned long long)cnt;
+        __syncthreads();
+        if (__ballot(!done) == 0ull) continue;          // this wave's strip is finished
+        const uint32_t first = (uint32_t)(i * kBatch);
+        for (int j = 0; j < cnt; ++j) {
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - fx, dy = xy.y - fy;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            // co.w (opacity) is wave-uniform; the floor only holds for opacity <= 1.
+            const bool candidate = !done && !(power > 0.0f) && (power >= kPowerFloor || co.w > 1.0f);
+            if (__ballot(candidate) == 0ull) continue;
+            const float alpha = fminf(0.99f, co.w * __expf(power));
+            const bool live = candidate && !(alpha < 1.0f / 255.0f);
+            const float test = T * (1.0f - alpha);
+            const bool stop = live && test < 0.001f;
+            if (live && !stop) {
+                const float4 c = s_rgb[j];
+                cr += c.x * alpha * T;
+                cg += c.y * alpha * T;
+                cb += c.z * alpha * T;
+                T = test;
+                last = first + (uint32_t)j + 1u;
+            }
+            done = done || stop;
+            if (stop && __ballot(!done) == 0ull) break;
+        }
+    }
+
+    if (inside) {
+        const size_t plane = (size_t)p.dims.width * (size_t)p.dims.height;
+        const size_t pid = (size_t)py * (size_t)p.dims.width + (size_t)px;
+        p.final_t[pid] = T;
+        p.n_contrib[pid] = last;
+        p.out_color[pid] = cr + T * p.background[0];
+        p.out_color[pid + plane] = cg + T * p.background[1];
+        p.out_color[pid + 2 * plane] = cb + T * p.background[2];
+    }
+    if (p.staged_counter && threadIdx.x == 0) atomicAdd(p.staged_counter, staged);
+}
+
+}  // namespace
+
+int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
+                 const float* means2D, const float* colors, const float* conic_opacity,
+                 float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
+                 unsigned long long* staged_counter, hipStream_t stream) {
+    BlendParams p;
+    p.ranges = reinterpret_cast<const uint2*>(ranges);
+    p.point_list = point_list;
+    p.means2D = reinterpret_cast<const float2*>(means2D);
+    p.colors = colors;
+    p.conic_opacity = reinterpret_cast<const float4*>(conic_opacity);
+    p.final_t = final_t;
+    p.n_contrib = n_contrib;
+    p.background = background;
+    p.out_color = out_color;
+    p.staged_counter = staged_counter;
+    p.dims = d;
+    p.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
+    if (p.num_tiles <= 0) return GSR_OK;
+    hipLaunchKernelGGL(blend_kernel, dim3((unsigned)p.num_tiles), dim3(256), 0, stream, p);
+    GSR_LAUNCH_CHECK("blend_kernel");
+    return GSR_OK;
+}
+
+}  // namespace gsr

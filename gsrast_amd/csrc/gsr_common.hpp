@@ -1,0 +1,62 @@
+// Shared declarations of the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/gsrast_amd.h"
+
+namespace gsr {
+
+constexpr int kTile = 16;          // BLOCK_W / BLOCK_H, reference GSCuda.cu:20-21
+constexpr int kWave = 64;          // gfx950 wavefront
+
+// Records the failing HIP call for gsr_last_hip_error().
+void set_hip_error(hipError_t e, const char* what);
+
+#define GSR_HIP_TRY(expr)                                   \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                             \
+            ::gsr::set_hip_error(e_, #expr);                \
+            return GSR_ERR_HIP;                             \
+        }                                                   \
+    } while (0)
+
+#define GSR_LAUNCH_CHECK(name)                              \
+    do {                                                    \
+        hipError_t e_ = hipGetLastError();                  \
+        if (e_ != hipSuccess) {                             \
+            ::gsr::set_hip_error(e_, name);                 \
+            return GSR_ERR_HIP;                             \
+        }                                                   \
+    } while (0)
+
+struct FrameDims {
+    int width, height;
+    int grid_x, grid_y;            // tile grid of the whole image
+    int row_begin, row_end;        // tile rows this call bins / sorts / blends
+};
+
+// ---- stage launchers (each asynchronous on `stream`) ----
+int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
+                      const FrameDims& d, hipStream_t stream);
+
+int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
+size_t scan_temp_bytes(size_t n);
+
+int launch_duplicate(int n, const gsr_geometry_state& g, const int32_t* radii, const int32_t* rects,
+                     const FrameDims& d, uint64_t* keys, uint32_t* values, hipStream_t stream);
+
+int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
+                      uint32_t* values_out, size_t n, int end_bit, char* temp, hipStream_t stream);
+size_t sort_temp_bytes(size_t n);
+
+int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, hipStream_t stream);
+
+int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
+                 const float* means2D, const float* colors, const float* conic_opacity,
+                 float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
+                 unsigned long long* staged_counter, hipStream_t stream);
+
+}  // namespace gsr

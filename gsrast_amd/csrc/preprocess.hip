@@ -1,0 +1,237 @@
+// Per-Gaussian preprocess: cull, 3D covariance, EWA 2D covariance, conic, screen rect,
+// DC colour, depth, tiles touched. One lane per Gaussian, streaming (HBM-bound).
+//
+// Follows the semantics of reference apps/gsrast/gscuda/GSCuda.cu:261-375
+// (preprocessCUDA) with helpers :157-162 (quatToMat), :168-195 (computeCov3D),
+// :197-231 (computeCov2D), :237-259 (getRect). Arithmetic keeps the reference's
+// float32 operation order (this file is compiled with -ffp-contract=off), including
+// the double intermediates of quatToMat, so every integer output (radii, rects,
+// tilesTouched) is reproducible bit for bit.
+#include "gsr_common.hpp"
+
+namespace gsr {
+namespace {
+
+struct M3 { float m[3][3]; };   // m[col][row]
+
+__device__ __forceinline__ float fminr(float a, float b) { return (b < a) ? b : a; }   // glm::min
+__device__ __forceinline__ float fmaxr(float a, float b) { return (a < b) ? b : a; }   // glm::max
+
+__device__ __forceinline__ M3 mul3(const M3& a, const M3& b) {
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int row = 0; row < 3; ++row)
+            r.m[c][row] = a.m[0][row] * b.m[c][0] + a.m[1][row] * b.m[c][1] + a.m[2][row] * b.m[c][2];
+    return r;
+}
+__device__ __forceinline__ M3 transpose3(const M3& a) {
+    M3 r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int row = 0; row < 3; ++row) r.m[c][row] = a.m[row][c];
+    return r;
+}
+__device__ __forceinline__ float4 mat4_vec4(const float* __restrict__ m, float x, float y, float z, float w) {
+    float4 o;
+    o.x = (m[0] * x + m[4] * y) + (m[8] * z + m[12] * w);
+    o.y = (m[1] * x + m[5] * y) + (m[9] * z + m[13] * w);
+    o.z = (m[2] * x + m[6] * y) + (m[10] * z + m[14] * w);
+    o.w = (m[3] * x + m[7] * y) + (m[11] * z + m[15] * w);
+    return o;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
+
+// getRect with the y range clipped to the tile-row band of this call (the whole grid
+// when the call is not sharded: then it is exactly GSCuda.cu:249-259).
+__device__ __forceinline__ void tile_rect(float px, float py, int ex, int ey, const FrameDims& d,
+                                          int& x0, int& y0, int& x1, int& y1) {
+    x0 = clampi((int)((px - (float)ex) / 16.0f), 0, d.grid_x);
+    y0 = clampi((int)((py - (float)ey) / 16.0f), 0, d.grid_y);
+    x1 = clampi((int)((((px + (float)ex) + 16.0f) - 1.0f) / 16.0f), 0, d.grid_x);
+    y1 = clampi((int)((((py + (float)ey) + 16.0f) - 1.0f) / 16.0f), 0, d.grid_y);
+    y0 = clampi(y0, d.row_begin, d.row_end);
+    y1 = clampi(y1, d.row_begin, d.row_end);
+}
+
+struct PreprocessParams {
+    int n;
+    const float4* means3D;
+    const float4* scales;
+    float scale_modifier;
+    const float4* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    const float* view;
+    const float* proj;
+    float tan_fovx, tan_fovy, focal;
+    int32_t* radii;
+    float2* means2D;
+    float* depths;
+    float* cov3Ds;
+    float* rgb;
+    float4* conic_opacity;
+    uint32_t* tiles_touched;
+    int2* rects;
+    FrameDims dims;
+};
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.n) return;
+
+    int32_t out_radius = 0;
+    uint32_t out_tiles = 0;
+
+    // The two matrices are wave-uniform: they come in through the scalar cache.
+    const float4 mean = p.means3D[idx];
+    const float4 ph = mat4_vec4(p.proj, mean.x, mean.y, mean.z, mean.w);
+    const float one_over_w = 1.0f / (0.001f + ph.w);
+    const float prx = one_over_w * ph.x, pry = one_over_w * ph.y, prz = one_over_w * ph.z;
+    const bool in_frustum = !(prz < 0.0f || prz > 1.0f || prx < -1.3f || prx > 1.3f || pry < -1.3f || pry > 1.3f);
+    if (in_frustum) {
+        float c3[6];
+        if (p.cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c3[i] = p.cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            const float4 sc = p.scales[idx];
+            const float4 rot = p.rotations[idx];
+            M3 s;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) s.m[c][r] = 0.0f;
+            s.m[0][0] = p.scale_modifier * sc.x;
+            s.m[1][1] = p.scale_modifier * sc.y;
+            s.m[2][2] = p.scale_modifier * sc.z;
+            const float dq = (rot.x * rot.x + rot.y * rot.y) + (rot.z * rot.z + rot.w * rot.w);
+            const float inv = 1.0f / sqrtf(dq);
+            const float x = rot.x * inv, y = rot.y * inv, z = rot.z * inv, w = rot.w * inv;
+            M3 rm;
+            rm.m[0][0] = (float)(2.0 * (double)(x * x + y * y) - 1.0);
+            rm.m[0][1] = (float)(2.0 * (double)(y * z + x * w));
+            rm.m[0][2] = (float)(2.0 * (double)(y * w - x * z));
+            rm.m[1][0] = (float)(2.0 * (double)(y * z - x * w));
+            rm.m[1][1] = (float)(2.0 * (double)(x * x + z * z) - 1.0);
+            rm.m[1][2] = (float)(2.0 * (double)(z * w + x * y));
+            rm.m[2][0] = (float)(2.0 * (double)(y * w + x * z));
+            rm.m[2][1] = (float)(2.0 * (double)(z * w - x * y));
+            rm.m[2][2] = (float)(2.0 * (double)(x * x + w * w) - 1.0);
+            const M3 rs = mul3(rm, s);
+            const M3 sigma = mul3(rs, transpose3(rs));
+            c3[0] = sigma.m[0][0]; c3[1] = sigma.m[1][0]; c3[2] = sigma.m[2][0];
+            c3[3] = sigma.m[1][1]; c3[4] = sigma.m[2][1]; c3[5] = sigma.m[2][2];
+            float2* dst = reinterpret_cast<float2*>(p.cov3Ds + 6 * (size_t)idx);
+            dst[0] = make_float2(c3[0], c3[1]);
+            dst[1] = make_float2(c3[2], c3[3]);
+            dst[2] = make_float2(c3[4], c3[5]);
+        }
+
+        // EWA projection (computeCov2D)
+        float4 t = mat4_vec4(p.view, mean.x, mean.y, mean.z, 1.0f);
+        const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
+        const float txtz = t.x / t.z, tytz = t.y / t.z;
+        t.x = fminr(limx, fmaxr(-limx, txtz)) * t.z;
+        t.y = fminr(limy, fmaxr(-limy, tytz)) * t.z;
+        M3 j;
+        j.m[0][0] = p.focal / t.z; j.m[0][1] = 0.0f; j.m[0][2] = (-p.focal * t.x) / (t.z * t.z);
+        j.m[1][0] = 0.0f; j.m[1][1] = p.focal / t.z; j.m[1][2] = (-p.focal * t.y) / (t.z * t.z);
+        j.m[2][0] = 0.0f; j.m[2][1] = 0.0f; j.m[2][2] = 0.0f;
+        M3 wv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) wv.m[c][r] = p.view[4 * r + c];
+        const M3 tm = mul3(wv, j);
+        M3 vrk;
+        vrk.m[0][0] = c3[0]; vrk.m[0][1] = c3[1]; vrk.m[0][2] = c3[2];
+        vrk.m[1][0] = c3[1]; vrk.m[1][1] = c3[3]; vrk.m[1][2] = c3[4];
+        vrk.m[2][0] = c3[2]; vrk.m[2][1] = c3[4]; vrk.m[2][2] = c3[5];
+        const M3 cv = mul3(mul3(transpose3(tm), vrk), tm);
+        const float ca = cv.m[0][0] + 0.3f, cb = cv.m[0][1], cc = cv.m[1][1] + 0.3f;
+
+        const float det = ca * cc - cb * cb;
+        if (det != 0.0f) {
+            const float det_inv = 1.0f / det;
+            const float mid = 0.5f * (ca + cc);
+            const float root = sqrtf(fmaxr(0.1f, mid * mid - det));
+            const float lambda1 = mid + root, lambda2 = mid - root;
+            const float my_radius = ceilf(3.0f * sqrtf(fmaxr(lambda1, lambda2)));
+            const float pix = (prx * 0.5f + 0.5f) * (float)p.dims.width;
+            const float piy = (pry * 0.5f + 0.5f) * (float)p.dims.height;
+            int ex, ey;
+            if (p.rects) {
+                ex = (int)ceilf(3.0f * sqrtf(ca));
+                ey = (int)ceilf(3.0f * cc);            // sic, reference GSCuda.cu:352
+                p.rects[idx] = make_int2(ex, ey);
+            } else {
+                ex = ey = (int)my_radius;
+            }
+            int x0, y0, x1, y1;
+            tile_rect(pix, piy, ex, ey, p.dims, x0, y0, x1, y1);
+            // Visibility follows the UNCLIPPED rectangle (reference :356); the count is of the
+            // tiles inside this call's row band, which is the same thing when not sharded.
+            int fy0 = clampi((int)((piy - (float)ey) / 16.0f), 0, p.dims.grid_y);
+            int fy1 = clampi((int)((((piy + (float)ey) + 16.0f) - 1.0f) / 16.0f), 0, p.dims.grid_y);
+            const uint32_t full_area = (uint32_t)(x1 - x0) * (uint32_t)(fy1 - fy0);
+            if (full_area != 0) {
+                if (!p.colors_precomp) {
+                    const float* sh = p.shs + 48 * (size_t)idx;
+                    float* o = p.rgb + 3 * (size_t)idx;
+                    o[0] = 0.5f + 0.4f * sh[0];
+                    o[1] = 0.5f + 0.4f * sh[1];
+                    o[2] = 0.5f + 0.4f * sh[2];
+                }
+                p.depths[idx] = prz;
+                p.means2D[idx] = make_float2(pix, piy);
+                p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[idx]);
+                out_radius = (int)my_radius;
+                out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+            }
+        }
+    }
+    p.radii[idx] = out_radius;
+    p.tiles_touched[idx] = out_tiles;
+}
+
+}  // namespace
+
+int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
+                      const FrameDims& d, hipStream_t stream) {
+    PreprocessParams p;
+    p.n = a.num_gaussians;
+    p.means3D = reinterpret_cast<const float4*>(a.means3D);
+    p.scales = reinterpret_cast<const float4*>(a.scales);
+    p.scale_modifier = a.scale_modifier;
+    p.rotations = reinterpret_cast<const float4*>(a.rotations);
+    p.opacities = a.opacities;
+    p.shs = a.shs;
+    p.cov3D_precomp = a.cov3D_precomp;
+    p.colors_precomp = a.colors_precomp;
+    p.view = a.view_matrix;
+    p.proj = a.proj_matrix;
+    p.tan_fovx = a.tan_fovx;
+    p.tan_fovy = a.tan_fovy;
+    p.focal = (float)a.height / (2.0f * a.tan_fovy);   // GSCuda.cu:721
+    p.radii = radii;
+    p.means2D = reinterpret_cast<float2*>(g.means2D);
+    p.depths = g.depths;
+    p.cov3Ds = g.cov3D;
+    p.rgb = g.rgb;
+    p.conic_opacity = reinterpret_cast<float4*>(g.conic_opacity);
+    p.tiles_touched = g.tiles_touched;
+    p.rects = reinterpret_cast<int2*>(a.rects);
+    p.dims = d;
+    const unsigned blocks = (unsigned)((a.num_gaussians + 255) / 256);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    GSR_LAUNCH_CHECK("preprocess_kernel");
+    return GSR_OK;
+}
+
+}  // namespace gsr

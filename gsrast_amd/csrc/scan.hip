@@ -1,0 +1,152 @@
+// Inclusive u32 prefix sum over N elements (replaces cub::DeviceScan::InclusiveSum at
+// reference GSCuda.cu:771). Reduce-then-scan in three launches; every launch reads or
+// writes whole 16-byte vectors per lane, and the only scratch is one u32 per 4096-element
+// tile, carved from GeometryState::scanningSpace.
+//
+//   1. tile_reduce : tile t (4096 elements) -> partial[t]
+//   2. partial_scan: one workgroup turns partial[] into its exclusive prefix
+//   3. tile_scan   : tile t re-reads its elements, scans them in registers + wave shuffles,
+//                    adds partial[t] and stores
+// Integer wrap-around is that of u32 addition, as in the reference.
+#include "gsr_common.hpp"
+
+namespace gsr {
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;                               // per lane: 4 x uint4
+constexpr int kScanTile = kScanThreads * kScanItems;         // 4096
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, kWave);
+        if ((int)(threadIdx.x & (kWave - 1)) >= off) v += o;
+    }
+    return v;
+}
+
+// Block-wide exclusive prefix of one value per thread; also returns the block total.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave_sums, uint32_t& total) {
+    constexpr int kWaves = THREADS / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t incl = wave_inclusive_scan(v);
+    if (lane == kWave - 1) lds_wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        const uint32_t s = lds_wave_sums[w];
+        if (w < wave) wave_base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return wave_base + incl - v;
+}
+
+// Loads the 16 items of this lane: item k of lane l is element tile*4096 + (k/4)*1024 + 4*l + k%4,
+// so each of the four uint4 loads of a wave covers 1 KiB contiguous.
+__device__ __forceinline__ void load_items(const uint32_t* in, size_t n, size_t tile, uint32_t (&v)[kScanItems]) {
+    const size_t base = tile * kScanTile;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t e = base + (size_t)q * 1024 + 4 * (size_t)threadIdx.x;
+        if (e + 3 < n) {
+            const uint4 x = *reinterpret_cast<const uint4*>(in + e);
+            v[4 * q + 0] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * q + k] = (e + k < n) ? in[e + k] : 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                                    uint32_t* __restrict__ partial) {
+    __shared__ uint32_t wave_sums[kScanThreads / kWave];
+    uint32_t v[kScanItems];
+    load_items(in, n, blockIdx.x, v);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += v[k];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_sums[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / kWave; ++w) t += wave_sums[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict__ partial, size_t tiles) {
+    __shared__ uint32_t wave_sums[1024 / kWave];
+    uint32_t carry = 0;
+    for (size_t base = 0; base < tiles; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const uint32_t v = (i < tiles) ? partial[i] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan<1024>(v, wave_sums, total);
+        if (i < tiles) partial[i] = carry + excl;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(const uint32_t* in, uint32_t* out,
+                                                                  size_t n, const uint32_t* __restrict__ partial) {
+    __shared__ uint32_t wave_sums[kScanThreads / kWave];
+    uint32_t v[kScanItems];
+    load_items(in, n, blockIdx.x, v);
+    // Order of elements inside the tile: chunk q (1024 elements) -> lane -> 4 items.
+    uint32_t running = partial[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[4 * q + 1] += v[4 * q + 0];
+        v[4 * q + 2] += v[4 * q + 1];
+        v[4 * q + 3] += v[4 * q + 2];
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan<kScanThreads>(v[4 * q + 3], wave_sums, total);
+        const uint32_t add = running + excl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 * q + k] += add;
+        running += total;
+    }
+    const size_t base = (size_t)blockIdx.x * kScanTile;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t e = base + (size_t)q * 1024 + 4 * (size_t)threadIdx.x;
+        if (e + 3 < n) {
+            *reinterpret_cast<uint4*>(out + e) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k < n) out[e + k] = v[4 * q + k];
+        }
+    }
+}
+
+}  // namespace
+
+size_t scan_temp_bytes(size_t n) {
+    const size_t tiles = (n + kScanTile - 1) / kScanTile;
+    return ((tiles + 1) * sizeof(uint32_t) + 127) / 128 * 128;
+}
+
+int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream) {
+    if (n == 0) return GSR_OK;
+    const size_t tiles = (n + kScanTile - 1) / kScanTile;
+    uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial);
+    GSR_LAUNCH_CHECK("tile_reduce_kernel");
+    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles);
+    GSR_LAUNCH_CHECK("partial_scan_kernel");
+    hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, partial);
+    GSR_LAUNCH_CHECK("tile_scan_kernel");
+    return GSR_OK;
+}
+
+}  // namespace gsr

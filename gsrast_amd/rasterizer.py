@@ -1,0 +1,217 @@
+"""Host side of the rasterizer: the role `GSGaussians` plays in the reference
+(apps/gsrast/GSGaussians.cpp). PyTorch is used for device memory and streams only; every
+stage runs in libgsrast_amd.so through the C ABI (include/gsrast_amd.h).
+
+  ChunkBuffer            <-> resizeFunctional           (GSGaussians.cpp:27-42)
+  SplatRasterizer.configure_from_scene <-> configureFromSplatData (:109-153)
+  SplatRasterizer.draw   <-> GSGaussians::draw          (:155-212)
+  SplatRasterizer.map_geometry_state <-> mapGeometryState (:214-219)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .camera import Camera
+
+
+class ChunkBuffer:
+    """Grow-only device chunk with 2x over-allocation, handed to the library as an
+    allocator callback: `resizeFunctional` of the reference."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.tensor: torch.Tensor | None = None
+        self.capacity = 0
+        self.calls: list[int] = []          # sizes requested, in order (observable contract)
+        self._cb = _capi.ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        self.calls.append(int(nbytes))
+        try:
+            if nbytes > self.capacity:
+                self.tensor = None
+                self.tensor = torch.empty(2 * int(nbytes), dtype=torch.uint8, device=self.device)
+                self.capacity = 2 * int(nbytes)
+            return self.tensor.data_ptr()
+        except Exception:       # an exception must not cross the C boundary; NULL -> GSR_ERR_ALLOC
+            return None
+
+    @property
+    def callback(self):
+        return self._cb
+
+    def base(self) -> int:
+        return 0 if self.tensor is None else self.tensor.data_ptr()
+
+    def view(self, ptr: int, count: int, dtype: torch.dtype) -> torch.Tensor:
+        """Typed view of `count` elements starting at device address `ptr` inside the chunk."""
+        off = ptr - self.base()
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        assert 0 <= off and off + nbytes <= self.capacity, "state pointer outside its chunk"
+        return self.tensor[off:off + nbytes].view(dtype)
+
+
+def _dev(a, device, dtype=torch.float32) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype).contiguous()
+
+
+class SplatRasterizer:
+    """Uploads a scene once and renders it per camera through gsr_forward."""
+
+    def __init__(self, width: int, height: int, device="cuda:0", background=(0.0, 0.0, 0.0)):
+        self.lib = _capi.lib()                       # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("SplatRasterizer needs a HIP device (no CPU fallback exists)")
+        self.device = torch.device(device)
+        self.width, self.height = int(width), int(height)
+        self.geom = ChunkBuffer(self.device)
+        self.binning = ChunkBuffer(self.device)
+        self.image = ChunkBuffer(self.device)
+        self.background = _dev(np.asarray(background, np.float32), self.device)
+        self.out_color = torch.zeros((3, self.height, self.width), dtype=torch.float32, device=self.device)
+        self.num_gaussians = 0
+        self.use_rects = True
+        self.last_num_rendered = 0
+        self.last_records_staged = 0
+        self.last_stage_ms: dict[str, float] = {}
+        self._view = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self._proj = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self._cam_pos = torch.zeros(3, dtype=torch.float32, device=self.device)
+
+    # -- scene upload -----------------------------------------------------------------
+    def configure_from_scene(self, scene: dict, use_rects: bool = True) -> None:
+        self.means3D = _dev(scene["means3D"], self.device)
+        self.scales = _dev(scene["scales"], self.device)
+        self.rotations = _dev(scene["rotations"], self.device)
+        self.opacities = _dev(scene["opacities"], self.device)
+        self.shs = _dev(scene["shs"], self.device)
+        self.num_gaussians = int(self.means3D.shape[0])
+        assert self.means3D.shape == (self.num_gaussians, 4) and self.scales.shape == (self.num_gaussians, 4)
+        assert self.rotations.shape == (self.num_gaussians, 4) and self.shs.shape == (self.num_gaussians, 48)
+        self.use_rects = use_rects
+        self.rects = (torch.zeros((self.num_gaussians, 2), dtype=torch.int32, device=self.device)
+                      if use_rects else None)
+
+    def set_camera(self, cam: Camera) -> None:
+        assert cam.width == self.width and cam.height == self.height
+        self._view.copy_(torch.from_numpy(np.ascontiguousarray(cam.view, np.float32)))
+        self._proj.copy_(torch.from_numpy(np.ascontiguousarray(cam.proj, np.float32)))
+        self._cam_pos.copy_(torch.from_numpy(np.ascontiguousarray(cam.cam_pos, np.float32)))
+        self._tan = (float(cam.tan_fovx), float(cam.tan_fovy))
+
+    # -- one frame --------------------------------------------------------------------
+    def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
+             tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
+             sync: bool = True) -> torch.Tensor:
+        """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
+        tensor owned by this object. `sync` adds the device synchronise the reference's caller
+        performs after every call (CudaBuffer.hpp:8-12)."""
+        if cam is not None:
+            self.set_camera(cam)
+        a = _capi.ForwardArgs()
+        a.struct_size = C.sizeof(_capi.ForwardArgs)
+        a.flags = (_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
+        a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
+        a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, 3, 16
+        a.background = self.background.data_ptr()
+        a.width, a.height = self.width, self.height
+        a.means3D, a.shs = self.means3D.data_ptr(), self.shs.data_ptr()
+        a.colors_precomp = None
+        a.opacities, a.scales = self.opacities.data_ptr(), self.scales.data_ptr()
+        a.scale_modifier = scale_modifier
+        a.rotations = self.rotations.data_ptr()
+        a.cov3D_precomp = None
+        a.view_matrix, a.proj_matrix, a.cam_pos = self._view.data_ptr(), self._proj.data_ptr(), self._cam_pos.data_ptr()
+        a.tan_fovx, a.tan_fovy = self._tan
+        a.prefiltered = 0
+        a.out_color = self.out_color.data_ptr()
+        a.radii = None
+        a.rects = self.rects.data_ptr() if self.rects is not None else None
+        a.box_min = a.box_max = None
+        a.stream = torch.cuda.current_stream(self.device).cuda_stream
+        if tile_rows is not None:
+            a.tile_row_begin, a.tile_row_end = int(tile_rows[0]), int(tile_rows[1])
+        with torch.cuda.device(self.device):
+            rc = self.lib.gsr_forward(C.byref(a))
+        _capi.check(rc, "gsr_forward")
+        self.last_num_rendered = int(a.num_rendered)
+        self.last_records_staged = int(a.records_staged)
+        self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
+        if sync:
+            torch.cuda.current_stream(self.device).synchronize()
+        return self.out_color
+
+    # -- state inspection (what the reference's Inspector does through fromChunk) ------
+    def map_geometry_state(self) -> dict:
+        st = _capi.GeometryState()
+        self.lib.gsr_geometry_from_chunk(self.geom.base(), self.num_gaussians, C.byref(st))
+        n, v = self.num_gaussians, self.geom.view
+        return {
+            "tilesTouched": v(st.tiles_touched, n, torch.int32),
+            "depths": v(st.depths, n, torch.float32),
+            "radii": v(st.internal_radii, n, torch.int32),
+            "means2D": v(st.means2D, 2 * n, torch.float32).view(n, 2),
+            "cov3D": v(st.cov3D, 6 * n, torch.float32).view(n, 6),
+            "conicOpacity": v(st.conic_opacity, 4 * n, torch.float32).view(n, 4),
+            "rgb": v(st.rgb, 3 * n, torch.float32).view(n, 3),
+            "pointOffsets": v(st.point_offsets, n, torch.int32),
+        }
+
+    def map_image_state(self) -> dict:
+        st = _capi.ImageState()
+        P = self.width * self.height
+        self.lib.gsr_image_from_chunk(self.image.base(), P, C.byref(st))
+        T = ((self.width + 15) // 16) * ((self.height + 15) // 16)
+        v = self.image.view
+        return {
+            "ranges": v(st.ranges, 2 * T, torch.int32).view(T, 2),
+            "nContrib": v(st.n_contrib, P, torch.int32).view(self.height, self.width),
+            "finalT": v(st.accum_alpha, P, torch.float32).view(self.height, self.width),
+        }
+
+    def map_binning_state(self) -> dict:
+        st = _capi.BinningState()
+        R = self.last_num_rendered
+        self.lib.gsr_binning_from_chunk(self.binning.base(), R, C.byref(st))
+        v = self.binning.view
+        return {
+            "keys_unsorted": v(st.keys_unsorted, R, torch.int64),
+            "keys": v(st.keys, R, torch.int64),
+            "values_unsorted": v(st.values_unsorted, R, torch.int32),
+            "values": v(st.values, R, torch.int32),
+        }
+
+
+# ---- stage-level wrappers (unit parity tests) ------------------------------------------
+def inclusive_scan_u32(x: torch.Tensor) -> torch.Tensor:
+    L = _capi.lib()
+    assert x.dtype == torch.int32 and x.is_cuda and x.is_contiguous()
+    out = torch.empty_like(x)
+    temp = torch.empty(max(int(L.gsr_scan_temp_bytes(x.numel())), 128), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.gsr_inclusive_scan_u32(x.data_ptr(), out.data_ptr(), x.numel(), temp.data_ptr(),
+                                      torch.cuda.current_stream(x.device).cuda_stream)
+    _capi.check(rc, "gsr_inclusive_scan_u32")
+    torch.cuda.current_stream(x.device).synchronize()
+    return out
+
+
+def sort_pairs(keys: torch.Tensor, values: torch.Tensor, end_bit: int = 64):
+    L = _capi.lib()
+    assert keys.dtype == torch.int64 and values.dtype == torch.int32 and keys.is_cuda
+    assert keys.is_contiguous() and values.is_contiguous() and keys.numel() == values.numel()
+    n = keys.numel()
+    ko, vo = torch.empty_like(keys), torch.empty_like(values)
+    temp = torch.empty(max(int(L.gsr_sort_temp_bytes(n)), 128), dtype=torch.uint8, device=keys.device)
+    with torch.cuda.device(keys.device):
+        rc = L.gsr_sort_pairs_u64_u32(keys.data_ptr(), ko.data_ptr(), values.data_ptr(), vo.data_ptr(), n,
+                                      end_bit, temp.data_ptr(), torch.cuda.current_stream(keys.device).cuda_stream)
+    _capi.check(rc, "gsr_sort_pairs_u64_u32")
+    torch.cuda.current_stream(keys.device).synchronize()
+    return ko, vo

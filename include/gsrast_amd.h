@@ -1,0 +1,170 @@
+/* gsrast_amd.h — C ABI of the MI355X (gfx950) forward Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for the reference's rasterizer entry point
+ *   gscuda::forward            apps/gsrast/gscuda/GSCuda.cuh:103-126 (def. GSCuda.cu:695-811)
+ *   ≅ CudaRasterizer::Rasterizer::forward (apps/gsrast/GSGaussians.cpp:18-23)
+ * and for the chunk-layout helpers its callers re-derive pointers with
+ *   gscuda::required<T>, gs::{Geometry,Image,Binning}State::fromChunk
+ *                              apps/gsrast/gscuda/AuxBuffer.cuh:8-14,38-76, AuxBuffer.cu:13-21,44-89
+ *
+ * The reference interface is a C++ ABI (by-value std::function, namespaces); this header is
+ * the plain-C core a binding targets. include/gscuda_shim.hpp re-creates the exact C++
+ * signature on top of it. All pointers named "device" are HIP device pointers owned by
+ * the caller; the library allocates no device memory of its own.
+ */
+#ifndef GSRAST_AMD_H
+#define GSRAST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 1
+
+/* Error codes (gsr_forward's return value; the reference returns void and its caller
+ * polls the runtime's sticky error, apps/gsrast/CudaBuffer.hpp:8-12). */
+enum {
+    GSR_OK = 0,
+    GSR_ERR_INVALID_ARG = 1,   /* null pointer / non-positive size / bad struct_size      */
+    GSR_ERR_ALLOC = 2,         /* an allocator callback returned NULL                      */
+    GSR_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed               */
+    GSR_ERR_NO_DEVICE = 4,     /* no gfx950 device visible                                 */
+    GSR_ERR_TOO_LARGE = 5      /* numRendered does not fit the reference's u32 offsets     */
+};
+
+/* Chunk allocator: replaces std::function<char*(size_t)> (GSCuda.cuh:103-105). Must
+ * return device memory of at least `bytes` bytes, 128-byte aligned or better. */
+typedef char* (*gsr_alloc_fn)(void* user, size_t bytes);
+
+/* gs::GeometryState (AuxBuffer.cuh:38-54); field order = carve order (AuxBuffer.cu:44-63). */
+typedef struct gsr_geometry_state {
+    uint32_t* tiles_touched;   /* u32[N]                                   */
+    size_t    scan_size;       /* bytes of scanning_space                  */
+    uint32_t  num_rendered;    /* host copy of point_offsets[N-1]          */
+    char*     scanning_space;  /* scan scratch (this library's own layout) */
+    float*    depths;          /* f32[N]  NDC z                            */
+    uint8_t*  clamped;         /* bool[3N], never written (as reference)   */
+    int32_t*  internal_radii;  /* i32[N]                                   */
+    float*    means2D;         /* vec2[N]                                  */
+    float*    cov3D;           /* f32[6N]                                  */
+    float*    conic_opacity;   /* vec4[N]                                  */
+    float*    rgb;             /* vec3[N], 12-byte stride                  */
+    uint32_t* point_offsets;   /* u32[N] inclusive scan of tiles_touched   */
+} gsr_geometry_state;
+
+/* gs::ImageState (AuxBuffer.cuh:56-63). `size` = width*height. */
+typedef struct gsr_image_state {
+    uint32_t* ranges;          /* uvec2[size]; only the first ceil(W/16)*ceil(H/16) are used */
+    uint32_t* n_contrib;       /* u32[size]                                */
+    float*    accum_alpha;     /* f32[size] final transmittance            */
+} gsr_image_state;
+
+/* gs::BinningState (AuxBuffer.cuh:65-75). `size` = numRendered. */
+typedef struct gsr_binning_state {
+    uint64_t* keys_unsorted;   /* u64[R] (tile << 32) | depth bits         */
+    uint64_t* keys;            /* u64[R] sorted                            */
+    uint32_t* values_unsorted; /* u32[R] Gaussian index                    */
+    uint32_t* values;          /* u32[R] sorted                            */
+    size_t    sorting_size;    /* bytes of sorting_space                   */
+    char*     sorting_space;   /* radix-sort scratch                       */
+} gsr_binning_state;
+
+/* fromChunk: carve the sub-arrays out of `chunk`; returns the advanced chunk pointer
+ * (the reference advances a char*& in place). */
+char* gsr_geometry_from_chunk(char* chunk, int num_gaussians, gsr_geometry_state* out);
+char* gsr_image_from_chunk(char* chunk, int size, gsr_image_state* out);
+char* gsr_binning_from_chunk(char* chunk, size_t size, gsr_binning_state* out);
+/* required<T>(n): fromChunk on a null base (AuxBuffer.cuh:8-14). */
+size_t gsr_required_geometry(int num_gaussians);
+size_t gsr_required_image(int size);
+size_t gsr_required_binning(size_t size);
+
+/* Per-stage device times of the last profiled gsr_forward call, in milliseconds. */
+enum {
+    GSR_STAGE_PREPROCESS = 0,
+    GSR_STAGE_SCAN = 1,
+    GSR_STAGE_DUPLICATE = 2,
+    GSR_STAGE_SORT = 3,
+    GSR_STAGE_RANGES = 4,
+    GSR_STAGE_BLEND = 5,
+    GSR_NUM_STAGES = 6
+};
+
+#define GSR_FLAG_PROFILE 0x1u   /* record HIP events around every stage into stage_ms       */
+#define GSR_FLAG_COUNT_STAGED 0x2u /* count records staged by the blend stage (R_f) into records_staged */
+
+/* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
+ * gscuda::forward (GSCuda.cuh:103-126); the rest are extensions with neutral defaults (0). */
+typedef struct gsr_forward_args {
+    uint32_t struct_size;          /* = sizeof(gsr_forward_args) */
+    uint32_t flags;
+    gsr_alloc_fn geometry_alloc;   void* geometry_user;
+    gsr_alloc_fn binning_alloc;    void* binning_user;
+    gsr_alloc_fn image_alloc;      void* image_user;
+    int32_t num_gaussians;
+    int32_t sh_dims;               /* D, unused by the gscuda semantics */
+    int32_t M;                     /* unused */
+    const float* background;       /* device vec3 */
+    int32_t width, height;
+    const float* means3D;          /* device vec4[N] */
+    const float* shs;              /* device f32[48 N], DC first */
+    const float* colors_precomp;   /* device vec3[N] or NULL */
+    const float* opacities;        /* device f32[N] */
+    const float* scales;           /* device vec4[N] */
+    float scale_modifier;
+    const float* rotations;        /* device vec4[N], real part first */
+    const float* cov3D_precomp;    /* device f32[6 N] or NULL */
+    const float* view_matrix;      /* device 16 f32 column-major, row 2 negated */
+    const float* proj_matrix;      /* device 16 f32 column-major, perspective*view */
+    const float* cam_pos;          /* device vec3, unused */
+    float tan_fovx, tan_fovy;
+    int32_t prefiltered;           /* unused */
+    float* out_color;              /* device f32[3 W H], planar CHW */
+    int32_t* radii;                /* device i32[N] or NULL (falls back to internal_radii) */
+    int32_t* rects;                /* device i32[2 N] or NULL (radius-based rectangles) */
+    const float* box_min;          /* unused (reference overrides with -FLT_MAX) */
+    const float* box_max;          /* unused */
+    /* ---- extensions ---- */
+    void* stream;                  /* hipStream_t; NULL = the default stream */
+    int32_t tile_row_begin;        /* multi-GPU: only tile rows [begin,end) are binned,   */
+    int32_t tile_row_end;          /*   sorted and blended; 0,0 = all rows                 */
+    /* ---- outputs ---- */
+    uint32_t num_rendered;         /* R = sum of tiles touched (for the rows processed)    */
+    uint64_t records_staged;       /* R_f, only with GSR_FLAG_COUNT_STAGED                 */
+    float stage_ms[GSR_NUM_STAGES];/* only with GSR_FLAG_PROFILE                           */
+} gsr_forward_args;
+
+/* The forward pass. Calls geometry_alloc(required_geometry(N)), then
+ * image_alloc(required_image(W*H)+128), then — only if R>0, after the scan —
+ * binning_alloc(required_binning(R)+128): once each, in that order (GSCuda.cu:723-784).
+ * Synchronises `stream` once mid-call to read R back (GSCuda.cu:772). Returns GSR_*.
+ * R == 0 returns GSR_OK and leaves out_color untouched (GSCuda.cu:775-778). */
+int gsr_forward(gsr_forward_args* args);
+
+/* Sticky last error of the calling thread's most recent gsr_* call + its text. */
+int gsr_last_error(void);
+const char* gsr_error_string(int code);
+/* Text of the HIP error behind the last GSR_ERR_HIP ("" if none). */
+const char* gsr_last_hip_error(void);
+
+/* getHigherMsb (GSCuda.cu:481-502): bits of the tile id that take part in the sort. */
+uint32_t gsr_higher_msb(uint32_t n);
+
+/* ---- stage entry points (unit-level parity tests; all asynchronous on `stream`) ---- */
+/* Inclusive u32 prefix sum (replaces cub::DeviceScan::InclusiveSum, GSCuda.cu:771).
+ * temp needs gsr_scan_temp_bytes(n) bytes. in == out is allowed. */
+size_t gsr_scan_temp_bytes(size_t n);
+int gsr_inclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream);
+/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit)
+ * (replaces cub::DeviceRadixSort::SortPairs, GSCuda.cu:794-797). Inputs are preserved. */
+size_t gsr_sort_temp_bytes(size_t n);
+int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
+                           uint32_t* values_out, size_t n, int end_bit, char* temp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_AMD_H */
