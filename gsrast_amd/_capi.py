@@ -102,6 +102,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP library first (python -m gsrast_amd.build). "
                 "gsrast_amd has no CPU or PyTorch fallback.")
+        # PyTorch bundles its own libamdhip64.so.7; it must be the one already mapped when our
+        # library resolves that soname, otherwise two HIP runtimes end up in the process and
+        # torch's device pointers mean nothing to ours ("no HIP device").
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

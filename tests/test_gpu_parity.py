@@ -117,7 +117,7 @@ def test_single_instance_draws_nothing():
     """R == 1: identifyTileRanges never closes the only tile (GSCuda.cu:515-537)."""
     from gsrast_amd import camera
     from oracle import cpu_oracle
-    scene = single_gaussian_scene(pos=(0.02, 0.02, 0.0), scale=0.001, n=1)
+    scene = single_gaussian_scene(pos=(0.5178, -0.5178, 0.0), scale=0.001, n=1)   # lands mid-tile at pixel (40, 40)
     cam = camera.default_camera(64, 64)
     exp = cpu_oracle.forward(scene, cam, (0.2, 0.3, 0.4))
     assert exp["num_rendered"] == 1
