@@ -17,6 +17,7 @@ GSR_ERR_ALLOC = 2
 GSR_ERR_HIP = 3
 GSR_ERR_NO_DEVICE = 4
 GSR_ERR_TOO_LARGE = 5
+GSR_ERR_INTERNAL = 6
 
 GSR_FLAG_PROFILE = 0x1
 GSR_FLAG_COUNT_STAGED = 0x2
@@ -74,6 +75,7 @@ SIGNATURES = {
     "gsr_last_error": (C.c_int, []),
     "gsr_error_string": (C.c_char_p, [C.c_int]),
     "gsr_last_hip_error": (C.c_char_p, []),
+    "gsr_poll_async_error": (C.c_int, []),
     "gsr_higher_msb": (C.c_uint32, [C.c_uint32]),
     "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),
     "gsr_inclusive_scan_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

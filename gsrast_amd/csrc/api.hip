@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "gsr_common.hpp"
+#include "radix_sort.hpp"
 
 namespace gsr {
 
@@ -30,9 +31,52 @@ inline void obtain(char*& chunk, T*& out, size_t bytes, size_t align = 128) {
 
 inline int fail(int code) { g_last_error = code; return code; }
 
+inline size_t align128(size_t v) { return (v + 127) / 128 * 128; }
+
+// Layout of GeometryState::scanningSpace (the reference keeps CUB's scan temp there,
+// AuxBuffer.cu:49-51; this library keeps all of its per-Gaussian scratch there).
+struct GeoScratch {
+    char* scan_temp;          // partial sums of the two prefix scans
+    uint32_t* depth_key;      // u32[N] depth bits or ~0 (written by preprocess)
+    uint32_t *a_k, *a_v;      // depth-sort ping
+    uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
+    SweepScratch sweep;       // onesweep status words for the N-sized sort
+    size_t bytes;
+};
+GeoScratch carve_geo_scratch(char* base, size_t n) {
+    GeoScratch g;
+    size_t off = 0;
+    g.scan_temp = base + off; off += align128(scan_temp_bytes(n));
+    g.depth_key = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
+    g.bytes = off;
+    return g;
+}
+
+// Layout of BinningState::sortingSpace: one scratch copy of the pairs + onesweep status.
+struct BinScratch {
+    uint64_t* tmp_k;
+    uint32_t* tmp_v;
+    SweepScratch sweep;
+    size_t bytes;
+};
+BinScratch carve_bin_scratch(char* base, size_t r) {
+    BinScratch b;
+    size_t off = 0;
+    b.tmp_k = reinterpret_cast<uint64_t*>(base + off); off += align128(8 * r);
+    b.tmp_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * r);
+    b.sweep = carve_sweep_scratch(base + off, r); off += sweep_scratch_bytes(r);
+    b.bytes = off;
+    return b;
+}
+
 // Pinned 4-byte landing zone for the numRendered read-back, one per host thread.
 struct Readback {
-    uint32_t* host = nullptr;
+    uint32_t* host = nullptr;          // [0] numRendered, [1] / [2] onesweep error words, [8..] staged count
     unsigned long long* staged_dev = nullptr;
     unsigned long long* staged_host = nullptr;
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
@@ -68,7 +112,7 @@ extern "C" {
 char* gsr_geometry_from_chunk(char* chunk, int n, gsr_geometry_state* s) {
     const size_t N = (size_t)(n < 0 ? 0 : n);
     obtain(chunk, s->tiles_touched, sizeof(uint32_t) * N);
-    s->scan_size = scan_temp_bytes(N);
+    s->scan_size = carve_geo_scratch(nullptr, N).bytes;
     s->num_rendered = 0;
     obtain(chunk, s->scanning_space, s->scan_size);
     obtain(chunk, s->depths, sizeof(float) * N);
@@ -95,7 +139,7 @@ char* gsr_binning_from_chunk(char* chunk, size_t size, gsr_binning_state* s) {
     obtain(chunk, s->keys, sizeof(uint64_t) * size);
     obtain(chunk, s->values_unsorted, sizeof(uint32_t) * size);
     obtain(chunk, s->values, sizeof(uint32_t) * size);
-    s->sorting_size = sort_temp_bytes(size);
+    s->sorting_size = std::max(carve_bin_scratch(nullptr, size).bytes, sort_temp_bytes(size));
     obtain(chunk, s->sorting_space, s->sorting_size);
     return chunk;
 }
@@ -125,6 +169,7 @@ const char* gsr_error_string(int code) {
         case GSR_ERR_HIP: return "HIP runtime error";
         case GSR_ERR_NO_DEVICE: return "no HIP device";
         case GSR_ERR_TOO_LARGE: return "numRendered exceeds 32-bit offsets";
+        case GSR_ERR_INTERNAL: return "radix sort look-back gave up (bounded spin expired)";
         default: return "unknown error";
     }
 }
@@ -140,7 +185,12 @@ int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const ui
                            uint32_t* values_out, size_t n, int end_bit, char* temp, void* stream) {
     g_hip_error[0] = 0;
     if (n && (!keys_in || !keys_out || !values_in || !values_out || !temp)) return fail(GSR_ERR_INVALID_ARG);
-    return fail(launch_sort_pairs(keys_in, keys_out, values_in, values_out, n, end_bit, temp, (hipStream_t)stream));
+    return fail(launch_sort_pairs(keys_in, keys_out, values_in, values_out, n, 0, end_bit, temp, (hipStream_t)stream));
+}
+
+int gsr_poll_async_error(void) {
+    if (g_rb.host && (g_rb.host[1] || g_rb.host[2])) return fail(GSR_ERR_INTERNAL);
+    return GSR_OK;
 }
 
 int gsr_forward(gsr_forward_args* a) {
@@ -198,12 +248,15 @@ int gsr_forward(gsr_forward_args* a) {
 #define GSR_END(s) do { if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * (s) + 1], stream)); } while (0)
 #define GSR_STEP(call) do { rc = (call); if (rc != GSR_OK) return fail(rc); } while (0)
 
+    const GeoScratch gs = carve_geo_scratch(geom.scanning_space, (size_t)n);
+    g_rb.host[1] = g_rb.host[2] = 0;
+
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
-    GSR_STEP(launch_preprocess(*a, geom, radii, d, stream));                               // :744-768
+    GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, d, stream));                 // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
-                                   geom.scanning_space, stream));
+                                   gs.scan_temp, stream));
     GSR_END(GSR_STAGE_SCAN);
     // :772 — the pipeline's one device->host sync: the binning chunk is sized by R.
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -216,14 +269,48 @@ int gsr_forward(gsr_forward_args* a) {
     if (!bin_chunk) return fail(GSR_ERR_ALLOC);
     gsr_binning_state bin;
     gsr_binning_from_chunk(bin_chunk, R, &bin);
+    const BinScratch bs = carve_bin_scratch(bin.sorting_space, R);
 
+    // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
+    // half is the same for every key of a Gaussian, so those digit passes run once per
+    // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
     GSR_BEGIN(GSR_STAGE_DUPLICATE);
-    GSR_STEP(launch_duplicate(n, geom, radii, a->rects, d, bin.keys_unsorted, bin.values_unsorted, stream));   // :787
+    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
+    GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, sizeof(uint32_t), stream));
+    GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
+    GSR_STEP(launch_gather_counts(n, gs.b_k, gs.b_v, geom.tiles_touched, gs.a_k, stream));
+    GSR_STEP(launch_inclusive_scan(gs.a_k, gs.a_k, (size_t)n, gs.scan_temp, stream));
+    const bool xy_plan = d.grid_x <= 256 && d.grid_y <= 256;
+    uint32_t* hist_x = xy_plan ? bs.sweep.hist : nullptr;
+    uint32_t* hist_y = xy_plan ? bs.sweep.hist + 256 : nullptr;
+    if (xy_plan) GSR_HIP_TRY(hipMemsetAsync(bs.sweep.hist, 0, 512 * sizeof(uint32_t), stream));
+    GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, a->rects, d, bin.keys_unsorted,
+                              bin.values_unsorted, hist_x, hist_y, stream));               // :787
     GSR_END(GSR_STAGE_DUPLICATE);
-    const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                     // :791
+
     GSR_BEGIN(GSR_STAGE_SORT);
-    GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, end_bit,
-                               bin.sorting_space, stream));                                // :794-797
+    if (xy_plan) {
+        // tile = y * grid_x + x: a stable pass on x then one on y orders by tile id.
+        DigitSpec sx, sy;
+        sx.mode = kDigitTileX; sx.shift = 0; sx.nbins = (uint32_t)d.grid_x; sx.grid_x = (uint32_t)d.grid_x;
+        sx.magic = (uint32_t)(0x100000000ull / (uint32_t)d.grid_x) + 1u;
+        sy = sx; sy.mode = kDigitTileY; sy.nbins = (uint32_t)d.grid_y;
+        const bool px = d.grid_x > 1, py = d.grid_y > 1;
+        if (px && py) {
+            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bs.tmp_k, bs.tmp_v, R, sx, hist_x, bs.sweep, stream));
+            GSR_STEP(sweep_pass_u64(bs.tmp_k, bs.tmp_v, bin.keys, bin.values, R, sy, hist_y, bs.sweep, stream));
+        } else if (px || py) {
+            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, px ? sx : sy,
+                                    px ? hist_x : hist_y, bs.sweep, stream));
+        } else {
+            GSR_HIP_TRY(hipMemcpyAsync(bin.keys, bin.keys_unsorted, 8 * (size_t)R, hipMemcpyDeviceToDevice, stream));
+            GSR_HIP_TRY(hipMemcpyAsync(bin.values, bin.values_unsorted, 4 * (size_t)R, hipMemcpyDeviceToDevice, stream));
+        }
+    } else {
+        const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
+        GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, 32, end_bit,
+                                   bin.sorting_space, stream));
+    }
     GSR_END(GSR_STAGE_SORT);
     GSR_BEGIN(GSR_STAGE_RANGES);
     GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, stream));              // :800-801
@@ -236,6 +323,8 @@ int gsr_forward(gsr_forward_args* a) {
                           stream));                                                        // :804-810
     GSR_END(GSR_STAGE_BLEND);
 
+    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 1, gs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 2, bs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (profile || count_staged) {
         if (count_staged)
             GSR_HIP_TRY(hipMemcpyAsync(g_rb.staged_host, g_rb.staged_dev, sizeof(unsigned long long),

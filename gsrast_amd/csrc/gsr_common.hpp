@@ -40,17 +40,23 @@ struct FrameDims {
 
 // ---- stage launchers (each asynchronous on `stream`) ----
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      const FrameDims& d, hipStream_t stream);
+                      uint32_t* depth_keys, const FrameDims& d, hipStream_t stream);
 
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
 size_t scan_temp_bytes(size_t n);
 
-int launch_duplicate(int n, const gsr_geometry_state& g, const int32_t* radii, const int32_t* rects,
-                     const FrameDims& d, uint64_t* keys, uint32_t* values, hipStream_t stream);
+int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,
+                         uint32_t* counts, hipStream_t stream);
+int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* emit_end,
+                     const gsr_geometry_state& g, const int32_t* radii, const int32_t* rects, const FrameDims& d,
+                     uint64_t* keys, uint32_t* values, uint32_t* hist_x, uint32_t* hist_y, hipStream_t stream);
 
 int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
-                      uint32_t* values_out, size_t n, int end_bit, char* temp, hipStream_t stream);
+                      uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream);
 size_t sort_temp_bytes(size_t n);
+struct SweepScratch;
+int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
+                         const SweepScratch& sc, hipStream_t stream);
 
 int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, hipStream_t stream);
 

@@ -77,6 +77,7 @@ struct PreprocessParams {
     float* rgb;
     float4* conic_opacity;
     uint32_t* tiles_touched;
+    uint32_t* depth_keys;          // depth bits of Gaussians with >= 1 tile in this call, else ~0
     int2* rects;
     FrameDims dims;
 };
@@ -198,12 +199,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     }
     p.radii[idx] = out_radius;
     p.tiles_touched[idx] = out_tiles;
+    p.depth_keys[idx] = out_tiles ? __float_as_uint(prz) : 0xFFFFFFFFu;
 }
 
 }  // namespace
 
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      const FrameDims& d, hipStream_t stream) {
+                      uint32_t* depth_keys, const FrameDims& d, hipStream_t stream) {
     PreprocessParams p;
     p.n = a.num_gaussians;
     p.means3D = reinterpret_cast<const float4*>(a.means3D);
@@ -226,6 +228,7 @@ int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, in
     p.rgb = g.rgb;
     p.conic_opacity = reinterpret_cast<float4*>(g.conic_opacity);
     p.tiles_touched = g.tiles_touched;
+    p.depth_keys = depth_keys;
     p.rects = reinterpret_cast<int2*>(a.rects);
     p.dims = d;
     const unsigned blocks = (unsigned)((a.num_gaussians + 255) / 256);

@@ -1,115 +1,105 @@
-// Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit)
-// (replaces cub::DeviceRadixSort::SortPairs at reference GSCuda.cu:794-797; no CUB /
-// hipCUB / rocPRIM). 8-bit digits, 4096-key tiles, all ranking state in LDS.
+// Onesweep LSD radix sort, LDS-staged, written for gfx950 (no CUB / hipCUB / rocPRIM).
+// Replaces cub::DeviceRadixSort::SortPairs at reference GSCuda.cu:794-797.
 //
-// Per digit pass:
-//   digit_histogram_kernel : tile -> 256-bin digit counts (LDS atomics) -> global, digit-major
-//   (inclusive scan of the digit-major table: scan.hip)
-//   scatter_kernel         : tile re-read; stable ranks from wave64 __ballot match groups +
-//                            per-wave LDS counters; keys/values permuted through LDS so each
-//                            digit run leaves as one contiguous burst; scattered to
-//                            table[digit][tile] + position in run.
-// Stability: a tile's keys are ranked in (wave, item, lane) order, which is their index
-// order, and tiles are laid out in index order by the digit-major scan — so equal keys keep
-// ascending input order (the tie rule SURVEY.md §8a row a9 requires).
-// The input arrays are never written: pass 1 reads them and the remaining passes ping-pong
-// between the output arrays and a scratch copy inside `temp`.
+// One kernel launch per digit pass moves every key exactly once (12 B read + 12 B written
+// per u64/u32 pair): a workgroup takes the next 4096-key tile from an atomic ticket, ranks
+// its keys in LDS, publishes its per-digit counts and resolves its global offsets by
+// decoupled look-back over the tiles before it, then writes each digit's run as one
+// contiguous burst. Digit histograms of all passes come from one up-front read of the keys
+// (or, for the tile passes of the frame pipeline, analytically from the Gaussians'
+// rectangles — binning.hip — with no key traffic at all).
+//
+// Ranking: wave64 __ballot match groups + one LDS counter per (wave, digit); a tile's keys
+// are ranked in (wave, item, lane) order = index order, and tiles are ordered by ticket, so
+// the sort is stable (equal keys keep ascending input order).
+//
+// Cross-workgroup protocol: only the 64-bit status words travel between workgroups, each
+// written by ONE relaxed agent-scope atomic store and read by relaxed agent-scope atomic
+// loads (data-is-the-flag granules, cdna_hip_programming.md Guideline 16 R2); no payload is
+// exchanged inside the launch, so no fences are needed. Tickets make predecessors resident
+// before their successors; every spin is bounded and raises an error word instead of hanging.
 #include "gsr_common.hpp"
+#include "radix_sort.hpp"
 
 namespace gsr {
 namespace {
 
-constexpr int kBits = 8;
-constexpr int kRadix = 1 << kBits;
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kItems = 16;                              // keys per lane
+constexpr int kItems = 16;
 constexpr int kSortTile = kThreads * kItems;            // 4096 keys per workgroup
-constexpr int kWaveSpan = kWave * kItems;               // 1024 consecutive keys per wave
+constexpr int kWaveSpan = kWave * kItems;
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift) {
-    return (uint32_t)(key >> shift) & (uint32_t)(kRadix - 1);
+constexpr unsigned long long kFlagAggregate = 1ull << 62;
+constexpr unsigned long long kFlagPrefix = 2ull << 62;
+constexpr unsigned long long kValueMask = (1ull << 62) - 1ull;
+constexpr uint32_t kSpinLimit = 1u << 24;
+
+template <typename KeyT>
+__device__ __forceinline__ uint32_t digit_of(KeyT key, const DigitSpec& s) {
+    if (s.mode == kDigitBits) return (uint32_t)(key >> s.shift) & (s.nbins - 1u);
+    const uint32_t tile = (uint32_t)((unsigned long long)key >> 32);
+    const uint32_t y = __umulhi(tile, s.magic);
+    return s.mode == kDigitTileX ? tile - y * s.grid_x : y;
 }
 
-__global__ __launch_bounds__(kThreads) void digit_histogram_kernel(const uint64_t* __restrict__ keys, size_t n, int shift,
-                                                                    uint32_t* __restrict__ table, uint32_t num_tiles) {
-    __shared__ uint32_t hist[kRadix];
-    hist[threadIdx.x] = 0;
+// ---- histograms of all bit-field passes from one read of the keys -----------------------
+template <typename KeyT>
+__global__ __launch_bounds__(kThreads) void histogram_bits_kernel(const KeyT* __restrict__ keys, size_t n, int passes,
+                                                                   int first_shift, int end_bit, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lds[8 * 256];
+    for (int i = threadIdx.x; i < passes * 256; i += kThreads) lds[i] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * kSortTile;
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const size_t e = base + (size_t)i * kThreads + threadIdx.x;
-        if (e < n) atomicAdd(&hist[digit_of(keys[e], shift)], 1u);
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride) {
+        const KeyT k = keys[e];
+        for (int p = 0; p < passes; ++p) {
+            const int shift = first_shift + 8 * p;
+            const uint32_t mask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
+            atomicAdd(&lds[p * 256 + ((uint32_t)(k >> shift) & mask)], 1u);
+        }
     }
     __syncthreads();
-    table[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
+    for (int i = threadIdx.x; i < passes * 256; i += kThreads)
+        if (lds[i]) atomicAdd(&hist[i], lds[i]);
 }
 
-__global__ __launch_bounds__(kThreads) void scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                            size_t n, int shift, const uint32_t* __restrict__ table_incl,
-                                                            uint32_t num_tiles) {
-    __shared__ uint32_t wave_hist[kWaves][kRadix];
-    __shared__ uint32_t run_start[kRadix];      // first position of digit d inside the sorted tile
-    __shared__ uint32_t global_start[kRadix];   // first output index of this tile's digit-d run
+// ---- one digit pass ----------------------------------------------------------------------
+template <typename KeyT, int BITS>
+__global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                            KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint32_t n, const DigitSpec spec,
+                                                            const uint32_t* __restrict__ digit_hist,
+                                                            unsigned long long* status, uint32_t* ticket,
+                                                            uint32_t* error_word) {
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint32_t wave_hist[kWaves][RADIX];
+    __shared__ uint32_t run_start[RADIX];        // first slot of digit d inside the ranked tile
+    __shared__ uint32_t global_start[RADIX];     // output index of this tile's first digit-d key
     __shared__ uint32_t scan_ws[kWaves];
-    __shared__ uint64_t stage_keys[kSortTile];
-    __shared__ uint32_t stage_vals[kSortTile];
+    __shared__ uint32_t s_tile, s_fail;
+    __shared__ unsigned long long stage[kSortTile];   // keys, then (re-used) values
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const size_t tile_base = (size_t)blockIdx.x * kSortTile;
-    const uint32_t valid = (uint32_t)((n - tile_base < (size_t)kSortTile) ? (n - tile_base) : (size_t)kSortTile);
-
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) wave_hist[w][threadIdx.x] = 0;
-    {   // exclusive global offsets of this tile's runs, from the inclusive digit-major scan
-        const size_t cell = (size_t)threadIdx.x * num_tiles + blockIdx.x;
-        global_start[threadIdx.x] = (cell == 0) ? 0u : table_incl[cell - 1];
+    if (threadIdx.x == 0) {
+        s_tile = atomicAdd(ticket, 1u);
+        s_fail = 0;
     }
-
-    uint64_t key[kItems];
-    uint32_t rank[kItems];
+    if (threadIdx.x < RADIX) {
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        key[i] = (local < valid) ? keys_in[tile_base + local] : ~0ull;   // padding ranks last in the top digit
+        for (int w = 0; w < kWaves; ++w) wave_hist[w][threadIdx.x] = 0;
     }
     __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t tile_base = tile * (uint32_t)kSortTile;
+    if (tile_base >= n) return;                  // cannot happen with grid = ceil(n / tile)
+    const uint32_t valid = min((uint32_t)kSortTile, n - tile_base);
 
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t d = digit_of(key[i], shift);
-        unsigned long long peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < kBits; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
-        uint32_t prior = 0;
-        if (below == 0) {                       // lowest lane of the match group owns the counter
-            prior = wave_hist[wave][d];
-            wave_hist[wave][d] = prior + (uint32_t)__popcll(peers);
-        }
-        prior = __shfl(prior, __ffsll((long long)peers) - 1, kWave);
-        rank[i] = prior + below;
-    }
-    __syncthreads();
-
-    {   // per digit: exclusive offsets across waves, then across digits
-        const int d = threadIdx.x;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t c = wave_hist[w][d];
-            wave_hist[w][d] = acc;
-            acc += c;
-        }
-        // block exclusive scan of acc over the 256 digits
-        uint32_t incl = acc;
+    // exclusive scan of the global digit histogram -> first output index of every digit
+    uint32_t digit_base = 0;
+    {
+        const uint32_t c = (threadIdx.x < spec.nbins) ? digit_hist[threadIdx.x] : 0u;
+        uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, kWave);
@@ -121,85 +111,274 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const uint64_t* __res
 #pragma unroll
         for (int w = 0; w < kWaves; ++w)
             if (w < wave) wbase += scan_ws[w];
-        run_start[d] = wbase + incl - acc;
+        digit_base = wbase + incl - c;
+        __syncthreads();
     }
-    __syncthreads();
 
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t d = digit_of(key[i], shift);
-        rank[i] += run_start[d] + wave_hist[wave][d];
-        stage_keys[rank[i]] = key[i];
-    }
+    KeyT key[kItems];
+    uint32_t dig[kItems];
+    uint32_t rank[kItems];
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        if (local < valid) stage_vals[rank[i]] = vals_in[tile_base + local];
+        key[i] = (local < valid) ? keys_in[tile_base + local] : (KeyT)0;
+    }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+        // padding of the last tile ranks after every real key: top digit, highest indices
+        const uint32_t d = (local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1);
+        dig[i] = d;
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+        uint32_t prior = 0;
+        if (below == 0) {
+            prior = wave_hist[wave][d];
+            wave_hist[wave][d] = prior + (uint32_t)__popcll(peers);
+        }
+        prior = __shfl(prior, __ffsll((long long)peers) - 1, kWave);
+        rank[i] = prior + below;
     }
     __syncthreads();
 
+    // per digit: counts -> exclusive offsets across waves and across digits; publish; look back
+    if (threadIdx.x < RADIX) {
+        const int d = threadIdx.x;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t c = wave_hist[w][d];
+            wave_hist[w][d] = acc;
+            acc += c;
+        }
+        run_start[d] = acc;                      // count for now; scanned below
+        // Padding keys were counted in the top digit: they must not be published.
+        uint32_t real = acc;
+        if (d == RADIX - 1) real -= ((uint32_t)kSortTile - valid);
+        if ((uint32_t)d < spec.nbins) {
+            unsigned long long* cell = status + (size_t)tile * RADIX + d;
+            if (tile == 0) {
+                __hip_atomic_store(cell, kFlagPrefix | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                global_start[d] = digit_base;
+            } else {
+                __hip_atomic_store(cell, kFlagAggregate | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long excl = 0;
+                uint32_t t = tile - 1, spins = 0;
+                for (;;) {
+                    const unsigned long long s = __hip_atomic_load(status + (size_t)t * RADIX + d, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long f = s & ~kValueMask;
+                    if (f == 0) {
+                        if (++spins > kSpinLimit) { s_fail = 1; atomicExch(error_word, 1u); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    excl += s & kValueMask;
+                    if (f == kFlagPrefix) break;
+                    --t;                         // tile 0 always carries kFlagPrefix
+                }
+                __hip_atomic_store(cell, kFlagPrefix | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                global_start[d] = digit_base + (uint32_t)excl;
+            }
+        } else {
+            global_start[d] = 0;
+        }
+    }
+    __syncthreads();
+    if (s_fail) return;
+
+    // exclusive scan of the tile's digit counts (RADIX <= 256 values, one per thread)
+    {
+        const uint32_t c = (threadIdx.x < RADIX) ? run_start[threadIdx.x] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        if (lane == kWave - 1) scan_ws[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w)
+            if (w < wave) wbase += scan_ws[w];
+        if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - c;
+    }
+    __syncthreads();
+
+    KeyT* stage_keys = reinterpret_cast<KeyT*>(stage);
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        rank[i] += run_start[dig[i]] + wave_hist[wave][dig[i]];
+        stage_keys[rank[i]] = key[i];
+    }
+    __syncthreads();
+    uint32_t dst[kItems];
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t p = (uint32_t)(i * kThreads) + threadIdx.x;
+        dst[i] = 0xFFFFFFFFu;
         if (p < valid) {
-            const uint64_t k = stage_keys[p];
-            const uint32_t d = digit_of(k, shift);
-            const size_t dst = (size_t)global_start[d] + (p - run_start[d]);
-            keys_out[dst] = k;
-            vals_out[dst] = stage_vals[p];
+            const KeyT k = stage_keys[p];
+            const uint32_t d = digit_of<KeyT>(k, spec);
+            dst[i] = global_start[d] + (p - run_start[d]);
+            if (dst[i] < n) keys_out[dst[i]] = k;
         }
+    }
+    __syncthreads();
+    uint32_t* stage_vals = reinterpret_cast<uint32_t*>(stage);
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+        if (local < valid) stage_vals[rank[i]] = vals_in ? vals_in[tile_base + local] : tile_base + local;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const uint32_t p = (uint32_t)(i * kThreads) + threadIdx.x;
+        if (p < valid && dst[i] < n) vals_out[dst[i]] = stage_vals[p];
     }
 }
 
-struct SortTemp {
-    uint64_t* keys;
-    uint32_t* vals;
-    uint32_t* table;
-    char* scan_temp;
-    size_t bytes;
-};
+template <typename KeyT>
+int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
+                const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream) {
+    int bits = 1;
+    while ((1u << bits) < spec.nbins) ++bits;
+    if (bits > 8) return GSR_ERR_INVALID_ARG;
+    if (bits < 4) bits = 4;
+    const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
+    const size_t status_bytes = (size_t)tiles * ((size_t)1 << bits) * sizeof(unsigned long long);
+    GSR_HIP_TRY(hipMemsetAsync(sc.status, 0, status_bytes, stream));
+    GSR_HIP_TRY(hipMemsetAsync(sc.ticket, 0, sizeof(uint32_t), stream));
+#define GSR_SWEEP(B)                                                                                              \
+    hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in,     \
+                       keys_out, vals_out, n, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
+    switch (bits) {
+        case 4: GSR_SWEEP(4); break;
+        case 5: GSR_SWEEP(5); break;
+        case 6: GSR_SWEEP(6); break;
+        case 7: GSR_SWEEP(7); break;
+        default: GSR_SWEEP(8); break;
+    }
+#undef GSR_SWEEP
+    GSR_LAUNCH_CHECK("onesweep_kernel");
+    return GSR_OK;
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-SortTemp carve_sort_temp(char* base, size_t n) {
-    const size_t tiles = (n + kSortTile - 1) / kSortTile;
-    size_t off = 0;
-    SortTemp t;
-    t.keys = reinterpret_cast<uint64_t*>(base + off); off = align_up(off + n * sizeof(uint64_t), 128);
-    t.vals = reinterpret_cast<uint32_t*>(base + off); off = align_up(off + n * sizeof(uint32_t), 128);
-    t.table = reinterpret_cast<uint32_t*>(base + off); off = align_up(off + tiles * kRadix * sizeof(uint32_t), 128);
-    t.scan_temp = base + off; off = align_up(off + scan_temp_bytes(tiles * kRadix), 128);
-    t.bytes = off;
-    return t;
-}
-
 }  // namespace
 
-size_t sort_temp_bytes(size_t n) { return carve_sort_temp(nullptr, n).bytes; }
+size_t sweep_scratch_bytes(size_t n) {
+    const size_t tiles = (n + kSortTile - 1) / kSortTile;
+    return align_up(tiles * 256 * sizeof(unsigned long long), 128) + 128 /*ticket*/ + 128 /*error*/ +
+           align_up(8 * 256 * sizeof(uint32_t), 128);
+}
 
-int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
-                      uint32_t* values_out, size_t n, int end_bit, char* temp, hipStream_t stream) {
+SweepScratch carve_sweep_scratch(char* base, size_t n) {
+    const size_t tiles = (n + kSortTile - 1) / kSortTile;
+    SweepScratch s;
+    size_t off = 0;
+    s.status = reinterpret_cast<unsigned long long*>(base + off); off += align_up(tiles * 256 * sizeof(unsigned long long), 128);
+    s.ticket = reinterpret_cast<uint32_t*>(base + off); off += 128;
+    s.error_word = reinterpret_cast<uint32_t*>(base + off); off += 128;
+    s.hist = reinterpret_cast<uint32_t*>(base + off); off += align_up(8 * 256 * sizeof(uint32_t), 128);
+    return s;
+}
+
+int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t n,
+                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream) {
+    return launch_pass<unsigned long long>(reinterpret_cast<const unsigned long long*>(keys_in), vals_in,
+                                           reinterpret_cast<unsigned long long*>(keys_out), vals_out, n, spec, digit_hist, sc, stream);
+}
+
+int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream) {
+    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream);
+}
+
+template <typename KeyT>
+static int histogram_bits(const KeyT* keys, size_t n, int first_shift, int end_bit, uint32_t* hist, hipStream_t stream) {
+    const int passes = (end_bit - first_shift + 7) / 8;
+    if (passes < 1 || passes > 8) return GSR_ERR_INVALID_ARG;
+    GSR_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)passes * 256 * sizeof(uint32_t), stream));
+    const unsigned blocks = (unsigned)std::min<size_t>((n + kSortTile - 1) / kSortTile, 2048);
+    hipLaunchKernelGGL((histogram_bits_kernel<KeyT>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, stream, keys, n, passes,
+                       first_shift, end_bit, hist);
+    GSR_LAUNCH_CHECK("histogram_bits_kernel");
+    return GSR_OK;
+}
+
+int histogram_bits_u32(const uint32_t* keys, size_t n, int begin_bit, int end_bit, uint32_t* hist, hipStream_t stream) {
+    return histogram_bits<uint32_t>(keys, n, begin_bit, end_bit, hist, stream);
+}
+int histogram_bits_u64(const uint64_t* keys, size_t n, int begin_bit, int end_bit, uint32_t* hist, hipStream_t stream) {
+    return histogram_bits<unsigned long long>(reinterpret_cast<const unsigned long long*>(keys), n, begin_bit, end_bit, hist, stream);
+}
+
+// ---- depth order: stable sort of N u32 keys carrying their own index ---------------------
+// in -> a -> b -> a -> b : the result (sorted keys, original indices) is in (b_k, b_v).
+int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
+                         const SweepScratch& sc, hipStream_t stream) {
     if (n == 0) return GSR_OK;
-    if (end_bit <= 0) end_bit = 1;
+    int rc = histogram_bits_u32(keys_in, n, 0, 32, sc.hist, stream);
+    if (rc != GSR_OK) return rc;
+    const uint32_t* src_k = keys_in;
+    const uint32_t* src_v = nullptr;
+    for (int p = 0; p < 4; ++p) {
+        uint32_t* dst_k = (p % 2 == 0) ? a_k : b_k;
+        uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
+        DigitSpec spec;
+        spec.mode = kDigitBits; spec.shift = 8 * p; spec.nbins = 256; spec.grid_x = 1; spec.magic = 0;
+        rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc.hist + 256 * p, sc, stream);
+        if (rc != GSR_OK) return rc;
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    return GSR_OK;
+}
+
+// ---- generic entry: stable sort of (u64, u32) pairs on key bits [0, end_bit) -------------
+size_t sort_temp_bytes(size_t n) {
+    return align_up(n * sizeof(uint64_t), 128) + align_up(n * sizeof(uint32_t), 128) + sweep_scratch_bytes(n);
+}
+
+int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in, uint32_t* values_out,
+                      size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream) {
+    if (n == 0) return GSR_OK;
+    if (n >= 0xFFFFFFFFull) return GSR_ERR_TOO_LARGE;
     if (end_bit > 64) end_bit = 64;
-    const int passes = (end_bit + kBits - 1) / kBits;
-    const SortTemp t = carve_sort_temp(temp, n);
-    const uint32_t tiles = (uint32_t)((n + kSortTile - 1) / kSortTile);
+    if (begin_bit < 0) begin_bit = 0;
+    if (end_bit <= begin_bit) end_bit = begin_bit + 1;
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    uint64_t* tmp_k = reinterpret_cast<uint64_t*>(temp);
+    uint32_t* tmp_v = reinterpret_cast<uint32_t*>(temp + align_up(n * sizeof(uint64_t), 128));
+    const SweepScratch sc = carve_sweep_scratch(temp + align_up(n * sizeof(uint64_t), 128) + align_up(n * sizeof(uint32_t), 128), n);
+    GSR_HIP_TRY(hipMemsetAsync(sc.error_word, 0, sizeof(uint32_t), stream));
+    int rc = histogram_bits_u64(keys_in, n, begin_bit, end_bit, sc.hist, stream);
+    if (rc != GSR_OK) return rc;
     const uint64_t* src_k = keys_in;
     const uint32_t* src_v = values_in;
     for (int p = 0; p < passes; ++p) {
-        // The last pass must land in the output arrays: odd distance from the end -> scratch.
-        const bool to_out = ((passes - 1 - p) % 2) == 0;
-        uint64_t* dst_k = to_out ? keys_out : t.keys;
-        uint32_t* dst_v = to_out ? values_out : t.vals;
-        const int shift = p * kBits;
-        hipLaunchKernelGGL(digit_histogram_kernel, dim3(tiles), dim3(kThreads), 0, stream, src_k, n, shift, t.table, tiles);
-        GSR_LAUNCH_CHECK("digit_histogram_kernel");
-        const int rc = launch_inclusive_scan(t.table, t.table, (size_t)tiles * kRadix, t.scan_temp, stream);
+        const bool to_out = ((passes - 1 - p) % 2) == 0;     // the last pass lands in the outputs
+        uint64_t* dst_k = to_out ? keys_out : tmp_k;
+        uint32_t* dst_v = to_out ? values_out : tmp_v;
+        DigitSpec spec;
+        spec.mode = kDigitBits;
+        spec.shift = begin_bit + 8 * p;
+        spec.nbins = 1u << std::min(8, end_bit - spec.shift);
+        spec.grid_x = 1;
+        spec.magic = 0;
+        rc = sweep_pass_u64(src_k, src_v, dst_k, dst_v, (uint32_t)n, spec, sc.hist + 256 * p, sc, stream);
         if (rc != GSR_OK) return rc;
-        hipLaunchKernelGGL(scatter_kernel, dim3(tiles), dim3(kThreads), 0, stream, src_k, src_v, dst_k, dst_v, n, shift,
-                           t.table, tiles);
-        GSR_LAUNCH_CHECK("scatter_kernel");
         src_k = dst_k;
         src_v = dst_v;
     }

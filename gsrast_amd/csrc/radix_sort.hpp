@@ -1,0 +1,45 @@
+// Internal interface of the onesweep radix sort (radix_sort.hip).
+#pragma once
+#include <algorithm>
+
+#include "gsr_common.hpp"
+
+namespace gsr {
+
+enum { kDigitBits = 0, kDigitTileX = 1, kDigitTileY = 2 };
+
+// How a pass takes its digit out of a key.
+//   kDigitBits : (key >> shift) & (nbins - 1), nbins a power of two
+//   kDigitTileX: (key >> 32) % grid_x      kDigitTileY: (key >> 32) / grid_x
+// (magic = 2^32 / grid_x + 1; exact while tile * grid_x < 2^32)
+struct DigitSpec {
+    int mode;
+    int shift;
+    uint32_t nbins;      // <= 256
+    uint32_t grid_x;
+    uint32_t magic;
+};
+
+struct SweepScratch {
+    unsigned long long* status;   // tiles x radix look-back words
+    uint32_t* ticket;
+    uint32_t* error_word;         // set to 1 if a bounded spin ever gave up
+    uint32_t* hist;               // 8 x 256 digit counts
+};
+
+size_t sweep_scratch_bytes(size_t n);
+SweepScratch carve_sweep_scratch(char* base, size_t n);
+
+// One stable digit pass. digit_hist: nbins raw counts of this pass's digit over all n keys.
+// vals_in == nullptr means "value = input index".
+int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t n,
+                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream);
+int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
+                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream);
+
+// Digit counts of `passes` consecutive 8-bit fields starting at begin_bit (the last one
+// narrowed so that no bit at or above end_bit takes part), from one read of the keys.
+int histogram_bits_u32(const uint32_t* keys, size_t n, int begin_bit, int end_bit, uint32_t* hist, hipStream_t stream);
+int histogram_bits_u64(const uint64_t* keys, size_t n, int begin_bit, int end_bit, uint32_t* hist, hipStream_t stream);
+
+}  // namespace gsr

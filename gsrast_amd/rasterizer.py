@@ -145,6 +145,7 @@ class SplatRasterizer:
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()
+            _capi.check(self.lib.gsr_poll_async_error(), "gsr_forward (device side)")
         return self.out_color
 
     # -- state inspection (what the reference's Inspector does through fromChunk) ------

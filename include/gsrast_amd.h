@@ -32,7 +32,8 @@ enum {
     GSR_ERR_ALLOC = 2,         /* an allocator callback returned NULL                      */
     GSR_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed               */
     GSR_ERR_NO_DEVICE = 4,     /* no gfx950 device visible                                 */
-    GSR_ERR_TOO_LARGE = 5      /* numRendered does not fit the reference's u32 offsets     */
+    GSR_ERR_TOO_LARGE = 5,     /* numRendered does not fit the reference's u32 offsets     */
+    GSR_ERR_INTERNAL = 6       /* a bounded device-side wait expired (see gsr_poll_async_error) */
 };
 
 /* Chunk allocator: replaces std::function<char*(size_t)> (GSCuda.cuh:103-105). Must
@@ -149,6 +150,11 @@ int gsr_last_error(void);
 const char* gsr_error_string(int code);
 /* Text of the HIP error behind the last GSR_ERR_HIP ("" if none). */
 const char* gsr_last_hip_error(void);
+
+/* After the caller has synchronised the stream of the last gsr_forward call: GSR_OK, or
+ * GSR_ERR_INTERNAL if a radix-sort look-back wait expired during that call (the frame is
+ * then invalid). Mirrors the reference caller polling the sticky error after its sync. */
+int gsr_poll_async_error(void);
 
 /* getHigherMsb (GSCuda.cu:481-502): bits of the tile id that take part in the sort. */
 uint32_t gsr_higher_msb(uint32_t n);

@@ -50,8 +50,14 @@ def _compare_all(r, img, exp, n):
     assert r.last_num_rendered == exp["num_rendered"]
     if exp["num_rendered"] > 0:
         b = {k: v.cpu().numpy() for k, v in r.map_binning_state().items()}
-        assert np.array_equal(b["keys_unsorted"].view(np.uint64), exp["keys_unsorted"])
-        assert np.array_equal(b["values_unsorted"].view(np.uint32), exp["values_unsorted"])
+        # The HIP path emits the pairs in depth order (the depth half of the key is sorted per
+        # Gaussian before duplication), the reference in index order: same multiset of pairs.
+        ku, vu = b["keys_unsorted"].view(np.uint64), b["values_unsorted"].view(np.uint32)
+        o_g, o_e = np.lexsort((vu, ku)), np.lexsort((exp["values_unsorted"], exp["keys_unsorted"]))
+        assert np.array_equal(ku[o_g], exp["keys_unsorted"][o_e])
+        assert np.array_equal(vu[o_g], exp["values_unsorted"][o_e])
+        depth_half = (ku & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        assert bool((np.diff(depth_half) >= 0).all())
         assert np.array_equal(b["keys"].view(np.uint64), exp["keys"])
         assert np.array_equal(b["values"].view(np.uint32), exp["values"])
     im = {k: v.cpu().numpy() for k, v in r.map_image_state().items()}
