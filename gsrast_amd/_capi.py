@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgsrast_amd.so")
+# GSR_LIB_TAG selects a tuning build made with `python -m gsrast_amd.build --tag NAME` (experiments only).
+_TAG = os.environ.get("GSR_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, "lib", f"libgsrast_amd{'_' + _TAG if _TAG else ''}.so")
 
 GSR_OK = 0
 GSR_ERR_INVALID_ARG = 1
@@ -80,7 +82,7 @@ SIGNATURES = {
     "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),
     "gsr_inclusive_scan_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "gsr_sort_temp_bytes": (C.c_size_t, [C.c_size_t]),
-    "gsr_sort_pairs_u64_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+    "gsr_sort_pairs_u64_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p]),
 }
 

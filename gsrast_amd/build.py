@@ -20,7 +20,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -ffp-contract=off: the preprocess / blend arithmetic keeps the reference's float32 operation
 # order (no fused multiply-add), which is what makes integer outputs reproducible bit for bit.
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+COMMON = (["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+          + os.environ.get("GSR_DEFINES", "").split())      # tuning experiments: GSR_DEFINES="-DX=1 ..."
 
 
 def _sources():
@@ -33,8 +34,8 @@ def _headers_mtime() -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+def _compile(src: str, force: bool, obj_dir: str = OBJ_DIR) -> str:
+    obj = os.path.join(obj_dir, src[:-4] + ".o")
     spath = os.path.join(CSRC, src)
     stale = (force or not os.path.exists(obj) or os.path.getmtime(obj) < os.path.getmtime(spath)
              or os.path.getmtime(obj) < _headers_mtime())
@@ -48,21 +49,27 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, tag: str = "") -> str:
+    """tag: experiments only — builds lib/libgsrast_amd_<tag>.so from its own object directory
+    (always from scratch, with whatever GSR_DEFINES is set), selected at run time by GSR_LIB_TAG."""
+    obj_dir = OBJ_DIR + ("_" + tag if tag else "")
+    lib_path = LIB_PATH if not tag else os.path.join(LIB_DIR, f"libgsrast_amd_{tag}.so")
+    force = force or bool(tag)
+    os.makedirs(obj_dir, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, obj_dir), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if force or not os.path.exists(lib_path) or os.path.getmtime(lib_path) < newest:
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print("built", LIB_PATH)
-    return LIB_PATH
+        print("built", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    _tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
+    build(force="--force" in sys.argv, verbose=True, tag=_tag)

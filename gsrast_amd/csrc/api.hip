@@ -182,10 +182,10 @@ int gsr_inclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* te
 }
 size_t gsr_sort_temp_bytes(size_t n) { return sort_temp_bytes(n); }
 int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
-                           uint32_t* values_out, size_t n, int end_bit, char* temp, void* stream) {
+                           uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, void* stream) {
     g_hip_error[0] = 0;
     if (n && (!keys_in || !keys_out || !values_in || !values_out || !temp)) return fail(GSR_ERR_INVALID_ARG);
-    return fail(launch_sort_pairs(keys_in, keys_out, values_in, values_out, n, 0, end_bit, temp, (hipStream_t)stream));
+    return fail(launch_sort_pairs(keys_in, keys_out, values_in, values_out, n, begin_bit, end_bit, temp, (hipStream_t)stream));
 }
 
 int gsr_poll_async_error(void) {

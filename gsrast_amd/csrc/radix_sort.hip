@@ -24,16 +24,32 @@
 namespace gsr {
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef GSR_SWEEP_THREADS
+#define GSR_SWEEP_THREADS 512
+#endif
+#ifndef GSR_SWEEP_ITEMS
+#define GSR_SWEEP_ITEMS 8
+#endif
+#ifndef GSR_SWEEP_MIN_WAVES
+#define GSR_SWEEP_MIN_WAVES 1
+#endif
+constexpr int kThreads = GSR_SWEEP_THREADS;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kItems = 16;
-constexpr int kSortTile = kThreads * kItems;            // 4096 keys per workgroup
+constexpr int kItems = GSR_SWEEP_ITEMS;
+constexpr int kSortTile = kThreads * kItems;            // keys per workgroup
 constexpr int kWaveSpan = kWave * kItems;
 
 constexpr unsigned long long kFlagAggregate = 1ull << 62;
 constexpr unsigned long long kFlagPrefix = 2ull << 62;
 constexpr unsigned long long kValueMask = (1ull << 62) - 1ull;
-constexpr uint32_t kSpinLimit = 1u << 24;
+constexpr uint32_t kSpinLimit = 1u << 22;
+#ifndef GSR_LOOK_WINDOW
+#define GSR_LOOK_WINDOW 4
+#endif
+constexpr int kLookWindow = GSR_LOOK_WINDOW;
+#ifndef GSR_LOOK_LANES
+#define GSR_LOOK_LANES 1
+#endif
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t digit_of(KeyT key, const DigitSpec& s) {
@@ -65,22 +81,115 @@ __global__ __launch_bounds__(kThreads) void histogram_bits_kernel(const KeyT* __
 }
 
 // ---- one digit pass ----------------------------------------------------------------------
+// Diagnostic build only (-DGSR_SWEEP_STAMPS): lane 0 of every workgroup keeps the shader-clock
+// cycles of each phase and stores them once, at exit, into its own 128-byte slot of a debug
+// buffer placed behind the status words (memory no other code reads). No stamp executes in the
+// product build.
+#ifdef GSR_SWEEP_STAMPS
+#define GSR_STAMP(i)                                                                               \
+    do {                                                                                           \
+        if (threadIdx.x == 0) {                                                                    \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
+            dbg_[i] = now_ - stamp_;                                                               \
+            stamp_ = now_;                                                                         \
+        }                                                                                          \
+    } while (0)
+#else
+#define GSR_STAMP(i) do { } while (0)
+#endif
+
+// Look-back state of one digit group, resumable so that its round trips can be interleaved
+// with the ranking and staging work of the tile.
+template <int RADIX, int LPD>
+struct LookBack {
+    unsigned long long sw[kLookWindow];
+    unsigned long long excl = 0;
+    uint32_t t = 0;          // next predecessor to consume is t - 1
+    uint32_t spins = 0;
+    bool active = false;     // this lane takes part
+    bool found = false;
+    int d = 0, sub = 0;
+
+    __device__ __forceinline__ void issue(const unsigned long long* status) {
+#pragma unroll
+        for (int k = 0; k < kLookWindow; ++k) {
+            const uint32_t back = (uint32_t)(sub * kLookWindow + k);
+            const uint32_t tk = (t > back) ? t - 1 - back : 0u;
+            sw[k] = __hip_atomic_load(status + (size_t)tk * RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // Consumes the words of the round in flight, in tile order. Returns the tiles consumed.
+    __device__ __forceinline__ uint32_t consume(int lane) {
+        unsigned long long seg_sum = 0;
+        uint32_t seg_used = 0;
+        bool seg_found = false;
+#pragma unroll
+        for (int k = 0; k < kLookWindow; ++k) {
+            const uint32_t back = (uint32_t)(sub * kLookWindow + k);
+            if (!seg_found && seg_used == (uint32_t)k && t > back) {
+                const unsigned long long f = sw[k] & ~kValueMask;
+                if (f != 0) {
+                    seg_sum += sw[k] & kValueMask;
+                    seg_used = (uint32_t)k + 1;
+                    if (f == kFlagPrefix) seg_found = true;
+                }
+            }
+        }
+        uint32_t consumed = 0;
+        if (LPD == 1) {
+            excl += seg_sum;
+            consumed = seg_used;
+            found = seg_found;
+        } else {
+            const int group_lane0 = lane - sub;
+            bool open = true;
+#pragma unroll
+            for (int j = 0; j < LPD; ++j) {
+                const unsigned long long js = __shfl(seg_sum, group_lane0 + j, kWave);
+                const uint32_t ju = __shfl(seg_used, group_lane0 + j, kWave);
+                const int jf = __shfl((int)seg_found, group_lane0 + j, kWave);
+                if (open) {
+                    excl += js;
+                    consumed += ju;
+                    if (jf) { found = true; open = false; }
+                    else if (ju != (uint32_t)kLookWindow) open = false;
+                }
+            }
+        }
+        t -= min(consumed, t);                   // tile 0 always carries kFlagPrefix
+        return consumed;
+    }
+};
+
 template <typename KeyT, int BITS>
-__global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             uint32_t n, const DigitSpec spec,
                                                             const uint32_t* __restrict__ digit_hist,
                                                             unsigned long long* status, uint32_t* ticket,
                                                             uint32_t* error_word) {
     constexpr int RADIX = 1 << BITS;
+    constexpr int kLanesPerDigit = (kThreads / RADIX) < GSR_LOOK_LANES ? (kThreads / RADIX) : GSR_LOOK_LANES;
     __shared__ uint32_t wave_hist[kWaves][RADIX];
+    __shared__ uint32_t tile_hist[RADIX];        // digit counts of the tile (early, by LDS atomics)
     __shared__ uint32_t run_start[RADIX];        // first slot of digit d inside the ranked tile
     __shared__ uint32_t global_start[RADIX];     // output index of this tile's first digit-d key
     __shared__ uint32_t scan_ws[kWaves];
     __shared__ uint32_t s_tile, s_fail;
-    __shared__ unsigned long long stage[kSortTile];   // keys, then (re-used) values
+    __shared__ KeyT stage_keys[kSortTile];
+    __shared__ uint32_t stage_vals[kSortTile];
+#ifdef GSR_SWEEP_LDS_PAD
+    __shared__ uint32_t occupancy_pad[GSR_SWEEP_LDS_PAD / 4];   // tuning experiment: caps workgroups per CU
+    if (threadIdx.x == 0 && n == 0xFFFFFFFFu) occupancy_pad[0] = 1;
+#endif
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#ifdef GSR_SWEEP_STAMPS
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dbg_[i] = 0;
+#endif
     if (threadIdx.x == 0) {
         s_tile = atomicAdd(ticket, 1u);
         s_fail = 0;
@@ -88,18 +197,57 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
     if (threadIdx.x < RADIX) {
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) wave_hist[w][threadIdx.x] = 0;
+        tile_hist[threadIdx.x] = 0;
     }
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t tile_base = tile * (uint32_t)kSortTile;
     if (tile_base >= n) return;                  // cannot happen with grid = ceil(n / tile)
     const uint32_t valid = min((uint32_t)kSortTile, n - tile_base);
+    GSR_STAMP(0);   // ticket
+
+    // Issue every global load of the tile first (keys AND values): the HBM latency is paid once.
+    KeyT key[kItems];
+    uint32_t val[kItems];
+    uint32_t rd[kItems];                         // rank (low 16 bits) | digit (high 16 bits)
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+        key[i] = (local < valid) ? keys_in[tile_base + local] : (KeyT)0;
+    }
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+        val[i] = (local < valid && vals_in) ? vals_in[tile_base + local] : tile_base + local;
+    }
+    const uint32_t hist_c = (threadIdx.x < spec.nbins) ? digit_hist[threadIdx.x] : 0u;
+
+    // The tile's digit counts, as early as possible: successors only need these to walk past us.
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+        const uint32_t d = (local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1);
+        rd[i] = d << 16;
+        if (local < valid) atomicAdd(&tile_hist[d], 1u);
+    }
+    GSR_STAMP(1);   // load wait + tile histogram
+    __syncthreads();
+    if (threadIdx.x < spec.nbins)
+        __hip_atomic_store(status + (size_t)tile * RADIX + threadIdx.x,
+                           (tile == 0 ? kFlagPrefix : kFlagAggregate) | tile_hist[threadIdx.x], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+
+    // Decoupled look-back: first round issued now, consumed after the ranking below.
+    LookBack<RADIX, kLanesPerDigit> lb;
+    lb.d = threadIdx.x / kLanesPerDigit;
+    lb.sub = threadIdx.x % kLanesPerDigit;
+    lb.t = tile;
+    lb.active = tile != 0 && threadIdx.x < RADIX * kLanesPerDigit && (uint32_t)lb.d < spec.nbins;
+    if (lb.active) lb.issue(status);
 
     // exclusive scan of the global digit histogram -> first output index of every digit
-    uint32_t digit_base = 0;
     {
-        const uint32_t c = (threadIdx.x < spec.nbins) ? digit_hist[threadIdx.x] : 0u;
-        uint32_t incl = c;
+        uint32_t incl = hist_c;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, kWave);
@@ -111,25 +259,16 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
 #pragma unroll
         for (int w = 0; w < kWaves; ++w)
             if (w < wave) wbase += scan_ws[w];
-        digit_base = wbase + incl - c;
+        if (threadIdx.x < RADIX) global_start[threadIdx.x] = wbase + incl - hist_c;
         __syncthreads();
     }
+    GSR_STAMP(2);   // publish + digit-base scan
 
-    KeyT key[kItems];
-    uint32_t dig[kItems];
-    uint32_t rank[kItems];
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        key[i] = (local < valid) ? keys_in[tile_base + local] : (KeyT)0;
-    }
+    // stable ranks: wave64 match groups + per-wave LDS counters
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        // padding of the last tile ranks after every real key: top digit, highest indices
-        const uint32_t d = (local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1);
-        dig[i] = d;
+        const uint32_t d = rd[i] >> 16;
         unsigned long long peers = ~0ull;
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
@@ -144,60 +283,30 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
             wave_hist[wave][d] = prior + (uint32_t)__popcll(peers);
         }
         prior = __shfl(prior, __ffsll((long long)peers) - 1, kWave);
-        rank[i] = prior + below;
+        rd[i] |= prior + below;
+    }
+    GSR_STAMP(3);   // ranking
+    if (lb.active && !lb.found) {                // round 1 has had the whole ranking to arrive
+        const uint32_t used = lb.consume(lane);
+#ifdef GSR_SWEEP_STAMPS
+        if (threadIdx.x == 0) { dbg_[12] += 1; dbg_[13] += used; if (!used) dbg_[14] += 1; }
+#endif
+        if (!lb.found) lb.issue(status);         // round 2 flies during the scans and the staging
     }
     __syncthreads();
 
-    // per digit: counts -> exclusive offsets across waves and across digits; publish; look back
-    if (threadIdx.x < RADIX) {
-        const int d = threadIdx.x;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t c = wave_hist[w][d];
-            wave_hist[w][d] = acc;
-            acc += c;
-        }
-        run_start[d] = acc;                      // count for now; scanned below
-        // Padding keys were counted in the top digit: they must not be published.
-        uint32_t real = acc;
-        if (d == RADIX - 1) real -= ((uint32_t)kSortTile - valid);
-        if ((uint32_t)d < spec.nbins) {
-            unsigned long long* cell = status + (size_t)tile * RADIX + d;
-            if (tile == 0) {
-                __hip_atomic_store(cell, kFlagPrefix | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                global_start[d] = digit_base;
-            } else {
-                __hip_atomic_store(cell, kFlagAggregate | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long excl = 0;
-                uint32_t t = tile - 1, spins = 0;
-                for (;;) {
-                    const unsigned long long s = __hip_atomic_load(status + (size_t)t * RADIX + d, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long f = s & ~kValueMask;
-                    if (f == 0) {
-                        if (++spins > kSpinLimit) { s_fail = 1; atomicExch(error_word, 1u); break; }
-                        __builtin_amdgcn_s_sleep(2);
-                        continue;
-                    }
-                    excl += s & kValueMask;
-                    if (f == kFlagPrefix) break;
-                    --t;                         // tile 0 always carries kFlagPrefix
-                }
-                __hip_atomic_store(cell, kFlagPrefix | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                global_start[d] = digit_base + (uint32_t)excl;
-            }
-        } else {
-            global_start[d] = 0;
-        }
-    }
-    __syncthreads();
-    if (s_fail) return;
-
-    // exclusive scan of the tile's digit counts (RADIX <= 256 values, one per thread)
+    // per digit: exclusive offsets across waves, then across digits (padding sits in the top digit)
     {
-        const uint32_t c = (threadIdx.x < RADIX) ? run_start[threadIdx.x] : 0u;
-        uint32_t incl = c;
+        uint32_t acc = 0;
+        if (threadIdx.x < RADIX) {
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const uint32_t c = wave_hist[w][threadIdx.x];
+                wave_hist[w][threadIdx.x] = acc;
+                acc += c;
+            }
+        }
+        uint32_t incl = acc;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, kWave);
@@ -209,42 +318,64 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
 #pragma unroll
         for (int w = 0; w < kWaves; ++w)
             if (w < wave) wbase += scan_ws[w];
-        if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - c;
+        if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - acc;
     }
     __syncthreads();
-
-    KeyT* stage_keys = reinterpret_cast<KeyT*>(stage);
+    // keys and values go to their slot in the ranked tile
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        rank[i] += run_start[dig[i]] + wave_hist[wave][dig[i]];
-        stage_keys[rank[i]] = key[i];
+        const uint32_t d = rd[i] >> 16;
+        const uint32_t slot = (rd[i] & 0xFFFFu) + run_start[d] + wave_hist[wave][d];
+        stage_keys[slot] = key[i];
+        stage_vals[slot] = val[i];
     }
+    GSR_STAMP(4);   // scans + staging
+
+    if (lb.active) {
+        while (!lb.found) {
+            const uint32_t used = lb.consume(lane);
+#ifdef GSR_SWEEP_STAMPS
+            if (threadIdx.x == 0) { dbg_[12] += 1; dbg_[13] += used; if (!used) dbg_[14] += 1; }
+#endif
+            if (lb.found) break;
+            if (used == 0) {
+                if (++lb.spins > kSpinLimit) { s_fail = 1; atomicExch(error_word, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            lb.issue(status);
+        }
+        if (lb.sub == 0 && lb.found) {
+            __hip_atomic_store(status + (size_t)tile * RADIX + lb.d, kFlagPrefix | (lb.excl + tile_hist[lb.d]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            global_start[lb.d] += (uint32_t)lb.excl;
+        }
+    }
+    GSR_STAMP(5);   // rest of the look-back of digit 0
     __syncthreads();
-    uint32_t dst[kItems];
+    GSR_STAMP(6);   // barrier: slowest digit's look-back
+    if (s_fail) return;
+
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t p = (uint32_t)(i * kThreads) + threadIdx.x;
-        dst[i] = 0xFFFFFFFFu;
         if (p < valid) {
             const KeyT k = stage_keys[p];
             const uint32_t d = digit_of<KeyT>(k, spec);
-            dst[i] = global_start[d] + (p - run_start[d]);
-            if (dst[i] < n) keys_out[dst[i]] = k;
+            const uint32_t dst = global_start[d] + (p - run_start[d]);
+            if (dst < n) {
+                keys_out[dst] = k;
+                vals_out[dst] = stage_vals[p];
+            }
         }
     }
-    __syncthreads();
-    uint32_t* stage_vals = reinterpret_cast<uint32_t*>(stage);
+    GSR_STAMP(7);   // write-out issued
+#ifdef GSR_SWEEP_STAMPS
+    if (threadIdx.x == 0) {
+        unsigned long long* slot = status + (size_t)gridDim.x * 256 + (size_t)tile * 16;
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        if (local < valid) stage_vals[rank[i]] = vals_in ? vals_in[tile_base + local] : tile_base + local;
+        for (int i = 0; i < 16; ++i) slot[i] += dbg_[i];
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t p = (uint32_t)(i * kThreads) + threadIdx.x;
-        if (p < valid && dst[i] < n) vals_out[dst[i]] = stage_vals[p];
-    }
+#endif
 }
 
 template <typename KeyT>
@@ -277,9 +408,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+#ifdef GSR_SWEEP_STAMPS
+constexpr size_t kDebugPerTile = 128;
+#else
+constexpr size_t kDebugPerTile = 0;
+#endif
+
 size_t sweep_scratch_bytes(size_t n) {
     const size_t tiles = (n + kSortTile - 1) / kSortTile;
-    return align_up(tiles * 256 * sizeof(unsigned long long), 128) + 128 /*ticket*/ + 128 /*error*/ +
+    return align_up(tiles * (256 * sizeof(unsigned long long) + kDebugPerTile), 128) + 128 /*ticket*/ + 128 /*error*/ +
            align_up(8 * 256 * sizeof(uint32_t), 128);
 }
 
@@ -287,7 +424,8 @@ SweepScratch carve_sweep_scratch(char* base, size_t n) {
     const size_t tiles = (n + kSortTile - 1) / kSortTile;
     SweepScratch s;
     size_t off = 0;
-    s.status = reinterpret_cast<unsigned long long*>(base + off); off += align_up(tiles * 256 * sizeof(unsigned long long), 128);
+    s.status = reinterpret_cast<unsigned long long*>(base + off);
+    off += align_up(tiles * (256 * sizeof(unsigned long long) + kDebugPerTile), 128);
     s.ticket = reinterpret_cast<uint32_t*>(base + off); off += 128;
     s.error_word = reinterpret_cast<uint32_t*>(base + off); off += 128;
     s.hist = reinterpret_cast<uint32_t*>(base + off); off += align_up(8 * 256 * sizeof(uint32_t), 128);

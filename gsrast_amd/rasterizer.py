@@ -203,16 +203,19 @@ def inclusive_scan_u32(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def sort_pairs(keys: torch.Tensor, values: torch.Tensor, end_bit: int = 64):
+def sort_pairs(keys: torch.Tensor, values: torch.Tensor, end_bit: int = 64, begin_bit: int = 0, sync: bool = True,
+               out=None, temp=None):
     L = _capi.lib()
     assert keys.dtype == torch.int64 and values.dtype == torch.int32 and keys.is_cuda
     assert keys.is_contiguous() and values.is_contiguous() and keys.numel() == values.numel()
     n = keys.numel()
-    ko, vo = torch.empty_like(keys), torch.empty_like(values)
-    temp = torch.empty(max(int(L.gsr_sort_temp_bytes(n)), 128), dtype=torch.uint8, device=keys.device)
+    ko, vo = out if out is not None else (torch.empty_like(keys), torch.empty_like(values))
+    if temp is None:
+        temp = torch.empty(max(int(L.gsr_sort_temp_bytes(n)), 128), dtype=torch.uint8, device=keys.device)
     with torch.cuda.device(keys.device):
-        rc = L.gsr_sort_pairs_u64_u32(keys.data_ptr(), ko.data_ptr(), values.data_ptr(), vo.data_ptr(), n,
+        rc = L.gsr_sort_pairs_u64_u32(keys.data_ptr(), ko.data_ptr(), values.data_ptr(), vo.data_ptr(), n, begin_bit,
                                       end_bit, temp.data_ptr(), torch.cuda.current_stream(keys.device).cuda_stream)
     _capi.check(rc, "gsr_sort_pairs_u64_u32")
-    torch.cuda.current_stream(keys.device).synchronize()
+    if sync:
+        torch.cuda.current_stream(keys.device).synchronize()
     return ko, vo

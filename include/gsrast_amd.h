@@ -164,11 +164,11 @@ uint32_t gsr_higher_msb(uint32_t n);
  * temp needs gsr_scan_temp_bytes(n) bytes. in == out is allowed. */
 size_t gsr_scan_temp_bytes(size_t n);
 int gsr_inclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* temp, void* stream);
-/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit)
+/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [begin_bit, end_bit)
  * (replaces cub::DeviceRadixSort::SortPairs, GSCuda.cu:794-797). Inputs are preserved. */
 size_t gsr_sort_temp_bytes(size_t n);
 int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
-                           uint32_t* values_out, size_t n, int end_bit, char* temp, void* stream);
+                           uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -185,5 +185,11 @@ def test_sort_matches_stable_argsort():
         ko, vo = sort_pairs(torch.from_numpy(keys.view(np.int64)).cuda(),
                             torch.from_numpy(vals.view(np.int32)).cuda(), end_bit=bits)
         order = np.argsort(keys, kind="stable")
+        if n > 1000:    # only the tile half [32, bits): depth order of equal tiles must survive
+            k2, v2 = sort_pairs(torch.from_numpy(keys.view(np.int64)).cuda(),
+                                torch.from_numpy(vals.view(np.int32)).cuda(), end_bit=bits, begin_bit=32)
+            o2 = np.argsort(keys >> np.uint64(32), kind="stable")
+            assert np.array_equal(k2.cpu().numpy().view(np.uint64), keys[o2]), (n, bits, "tile half")
+            assert np.array_equal(v2.cpu().numpy().view(np.uint32), vals[o2]), (n, bits, "tile half")
         assert np.array_equal(ko.cpu().numpy().view(np.uint64), keys[order]), (n, bits)
         assert np.array_equal(vo.cpu().numpy().view(np.uint32), vals[order]), (n, bits)
