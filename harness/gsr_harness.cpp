@@ -1,0 +1,116 @@
+// gsr_harness — a C++ caller written the way the reference's GSGaussians is
+// (apps/gsrast/GSGaussians.cpp): grow-only chunk functionals (resizeFunctional, :27-42), one-time
+// SoA upload (:109-137), per-frame matrix prep (:155-176), then gscuda::forward(...) with the
+// reference's exact argument list through include/gscuda_shim.hpp, then the device sync + error
+// poll of CHECK_CUDA_ERROR (CudaBuffer.hpp:8-12). It stands in for the app, which needs
+// GLFW/GL/imgui/lmdb and cannot exist on a headless MI355X box.
+//
+//   gsr_harness <scene.bin> <out.bin> [frames]
+// scene.bin: int32 N, W, H; float32 view[16], proj[16], camPos[3], tanFOVx, tanFOVy, bg[3];
+//            then means3D[4N], scales[4N], rotations[4N], opacities[N], shs[48N].
+// out.bin  : float32 outColor[3*W*H] (planar), then uint32 numRendered-independent checksum-free raw.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "../include/gscuda_shim.hpp"
+
+#define CHECK_HIP_ERROR(expr)                                                          \
+    do {                                                                               \
+        expr;                                                                          \
+        hipError_t e_ = hipDeviceSynchronize();                                        \
+        if (e_ == hipSuccess) e_ = hipPeekAtLastError();                               \
+        if (e_ != hipSuccess) fprintf(stderr, "HIP error: %s\n", hipGetErrorString(e_)); \
+    } while (0)
+
+static std::function<char*(size_t)> resizeFunctional(void** ptr, size_t& S) {
+    return [ptr, &S](size_t N) {
+        if (N > S) {
+            if (*ptr) (void)hipFree(*ptr);
+            (void)hipMalloc(ptr, 2 * N);
+            S = 2 * N;
+        }
+        return reinterpret_cast<char*>(*ptr);
+    };
+}
+
+template <typename T>
+static T* upload(const std::vector<T>& v) {
+    T* d = nullptr;
+    (void)hipMalloc(reinterpret_cast<void**>(&d), v.size() * sizeof(T));
+    (void)hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+
+template <typename T>
+static bool read_vec(FILE* f, std::vector<T>& v, size_t n) {
+    v.resize(n);
+    return fread(v.data(), sizeof(T), n, f) == n;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s scene.bin out.bin [frames]\n", argv[0]); return 2; }
+    const int frames = argc > 3 ? atoi(argv[3]) : 1;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("scene"); return 2; }
+    int32_t hdr[3];
+    if (fread(hdr, 4, 3, f) != 3) return 2;
+    const int N = hdr[0], W = hdr[1], H = hdr[2];
+    std::vector<float> cam, means, scales, rots, opac, shs;
+    if (!read_vec(f, cam, 16 + 16 + 3 + 2 + 3) || !read_vec(f, means, 4 * (size_t)N) || !read_vec(f, scales, 4 * (size_t)N) ||
+        !read_vec(f, rots, 4 * (size_t)N) || !read_vec(f, opac, (size_t)N) || !read_vec(f, shs, 48 * (size_t)N)) {
+        fprintf(stderr, "short scene file\n");
+        return 2;
+    }
+    fclose(f);
+
+    float *dMeans = upload(means), *dScales = upload(scales), *dRots = upload(rots), *dOpac = upload(opac), *dShs = upload(shs);
+    std::vector<float> view(cam.begin(), cam.begin() + 16), proj(cam.begin() + 16, cam.begin() + 32);
+    std::vector<float> camPos(cam.begin() + 32, cam.begin() + 35), bg(cam.begin() + 37, cam.begin() + 40);
+    const float tanFOVx = cam[35], tanFOVy = cam[36];
+    float *dView = upload(view), *dProj = upload(proj), *dCamPos = upload(camPos), *dBg = upload(bg);
+    int* dRects = nullptr;
+    (void)hipMalloc(reinterpret_cast<void**>(&dRects), sizeof(int) * 2 * (size_t)N);
+    float* dOut = nullptr;
+    (void)hipMalloc(reinterpret_cast<void**>(&dOut), sizeof(float) * 3 * (size_t)W * H);
+    (void)hipMemset(dOut, 0, sizeof(float) * 3 * (size_t)W * H);
+
+    void *geomPtr = nullptr, *binningPtr = nullptr, *imgPtr = nullptr;
+    size_t allocatedGeom = 0, allocatedBinning = 0, allocatedImg = 0;
+    auto geomFunc = resizeFunctional(&geomPtr, allocatedGeom);
+    auto binningFunc = resizeFunctional(&binningPtr, allocatedBinning);
+    auto imgFunc = resizeFunctional(&imgPtr, allocatedImg);
+
+    double best_ms = 1e30;
+    for (int i = 0; i < frames; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        CHECK_HIP_ERROR(gscuda::forward(geomFunc, binningFunc, imgFunc, N, 3, 16, dBg, W, H, dMeans, dShs, nullptr, dOpac,
+                                        dScales, 1.0f, dRots, nullptr, dView, dProj, dCamPos, tanFOVx, tanFOVy, false, dOut,
+                                        nullptr, dRects, nullptr, nullptr));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms < best_ms) best_ms = ms;
+        if (gscuda::lastError() != GSR_OK) {
+            fprintf(stderr, "gscuda::forward failed: %s (%s)\n", gsr_error_string(gscuda::lastError()), gsr_last_hip_error());
+            return 1;
+        }
+    }
+    // What the Inspector does: re-derive GeometryState pointers from the caller-owned chunk.
+    char* chunk = reinterpret_cast<char*>(geomPtr);
+    gscuda::gs::GeometryState st = gscuda::gs::GeometryState::fromChunk(chunk, N);
+    uint32_t lastOffset = 0;
+    (void)hipMemcpy(&lastOffset, st.pointOffsets + (N - 1), 4, hipMemcpyDeviceToHost);
+
+    std::vector<float> out(3 * (size_t)W * H);
+    (void)hipMemcpy(out.data(), dOut, out.size() * sizeof(float), hipMemcpyDeviceToHost);
+    FILE* o = fopen(argv[2], "wb");
+    if (!o) { perror("out"); return 2; }
+    fwrite(out.data(), sizeof(float), out.size(), o);
+    fclose(o);
+    printf("gsr_harness: N=%d %dx%d numRendered=%u frames=%d best_ms=%.3f required(Geometry)=%zu\n", N, W, H, lastOffset, frames,
+           best_ms, gscuda::required<gscuda::gs::GeometryState>(N));
+    return 0;
+}
