@@ -153,6 +153,9 @@ def main():
     staged_frame = rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None)
     r_f = rast.last_records_staged
     num_rendered = rast.last_num_rendered
+    geo = rast.map_geometry_state()
+    n_visible = int((geo["tilesTouched"] != 0).sum().item())        # V of this rank's band
+    n_visible_total = int((geo["radii"] > 0).sum().item())
 
     sync_all()
     t0 = time.perf_counter()
@@ -175,13 +178,39 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        # Algorithmic bytes of the blend launch on THIS rank: 40 per staged record,
-        # 20 per pixel written, 8 per tile range read.
+        # ALGORITHMIC bytes per launch on THIS rank (SURVEY.md §8d / BASELINE.md §2). N splats,
+        # V visible, R instances, R_f records staged by the blend, P pixels, T tiles of this rank.
         rows = exch.my_tile_rows() if exch else (0, grid_y)
         px_rows = min(rows[1] * 16, H) - min(rows[0] * 16, H)
-        blend_bytes = 40.0 * r_f + 20.0 * px_rows * W + 8.0 * (rows[1] - rows[0]) * grid_x
-        blend_ms = stage_ms.get("blend", 0.0)
-        achieved = blend_bytes / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+        P_loc, T_loc = px_rows * W, (rows[1] - rows[0]) * grid_x
+        N, R = n_splats, num_rendered
+        alg = {
+            "preprocess": N * (52 + 12 + 8) + n_visible * 72,
+            "scan": 8 * N,
+            "duplicate": 8 * N + 20 * n_visible + 12 * R,
+            "sort_pass1": 24 * R,            # one onesweep launch: 12 B read + 12 B written per pair
+            "sort_pass2": 24 * R,
+            "ranges": 8 * R + 16 * T_loc,
+            "blend": 40 * r_f + 20 * P_loc + 8 * T_loc,
+        }
+        kernels = {}
+        for k, b in alg.items():
+            t = stage_ms.get(k, 0.0)
+            if t > 0:
+                gbs = b / (t * 1e-3) / 1e9
+                kernels[k] = {"ms": round(t, 4), "alg_bytes": int(b), "gbs": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+        dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"),
+                  key=lambda k: stage_ms.get(k, 0.0))
+        dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
+                     "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)", "blend": "blend_kernel",
+                     "duplicate": "duplicate_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
+
+        def roof(k, note):
+            e = kernels.get(k, {"gbs": 0.0, "ms": 0.0, "alg_bytes": 0})
+            return {"bound": "hbm", "kernel": dom_names[k], "achieved": e["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(e["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": e["alg_bytes"], "avg_launch_ms": e["ms"], "note": note}
+
         out = {
             "metric": "forward_msplats_per_s",
             "value": round(n_splats / (ms_per_step * 1e-3) / 1e6, 3),
@@ -195,16 +224,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{label}, {W}x{H} forward, fixed reference default camera",
-                       "width": W, "height": H, "splats": n_splats, "num_rendered": r_total,
+                       "width": W, "height": H, "splats": n_splats, "visible": n_visible_total, "num_rendered": r_total,
                        "records_staged": r_f_total, "minstances_per_s": round(r_total / (ms_per_step * 1e-3) / 1e6, 2),
                        "parallelism": f"tile-rows x{world}" if distributed else "single GPU",
                        "bands": exch.bounds if exch else None},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "blend_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None,
-                         "algorithmic_bytes_per_launch": int(blend_bytes), "avg_launch_ms": round(blend_ms, 4),
-                         "note": "blend is VALU-bound at ~100 flop/B (SURVEY.md §7); fraction reported as measured"},
+            "roofline": roof(dom, "dominant kernel of this frame; HIP-event time of the launch on its own stream"),
+            "roofline_blend": roof("blend", "the kernel BASELINE.json names; VALU-bound (~100 flop/B), fraction as measured"),
+            "kernels": kernels,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)

@@ -23,8 +23,8 @@ GSR_ERR_INTERNAL = 6
 
 GSR_FLAG_PROFILE = 0x1
 GSR_FLAG_COUNT_STAGED = 0x2
-GSR_NUM_STAGES = 6
-STAGE_NAMES = ("preprocess", "scan", "duplicate", "sort", "ranges", "blend")
+GSR_NUM_STAGES = 8
+STAGE_NAMES = ("preprocess", "scan", "depth_order", "duplicate", "sort_pass1", "sort_pass2", "ranges", "blend")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

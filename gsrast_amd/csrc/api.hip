@@ -61,7 +61,8 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
 struct BinScratch {
     uint64_t* tmp_k;
     uint32_t* tmp_v;
-    SweepScratch sweep;
+    SweepScratch sweep;       // pass 1 (also holds the two tile-digit histograms)
+    SweepScratch sweep2;      // pass 2: its own look-back words, so both clears precede pass 1
     size_t bytes;
 };
 BinScratch carve_bin_scratch(char* base, size_t r) {
@@ -70,6 +71,7 @@ BinScratch carve_bin_scratch(char* base, size_t r) {
     b.tmp_k = reinterpret_cast<uint64_t*>(base + off); off += align128(8 * r);
     b.tmp_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * r);
     b.sweep = carve_sweep_scratch(base + off, r); off += sweep_scratch_bytes(r);
+    b.sweep2 = carve_sweep_scratch(base + off, r); off += sweep_scratch_bytes(r);
     b.bytes = off;
     return b;
 }
@@ -81,6 +83,7 @@ struct Readback {
     unsigned long long* staged_host = nullptr;
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
     bool events = false;
+    bool recorded[GSR_NUM_STAGES] = {};
     int ensure() {
         if (!host) {
             GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocDefault));
@@ -245,11 +248,12 @@ int gsr_forward(gsr_forward_args* a) {
     gsr_image_from_chunk(img_chunk, P, &img);
 
 #define GSR_BEGIN(s) do { if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * (s)], stream)); } while (0)
-#define GSR_END(s) do { if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * (s) + 1], stream)); } while (0)
+#define GSR_END(s) do { if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * (s) + 1], stream)); g_rb.recorded[s] = true; } } while (0)
 #define GSR_STEP(call) do { rc = (call); if (rc != GSR_OK) return fail(rc); } while (0)
 
     const GeoScratch gs = carve_geo_scratch(geom.scanning_space, (size_t)n);
     g_rb.host[1] = g_rb.host[2] = 0;
+    for (bool& r : g_rb.recorded) r = false;
 
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, d, stream));                 // :744-768
@@ -274,7 +278,7 @@ int gsr_forward(gsr_forward_args* a) {
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
     // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
-    GSR_BEGIN(GSR_STAGE_DUPLICATE);
+    GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
     GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
     GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, sizeof(uint32_t), stream));
     GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
@@ -283,35 +287,49 @@ int gsr_forward(gsr_forward_args* a) {
     const bool xy_plan = d.grid_x <= 256 && d.grid_y <= 256;
     uint32_t* hist_x = xy_plan ? bs.sweep.hist : nullptr;
     uint32_t* hist_y = xy_plan ? bs.sweep.hist + 256 : nullptr;
-    if (xy_plan) GSR_HIP_TRY(hipMemsetAsync(bs.sweep.hist, 0, 512 * sizeof(uint32_t), stream));
+    const bool px = xy_plan && d.grid_x > 1, py = xy_plan && d.grid_y > 1;
+    if (xy_plan) {
+        GSR_HIP_TRY(hipMemsetAsync(bs.sweep.hist, 0, 512 * sizeof(uint32_t), stream));
+        if (px) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_x, stream));
+        if (py) GSR_STEP(sweep_clear(px ? bs.sweep2 : bs.sweep, R, (uint32_t)d.grid_y, stream));
+    }
+    GSR_END(GSR_STAGE_DEPTH_ORDER);
+    GSR_BEGIN(GSR_STAGE_DUPLICATE);
     GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, a->rects, d, bin.keys_unsorted,
                               bin.values_unsorted, hist_x, hist_y, stream));               // :787
     GSR_END(GSR_STAGE_DUPLICATE);
 
-    GSR_BEGIN(GSR_STAGE_SORT);
     if (xy_plan) {
         // tile = y * grid_x + x: a stable pass on x then one on y orders by tile id.
         DigitSpec sx, sy;
         sx.mode = kDigitTileX; sx.shift = 0; sx.nbins = (uint32_t)d.grid_x; sx.grid_x = (uint32_t)d.grid_x;
         sx.magic = (uint32_t)(0x100000000ull / (uint32_t)d.grid_x) + 1u;
         sy = sx; sy.mode = kDigitTileY; sy.nbins = (uint32_t)d.grid_y;
-        const bool px = d.grid_x > 1, py = d.grid_y > 1;
         if (px && py) {
-            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bs.tmp_k, bs.tmp_v, R, sx, hist_x, bs.sweep, stream));
-            GSR_STEP(sweep_pass_u64(bs.tmp_k, bs.tmp_v, bin.keys, bin.values, R, sy, hist_y, bs.sweep, stream));
+            GSR_BEGIN(GSR_STAGE_SORT_PASS1);
+            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bs.tmp_k, bs.tmp_v, R, sx, hist_x, bs.sweep, stream, true));
+            GSR_END(GSR_STAGE_SORT_PASS1);
+            GSR_BEGIN(GSR_STAGE_SORT_PASS2);
+            GSR_STEP(sweep_pass_u64(bs.tmp_k, bs.tmp_v, bin.keys, bin.values, R, sy, hist_y, bs.sweep2, stream, true));
+            GSR_END(GSR_STAGE_SORT_PASS2);
         } else if (px || py) {
+            GSR_BEGIN(GSR_STAGE_SORT_PASS1);
             GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, px ? sx : sy,
-                                    px ? hist_x : hist_y, bs.sweep, stream));
+                                    px ? hist_x : hist_y, bs.sweep, stream, true));
+            GSR_END(GSR_STAGE_SORT_PASS1);
         } else {
+            GSR_BEGIN(GSR_STAGE_SORT_PASS1);
             GSR_HIP_TRY(hipMemcpyAsync(bin.keys, bin.keys_unsorted, 8 * (size_t)R, hipMemcpyDeviceToDevice, stream));
             GSR_HIP_TRY(hipMemcpyAsync(bin.values, bin.values_unsorted, 4 * (size_t)R, hipMemcpyDeviceToDevice, stream));
+            GSR_END(GSR_STAGE_SORT_PASS1);
         }
     } else {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
+        GSR_BEGIN(GSR_STAGE_SORT_PASS2);
         GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, 32, end_bit,
                                    bin.sorting_space, stream));
+        GSR_END(GSR_STAGE_SORT_PASS2);
     }
-    GSR_END(GSR_STAGE_SORT);
     GSR_BEGIN(GSR_STAGE_RANGES);
     GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, stream));              // :800-801
     GSR_END(GSR_STAGE_RANGES);
@@ -333,6 +351,7 @@ int gsr_forward(gsr_forward_args* a) {
         if (count_staged) a->records_staged = *g_rb.staged_host;
         if (profile) {
             for (int s = 0; s < GSR_NUM_STAGES; ++s) {
+                if (!g_rb.recorded[s]) continue;
                 float ms = 0.0f;
                 GSR_HIP_TRY(hipEventElapsedTime(&ms, g_rb.ev[2 * s], g_rb.ev[2 * s + 1]));
                 a->stage_ms[s] = ms;

@@ -18,10 +18,13 @@
 // loads (data-is-the-flag granules, cdna_hip_programming.md Guideline 16 R2); no payload is
 // exchanged inside the launch, so no fences are needed. Tickets make predecessors resident
 // before their successors; every spin is bounded and raises an error word instead of hanging.
+#include <stdlib.h>
+
 #include "gsr_common.hpp"
 #include "radix_sort.hpp"
 
 namespace gsr {
+int sweep_clear(const SweepScratch& sc, uint32_t n, uint32_t nbins, hipStream_t stream);
 namespace {
 
 #ifndef GSR_SWEEP_THREADS
@@ -38,6 +41,14 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int kItems = GSR_SWEEP_ITEMS;
 constexpr int kSortTile = kThreads * kItems;            // keys per workgroup
 constexpr int kWaveSpan = kWave * kItems;
+// The ranked tile leaves through LDS in kStageRounds slices of kStageSlots slots: a smaller LDS
+// footprint per workgroup buys more resident workgroups per CU (the pass is latency-bound).
+#ifndef GSR_SWEEP_STAGE_ROUNDS
+#define GSR_SWEEP_STAGE_ROUNDS 2
+#endif
+constexpr int kStageRounds = GSR_SWEEP_STAGE_ROUNDS;
+constexpr int kStageSlots = kSortTile / kStageRounds;
+static_assert(kItems % kStageRounds == 0, "items per lane must split evenly over the staging rounds");
 
 constexpr unsigned long long kFlagAggregate = 1ull << 62;
 constexpr unsigned long long kFlagPrefix = 2ull << 62;
@@ -176,8 +187,8 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     __shared__ uint32_t global_start[RADIX];     // output index of this tile's first digit-d key
     __shared__ uint32_t scan_ws[kWaves];
     __shared__ uint32_t s_tile, s_fail;
-    __shared__ KeyT stage_keys[kSortTile];
-    __shared__ uint32_t stage_vals[kSortTile];
+    __shared__ KeyT stage_keys[kStageSlots];
+    __shared__ uint32_t stage_vals[kStageSlots];
 #ifdef GSR_SWEEP_LDS_PAD
     __shared__ uint32_t occupancy_pad[GSR_SWEEP_LDS_PAD / 4];   // tuning experiment: caps workgroups per CU
     if (threadIdx.x == 0 && n == 0xFFFFFFFFu) occupancy_pad[0] = 1;
@@ -243,6 +254,9 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     lb.sub = threadIdx.x % kLanesPerDigit;
     lb.t = tile;
     lb.active = tile != 0 && threadIdx.x < RADIX * kLanesPerDigit && (uint32_t)lb.d < spec.nbins;
+#ifdef GSR_SWEEP_NO_LOOKBACK
+    lb.active = false;       // timing experiment only: every tile scatters from the digit base (wrong output)
+#endif
     if (lb.active) lb.issue(status);
 
     // exclusive scan of the global digit histogram -> first output index of every digit
@@ -321,15 +335,13 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - acc;
     }
     __syncthreads();
-    // keys and values go to their slot in the ranked tile
+    // final slot of every key inside the ranked tile (kept in the low half of rd)
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t d = rd[i] >> 16;
-        const uint32_t slot = (rd[i] & 0xFFFFu) + run_start[d] + wave_hist[wave][d];
-        stage_keys[slot] = key[i];
-        stage_vals[slot] = val[i];
+        rd[i] = (rd[i] & 0xFFFF0000u) | ((rd[i] & 0xFFFFu) + run_start[d] + wave_hist[wave][d]);
     }
-    GSR_STAMP(4);   // scans + staging
+    GSR_STAMP(4);   // scans + slots
 
     if (lb.active) {
         while (!lb.found) {
@@ -355,16 +367,32 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     GSR_STAMP(6);   // barrier: slowest digit's look-back
     if (s_fail) return;
 
+    // Slice r of the ranked tile: slots [r * kStageSlots, (r + 1) * kStageSlots) pass through LDS and
+    // leave as contiguous runs per digit.
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t p = (uint32_t)(i * kThreads) + threadIdx.x;
-        if (p < valid) {
-            const KeyT k = stage_keys[p];
-            const uint32_t d = digit_of<KeyT>(k, spec);
-            const uint32_t dst = global_start[d] + (p - run_start[d]);
-            if (dst < n) {
-                keys_out[dst] = k;
-                vals_out[dst] = stage_vals[p];
+    for (int r = 0; r < kStageRounds; ++r) {
+        if (r > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t slot = (rd[i] & 0xFFFFu) - (uint32_t)(r * kStageSlots);
+            if (slot < (uint32_t)kStageSlots) {
+                stage_keys[slot] = key[i];
+                stage_vals[slot] = val[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kItems / kStageRounds; ++i) {
+            const uint32_t q = (uint32_t)(i * kThreads) + threadIdx.x;          // slot inside the slice
+            const uint32_t p = q + (uint32_t)(r * kStageSlots);                  // slot inside the tile
+            if (p < valid) {
+                const KeyT k = stage_keys[q];
+                const uint32_t d = digit_of<KeyT>(k, spec);
+                const uint32_t dst = global_start[d] + (p - run_start[d]);
+                if (dst < n) {
+                    keys_out[dst] = k;
+                    vals_out[dst] = stage_vals[q];
+                }
             }
         }
     }
@@ -378,19 +406,28 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
 #endif
 }
 
+inline int radix_bits_for(uint32_t nbins) {
+    int bits = 1;
+    while ((1u << bits) < nbins) ++bits;
+    return bits < 4 ? 4 : bits;
+}
+
 template <typename KeyT>
 int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
-                const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream) {
-    int bits = 1;
-    while ((1u << bits) < spec.nbins) ++bits;
+                const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
+                bool already_cleared) {
+    const int bits = radix_bits_for(spec.nbins);
     if (bits > 8) return GSR_ERR_INVALID_ARG;
-    if (bits < 4) bits = 4;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
-    const size_t status_bytes = (size_t)tiles * ((size_t)1 << bits) * sizeof(unsigned long long);
-    GSR_HIP_TRY(hipMemsetAsync(sc.status, 0, status_bytes, stream));
-    GSR_HIP_TRY(hipMemsetAsync(sc.ticket, 0, sizeof(uint32_t), stream));
+    if (!already_cleared) {
+        const int rc = sweep_clear(sc, n, spec.nbins, stream);
+        if (rc != GSR_OK) return rc;
+    }
+    // Tuning aid: GSR_SWEEP_DYN_LDS=<bytes> adds unused dynamic LDS to every workgroup, which lowers the
+    // number of workgroups a CU can hold without changing the code (occupancy sensitivity runs).
+    static const unsigned dyn_lds = [] { const char* e = getenv("GSR_SWEEP_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
 #define GSR_SWEEP(B)                                                                                              \
-    hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in,     \
+    hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), dyn_lds, stream, keys_in, vals_in, \
                        keys_out, vals_out, n, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
     switch (bits) {
         case 4: GSR_SWEEP(4); break;
@@ -432,15 +469,28 @@ SweepScratch carve_sweep_scratch(char* base, size_t n) {
     return s;
 }
 
+// Zeroes the look-back words and the ticket of one pass (done inside sweep_pass_* unless the
+// caller has already done it, e.g. to keep the clears out of a timed region).
+int sweep_clear(const SweepScratch& sc, uint32_t n, uint32_t nbins, hipStream_t stream) {
+    const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
+    const size_t status_bytes = (size_t)tiles * ((size_t)1 << radix_bits_for(nbins)) * sizeof(unsigned long long);
+    GSR_HIP_TRY(hipMemsetAsync(sc.status, 0, status_bytes, stream));
+    GSR_HIP_TRY(hipMemsetAsync(sc.ticket, 0, sizeof(uint32_t), stream));
+    return GSR_OK;
+}
+
 int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t n,
-                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream) {
+                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
+                   bool already_cleared) {
     return launch_pass<unsigned long long>(reinterpret_cast<const unsigned long long*>(keys_in), vals_in,
-                                           reinterpret_cast<unsigned long long*>(keys_out), vals_out, n, spec, digit_hist, sc, stream);
+                                           reinterpret_cast<unsigned long long*>(keys_out), vals_out, n, spec, digit_hist, sc,
+                                           stream, already_cleared);
 }
 
 int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
-                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream) {
-    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream);
+                   const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
+                   bool already_cleared) {
+    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream, already_cleared);
 }
 
 template <typename KeyT>

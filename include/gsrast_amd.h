@@ -85,13 +85,15 @@ size_t gsr_required_binning(size_t size);
 
 /* Per-stage device times of the last profiled gsr_forward call, in milliseconds. */
 enum {
-    GSR_STAGE_PREPROCESS = 0,
-    GSR_STAGE_SCAN = 1,
-    GSR_STAGE_DUPLICATE = 2,
-    GSR_STAGE_SORT = 3,
-    GSR_STAGE_RANGES = 4,
-    GSR_STAGE_BLEND = 5,
-    GSR_NUM_STAGES = 6
+    GSR_STAGE_PREPROCESS = 0,   /* preprocess kernel                                             */
+    GSR_STAGE_SCAN = 1,         /* inclusive scan of tiles touched (3 small kernels)             */
+    GSR_STAGE_DEPTH_ORDER = 2,  /* per-Gaussian depth sort + depth-ordered offsets (N-sized)     */
+    GSR_STAGE_DUPLICATE = 3,    /* key emission kernel                                           */
+    GSR_STAGE_SORT_PASS1 = 4,   /* onesweep kernel, tile-column digit (or first generic pass)    */
+    GSR_STAGE_SORT_PASS2 = 5,   /* onesweep kernel, tile-row digit (remaining passes)            */
+    GSR_STAGE_RANGES = 6,       /* clear + tile ranges kernel                                    */
+    GSR_STAGE_BLEND = 7,        /* blend kernel                                                  */
+    GSR_NUM_STAGES = 8
 };
 
 #define GSR_FLAG_PROFILE 0x1u   /* record HIP events around every stage into stage_ms       */
