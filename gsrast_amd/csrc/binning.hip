@@ -136,6 +136,26 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __rest
     }
 }
 
+// Same result as tile_ranges_kernel without streaming the R keys: thread t finds the first sorted
+// key of tile t and of tile t + 1 by two interleaved binary searches (2 x ~log2 R dependent loads).
+// Tiles that own no key keep (0, 0) and the R == 1 quirk (the lone tile is never closed) is kept.
+__global__ __launch_bounds__(256) void tile_ranges_search_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                                 uint2* __restrict__ ranges, uint32_t num_tiles) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= num_tiles) return;
+    uint32_t lo_a = 0, hi_a = n, lo_b = 0, hi_b = n;      // lower bounds of tile t (a) and t + 1 (b)
+    while (lo_a < hi_a || lo_b < hi_b) {
+        const uint32_t mid_a = lo_a + ((hi_a - lo_a) >> 1), mid_b = lo_b + ((hi_b - lo_b) >> 1);
+        const uint32_t ka = (lo_a < hi_a) ? (uint32_t)(keys[mid_a] >> 32) : 0u;
+        const uint32_t kb = (lo_b < hi_b) ? (uint32_t)(keys[mid_b] >> 32) : 0u;
+        if (lo_a < hi_a) { if (ka < t) lo_a = mid_a + 1; else hi_a = mid_a; }
+        if (lo_b < hi_b) { if (kb < t + 1) lo_b = mid_b + 1; else hi_b = mid_b; }
+    }
+    uint2 r = make_uint2(0u, 0u);
+    if (lo_b > lo_a && n > 1) r = make_uint2(lo_a, lo_b);
+    ranges[t] = r;
+}
+
 }  // namespace
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,
@@ -158,8 +178,18 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
 }
 
 int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, hipStream_t stream) {
+    if (n == 0) {
+        GSR_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, stream));
+        return GSR_OK;
+    }
+    // One thread per tile beats one thread per key as soon as there are more keys than a few per tile.
+    if (n >= (size_t)num_tiles * 8 && n < 0xFFFFFFFFull) {
+        hipLaunchKernelGGL(tile_ranges_search_kernel, dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, stream, keys,
+                           (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles);
+        GSR_LAUNCH_CHECK("tile_ranges_search_kernel");
+        return GSR_OK;
+    }
     GSR_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, stream));
-    if (n == 0) return GSR_OK;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, stream, keys, n,
                        reinterpret_cast<uint2*>(ranges));
