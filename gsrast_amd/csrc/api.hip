@@ -41,6 +41,8 @@ struct GeoScratch {
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     SweepScratch sweep;       // onesweep status words for the N-sized sort
+    uint32_t* col_table;      // [tile column][workgroup of 256 Gaussians] key counts, then their scan
+    char* col_scan_temp;
     size_t bytes;
 };
 GeoScratch carve_geo_scratch(char* base, size_t n) {
@@ -53,6 +55,9 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
+    const size_t col_cells = ((n + 255) / 256) * 256;       // up to 256 tile columns
+    g.col_table = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * col_cells);
+    g.col_scan_temp = base + off; off += align128(scan_temp_bytes(col_cells));
     g.bytes = off;
     return g;
 }
@@ -282,48 +287,45 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
     GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, sizeof(uint32_t), stream));
     GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
-    GSR_STEP(launch_gather_counts(n, gs.b_k, gs.b_v, geom.tiles_touched, gs.a_k, stream));
-    GSR_STEP(launch_inclusive_scan(gs.a_k, gs.a_k, (size_t)n, gs.scan_temp, stream));
-    const bool xy_plan = d.grid_x <= 256 && d.grid_y <= 256;
-    uint32_t* hist_x = xy_plan ? bs.sweep.hist : nullptr;
-    uint32_t* hist_y = xy_plan ? bs.sweep.hist + 256 : nullptr;
-    const bool px = xy_plan && d.grid_x > 1, py = xy_plan && d.grid_y > 1;
+    // Tile grids up to 255 x 255: the tile-column pass is produced directly by a column-major
+    // emission and only the tile-row pass runs as a sort. Larger grids: depth-ordered emission and
+    // 8-bit digit passes over the tile bits.
+    const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (xy_plan) {
-        GSR_HIP_TRY(hipMemsetAsync(bs.sweep.hist, 0, 512 * sizeof(uint32_t), stream));
-        if (px) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_x, stream));
-        if (py) GSR_STEP(sweep_clear(px ? bs.sweep2 : bs.sweep, R, (uint32_t)d.grid_y, stream));
-    }
-    GSR_END(GSR_STAGE_DEPTH_ORDER);
-    GSR_BEGIN(GSR_STAGE_DUPLICATE);
-    GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, a->rects, d, bin.keys_unsorted,
-                              bin.values_unsorted, hist_x, hist_y, stream));               // :787
-    GSR_END(GSR_STAGE_DUPLICATE);
-
-    if (xy_plan) {
-        // tile = y * grid_x + x: a stable pass on x then one on y orders by tile id.
-        DigitSpec sx, sy;
-        sx.mode = kDigitTileX; sx.shift = 0; sx.nbins = (uint32_t)d.grid_x; sx.grid_x = (uint32_t)d.grid_x;
-        sx.magic = (uint32_t)(0x100000000ull / (uint32_t)d.grid_x) + 1u;
-        sy = sx; sy.mode = kDigitTileY; sy.nbins = (uint32_t)d.grid_y;
-        if (px && py) {
-            GSR_BEGIN(GSR_STAGE_SORT_PASS1);
-            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bs.tmp_k, bs.tmp_v, R, sx, hist_x, bs.sweep, stream, true));
-            GSR_END(GSR_STAGE_SORT_PASS1);
+        const uint32_t num_blocks = (uint32_t)((n + 255) / 256);
+        uint32_t* hist_y = bs.sweep.hist;
+        uint32_t* rect_packed = gs.a_k;
+        GSR_HIP_TRY(hipMemsetAsync(hist_y, 0, 256 * sizeof(uint32_t), stream));
+        if (d.grid_y > 1) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_y, stream));
+        GSR_STEP(launch_column_count(n, gs.b_k, gs.b_v, geom, radii, a->rects, d, rect_packed, gs.col_table, hist_y, stream));
+        GSR_STEP(launch_inclusive_scan(gs.col_table, gs.col_table, (size_t)d.grid_x * num_blocks, gs.col_scan_temp, stream));
+        GSR_END(GSR_STAGE_DEPTH_ORDER);
+        // one pass: with a single tile row the column-major list is already the sorted list
+        uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
+        uint32_t* emit_v = d.grid_y > 1 ? bin.values_unsorted : bin.values;
+        GSR_BEGIN(GSR_STAGE_DUPLICATE);
+        GSR_STEP(launch_emit_columns(n, gs.b_k, gs.b_v, rect_packed, gs.col_table, d.grid_x, emit_k, emit_v, stream));   // :787
+        GSR_END(GSR_STAGE_DUPLICATE);
+        if (d.grid_y > 1) {
+            DigitSpec sy;
+            sy.mode = kDigitTileY; sy.shift = 0; sy.nbins = (uint32_t)d.grid_y; sy.grid_x = (uint32_t)d.grid_x;
+            sy.magic = (uint32_t)(0x100000000ull / (uint32_t)d.grid_x) + 1u;
             GSR_BEGIN(GSR_STAGE_SORT_PASS2);
-            GSR_STEP(sweep_pass_u64(bs.tmp_k, bs.tmp_v, bin.keys, bin.values, R, sy, hist_y, bs.sweep2, stream, true));
+            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, sy, hist_y, bs.sweep, stream, true));
             GSR_END(GSR_STAGE_SORT_PASS2);
-        } else if (px || py) {
-            GSR_BEGIN(GSR_STAGE_SORT_PASS1);
-            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, px ? sx : sy,
-                                    px ? hist_x : hist_y, bs.sweep, stream, true));
-            GSR_END(GSR_STAGE_SORT_PASS1);
         } else {
-            GSR_BEGIN(GSR_STAGE_SORT_PASS1);
-            GSR_HIP_TRY(hipMemcpyAsync(bin.keys, bin.keys_unsorted, 8 * (size_t)R, hipMemcpyDeviceToDevice, stream));
-            GSR_HIP_TRY(hipMemcpyAsync(bin.values, bin.values_unsorted, 4 * (size_t)R, hipMemcpyDeviceToDevice, stream));
-            GSR_END(GSR_STAGE_SORT_PASS1);
+            // keep the "unsorted" arrays populated as the reference does
+            GSR_HIP_TRY(hipMemcpyAsync(bin.keys_unsorted, bin.keys, 8 * (size_t)R, hipMemcpyDeviceToDevice, stream));
+            GSR_HIP_TRY(hipMemcpyAsync(bin.values_unsorted, bin.values, 4 * (size_t)R, hipMemcpyDeviceToDevice, stream));
         }
     } else {
+        GSR_STEP(launch_gather_counts(n, gs.b_k, gs.b_v, geom.tiles_touched, gs.a_k, stream));
+        GSR_STEP(launch_inclusive_scan(gs.a_k, gs.a_k, (size_t)n, gs.scan_temp, stream));
+        GSR_END(GSR_STAGE_DEPTH_ORDER);
+        GSR_BEGIN(GSR_STAGE_DUPLICATE);
+        GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, a->rects, d, bin.keys_unsorted,
+                                  bin.values_unsorted, nullptr, nullptr, stream));         // :787
+        GSR_END(GSR_STAGE_DUPLICATE);
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
         GSR_BEGIN(GSR_STAGE_SORT_PASS2);
         GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, 32, end_bit,

@@ -119,6 +119,146 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int n, const uint32_t* _
     }
 }
 
+// ---- column-major emission (tile grids up to 255 x 255) -----------------------------------
+// The first of the two tile passes (stable sort on the tile column x) is not run as a sort at
+// all: its result is written directly. In depth order, the keys of column x are, Gaussian after
+// Gaussian, the h rows of the rectangle — so key (g, x, y) lands at
+//     start[x] + sum of h over earlier Gaussians covering x + (y - y0).
+// column_count_kernel gets the per-workgroup (256 depth-consecutive Gaussians) column sums, one
+// scan over the column-major table turns them into start offsets, emit_columns_kernel resolves
+// the order inside a workgroup in LDS and writes every (Gaussian, column) run as one burst.
+// What reaches the remaining pass (stable on the tile row y) is exactly what a stable x pass
+// over the depth-ordered list would have produced.
+
+// rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
+__global__ __launch_bounds__(256) void column_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
+                                                           const uint32_t* __restrict__ sorted_idx,
+                                                           const float2* __restrict__ means2D,
+                                                           const int32_t* __restrict__ radii,
+                                                           const int2* __restrict__ rects, FrameDims d,
+                                                           uint32_t* __restrict__ rect_packed,
+                                                           uint32_t* __restrict__ col_table, uint32_t num_blocks,
+                                                           uint32_t* __restrict__ hist_y) {
+    __shared__ uint32_t lds_hx[256], lds_hy[256];
+    lds_hx[threadIdx.x] = 0;
+    lds_hy[threadIdx.x] = 0;
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    uint32_t packed = 0;
+    if (r < n && sorted_depth[r] != 0xFFFFFFFFu) {
+        const uint32_t idx = sorted_idx[r];
+        const int rad = radii[idx];
+        const float2 p = means2D[idx];
+        int ex = rad, ey = rad;
+        if (rects) { const int2 e = rects[idx]; ex = e.x; ey = e.y; }
+        const int x0 = clampi((int)((p.x - (float)ex) / 16.0f), 0, d.grid_x);
+        int y0 = clampi((int)((p.y - (float)ey) / 16.0f), 0, d.grid_y);
+        const int x1 = clampi((int)((((p.x + (float)ex) + 16.0f) - 1.0f) / 16.0f), 0, d.grid_x);
+        int y1 = clampi((int)((((p.y + (float)ey) + 16.0f) - 1.0f) / 16.0f), 0, d.grid_y);
+        y0 = clampi(y0, d.row_begin, d.row_end);
+        y1 = clampi(y1, d.row_begin, d.row_end);
+        const int w = x1 - x0, h = y1 - y0;
+        if (w > 0 && h > 0) {
+            packed = (uint32_t)x0 | ((uint32_t)w << 8) | ((uint32_t)y0 << 16) | ((uint32_t)h << 24);
+            for (int x = x0; x < x1; ++x) atomicAdd(&lds_hx[x], (uint32_t)h);
+            for (int y = y0; y < y1; ++y) atomicAdd(&lds_hy[y], (uint32_t)w);
+        }
+    }
+    if (r < n) rect_packed[r] = packed;
+    __syncthreads();
+    if ((int)threadIdx.x < d.grid_x) col_table[(size_t)threadIdx.x * num_blocks + blockIdx.x] = lds_hx[threadIdx.x];
+    if (lds_hy[threadIdx.x]) atomicAdd(&hist_y[threadIdx.x], lds_hy[threadIdx.x]);
+}
+
+constexpr int kRunCap = 6144;     // (Gaussian, column) runs resolved per LDS round
+
+__global__ __launch_bounds__(256) void emit_columns_kernel(int n, const uint32_t* __restrict__ sorted_depth,
+                                                           const uint32_t* __restrict__ sorted_idx,
+                                                           const uint32_t* __restrict__ rect_packed,
+                                                           const uint32_t* __restrict__ col_table_incl,
+                                                           uint32_t num_blocks, int grid_x,
+                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
+    __shared__ uint32_t s_rect[256], s_depth[256], s_idx[256];
+    __shared__ uint32_t s_rowptr[257];          // exclusive prefix of rectangle widths inside the workgroup
+    __shared__ uint32_t s_ws[4];
+    __shared__ uint32_t s_off[kRunCap];         // output index of the first key of every (Gaussian, column) run
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
+    s_rect[threadIdx.x] = rect;
+    s_depth[threadIdx.x] = (r < n) ? sorted_depth[r] : 0u;
+    s_idx[threadIdx.x] = (r < n) ? sorted_idx[r] : 0u;
+    {   // block exclusive scan of the widths
+        const uint32_t wv = (rect >> 8) & 0xFFu;
+        uint32_t incl = wv;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        if (lane == kWave - 1) s_ws[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += s_ws[w];
+        s_rowptr[threadIdx.x] = base + incl - wv;
+        if (threadIdx.x == 255) s_rowptr[256] = base + incl;
+    }
+    // running output index of this workgroup in column x (exclusive scan of the column-major table)
+    uint32_t col = 0;
+    if ((int)threadIdx.x < grid_x) {
+        const size_t cell = (size_t)threadIdx.x * num_blocks + blockIdx.x;
+        col = cell ? col_table_incl[cell - 1] : 0u;
+    }
+    __syncthreads();
+    const uint32_t total_runs = s_rowptr[256];
+    // Rounds of at most kRunCap runs: Gaussians [g_lo, g_hi) whose runs fit the LDS table.
+    int g_lo = 0;
+    while (g_lo < 256 && s_rowptr[g_lo] < total_runs) {
+        const uint32_t run_lo = s_rowptr[g_lo];
+        int g_hi = g_lo + 1;                    // at least one Gaussian per round (w <= 255 < kRunCap)
+        while (g_hi < 256 && s_rowptr[g_hi + 1] - run_lo <= (uint32_t)kRunCap) ++g_hi;
+        // 1. column threads walk the round's Gaussians in depth order and hand out offsets
+        if ((int)threadIdx.x < grid_x) {
+            const uint32_t x = threadIdx.x;
+            for (int g = g_lo; g < g_hi; ++g) {
+                const uint32_t rc = s_rect[g];
+                const uint32_t x0 = rc & 0xFFu, w = (rc >> 8) & 0xFFu;
+                if (x - x0 < w) {
+                    s_off[s_rowptr[g] - run_lo + (x - x0)] = col;
+                    col += rc >> 24;
+                }
+            }
+        }
+        __syncthreads();
+        // 2. every wave takes Gaussians g = g_lo + wave, + 4, ...; lanes cover (column, row) patches
+        for (int g = g_lo + wave; g < g_hi; g += 4) {
+            const uint32_t rc = s_rect[g];
+            const uint32_t w = (rc >> 8) & 0xFFu, h = rc >> 24;
+            if (w == 0) continue;
+            const uint32_t x0 = rc & 0xFFu, y0 = (rc >> 16) & 0xFFu;
+            const uint32_t depth = s_depth[g], idx = s_idx[g];
+            const uint32_t first = s_rowptr[g] - run_lo;
+            // rows-per-column rounded up to a power of two: 64 / hp columns per wave step
+            uint32_t hp_log = 0;
+            while ((1u << hp_log) < h && hp_log < 6) ++hp_log;
+            const uint32_t cols_per_step = (h > 64) ? 1u : (64u >> hp_log);
+            for (uint32_t c0 = 0; c0 < w; c0 += cols_per_step) {
+                if (h > 64) {
+                    const uint32_t base = s_off[first + c0];
+                    for (uint32_t yy = lane; yy < h; yy += kWave)
+                        emit(keys, values, base + yy, (y0 + yy) * (uint32_t)grid_x + x0 + c0, depth, idx);
+                } else {
+                    const uint32_t c = c0 + ((uint32_t)lane >> hp_log), yy = (uint32_t)lane & ((1u << hp_log) - 1u);
+                    if (c < w && yy < h)
+                        emit(keys, values, s_off[first + c] + yy, (y0 + yy) * (uint32_t)grid_x + x0 + c, depth, idx);
+                }
+            }
+        }
+        __syncthreads();
+        g_lo = g_hi;
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys, size_t n,
                                                           uint2* __restrict__ ranges) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -174,6 +314,26 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
                        reinterpret_cast<const float2*>(g.means2D), radii, reinterpret_cast<const int2*>(rects), d, keys,
                        values, hist_x, hist_y);
     GSR_LAUNCH_CHECK("duplicate_kernel");
+    return GSR_OK;
+}
+
+int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const gsr_geometry_state& g,
+                        const int32_t* radii, const int32_t* rects, const FrameDims& d, uint32_t* rect_packed,
+                        uint32_t* col_table, uint32_t* hist_y, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(column_count_kernel, dim3(blocks), dim3(256), 0, stream, n, sorted_depth, sorted_idx,
+                       reinterpret_cast<const float2*>(g.means2D), radii, reinterpret_cast<const int2*>(rects), d, rect_packed,
+                       col_table, blocks, hist_y);
+    GSR_LAUNCH_CHECK("column_count_kernel");
+    return GSR_OK;
+}
+
+int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_packed,
+                        const uint32_t* col_table_incl, int grid_x, uint64_t* keys, uint32_t* values, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(emit_columns_kernel, dim3(blocks), dim3(256), 0, stream, n, sorted_depth, sorted_idx, rect_packed,
+                       col_table_incl, blocks, grid_x, keys, values);
+    GSR_LAUNCH_CHECK("emit_columns_kernel");
     return GSR_OK;
 }
 

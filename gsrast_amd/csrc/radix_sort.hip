@@ -66,7 +66,7 @@ template <typename KeyT>
 __device__ __forceinline__ uint32_t digit_of(KeyT key, const DigitSpec& s) {
     if (s.mode == kDigitBits) return (uint32_t)(key >> s.shift) & (s.nbins - 1u);
     const uint32_t tile = (uint32_t)((unsigned long long)key >> 32);
-    const uint32_t y = __umulhi(tile, s.magic);
+    const uint32_t y = (s.grid_x == 1u) ? tile : __umulhi(tile, s.magic);   // 2^32 / 1 does not fit the magic
     return s.mode == kDigitTileX ? tile - y * s.grid_x : y;
 }
 

@@ -50,14 +50,23 @@ def _compare_all(r, img, exp, n):
     assert r.last_num_rendered == exp["num_rendered"]
     if exp["num_rendered"] > 0:
         b = {k: v.cpu().numpy() for k, v in r.map_binning_state().items()}
-        # The HIP path emits the pairs in depth order (the depth half of the key is sorted per
-        # Gaussian before duplication), the reference in index order: same multiset of pairs.
+        # The reference emits the pairs in index order. The HIP path sorts the depth half of the key
+        # per Gaussian before duplication and writes the tile-column pass directly, so its
+        # "unsorted" arrays hold the same multiset of pairs ordered by (tile column, depth) — or by
+        # depth alone on grids wider than 255 tiles.
         ku, vu = b["keys_unsorted"].view(np.uint64), b["values_unsorted"].view(np.uint32)
         o_g, o_e = np.lexsort((vu, ku)), np.lexsort((exp["values_unsorted"], exp["keys_unsorted"]))
         assert np.array_equal(ku[o_g], exp["keys_unsorted"][o_e])
         assert np.array_equal(vu[o_g], exp["values_unsorted"][o_e])
+        gx, gy = (r.width + 15) // 16, (r.height + 15) // 16
         depth_half = (ku & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        assert bool((np.diff(depth_half) >= 0).all())
+        if gx <= 255 and gy <= 255:
+            col = ((ku >> np.uint64(32)) % np.uint64(gx)).astype(np.int64)
+            assert bool((np.diff(col) >= 0).all())
+            same_col = np.diff(col) == 0
+            assert bool((np.diff(depth_half)[same_col] >= 0).all())
+        else:
+            assert bool((np.diff(depth_half) >= 0).all())
         assert np.array_equal(b["keys"].view(np.uint64), exp["keys"])
         assert np.array_equal(b["values"].view(np.uint32), exp["values"])
     im = {k: v.cpu().numpy() for k, v in r.map_image_state().items()}
@@ -94,6 +103,31 @@ def test_anisotropic_scenes_against_oracle(w, h, n, seed):
     exp = cpu_oracle.forward(scene, cam, bg)
     r, img = _run(scene, cam, bg)
     _compare_all(r, img, exp, n)
+
+
+def test_grid_wider_than_255_tiles_uses_generic_digit_passes():
+    """4112 x 40 -> 257 x 3 tiles: depth-ordered emission + 8-bit digit passes over the tile bits."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.garden_like_scene(4000, seed=5)
+    scene["means3D"][:, :3] *= 0.2
+    scene["means3D"][:, 0] *= 12.0
+    cam = camera.default_camera(4112, 40, near=0.05, far=50.0)
+    exp = cpu_oracle.forward(scene, cam, (0.0, 0.1, 0.2))
+    assert exp["num_rendered"] > 1000
+    r, img = _run(scene, cam, (0.0, 0.1, 0.2))
+    _compare_all(r, img, exp, 4000)
+
+
+def test_single_tile_row_and_single_tile_grids():
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    for w, h in ((100, 16), (16, 16), (16, 90)):
+        scene = scenes.isotropic_scene(300, seed=8)
+        cam = camera.default_camera(w, h)
+        exp = cpu_oracle.forward(scene, cam)
+        r, img = _run(scene, cam)
+        _compare_all(r, img, exp, 300)
 
 
 def test_radius_rect_path():
