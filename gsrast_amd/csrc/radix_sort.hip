@@ -185,6 +185,7 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     __shared__ uint32_t tile_hist[RADIX];        // digit counts of the tile (early, by LDS atomics)
     __shared__ uint32_t run_start[RADIX];        // first slot of digit d inside the ranked tile
     __shared__ uint32_t global_start[RADIX];     // output index of this tile's first digit-d key
+    __shared__ uint32_t run_delta[RADIX];        // global_start - run_start (u32 wrap-around)
     __shared__ uint32_t scan_ws[kWaves];
     __shared__ uint32_t s_tile, s_fail;
     __shared__ KeyT stage_keys[kStageSlots];
@@ -233,32 +234,6 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     }
     const uint32_t hist_c = (threadIdx.x < spec.nbins) ? digit_hist[threadIdx.x] : 0u;
 
-    // The tile's digit counts, as early as possible: successors only need these to walk past us.
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        const uint32_t d = (local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1);
-        rd[i] = d << 16;
-        if (local < valid) atomicAdd(&tile_hist[d], 1u);
-    }
-    GSR_STAMP(1);   // load wait + tile histogram
-    __syncthreads();
-    if (threadIdx.x < spec.nbins)
-        __hip_atomic_store(status + (size_t)tile * RADIX + threadIdx.x,
-                           (tile == 0 ? kFlagPrefix : kFlagAggregate) | tile_hist[threadIdx.x], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-
-    // Decoupled look-back: first round issued now, consumed after the ranking below.
-    LookBack<RADIX, kLanesPerDigit> lb;
-    lb.d = threadIdx.x / kLanesPerDigit;
-    lb.sub = threadIdx.x % kLanesPerDigit;
-    lb.t = tile;
-    lb.active = tile != 0 && threadIdx.x < RADIX * kLanesPerDigit && (uint32_t)lb.d < spec.nbins;
-#ifdef GSR_SWEEP_NO_LOOKBACK
-    lb.active = false;       // timing experiment only: every tile scatters from the digit base (wrong output)
-#endif
-    if (lb.active) lb.issue(status);
-
     // exclusive scan of the global digit histogram -> first output index of every digit
     {
         uint32_t incl = hist_c;
@@ -276,40 +251,43 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         if (threadIdx.x < RADIX) global_start[threadIdx.x] = wbase + incl - hist_c;
         __syncthreads();
     }
-    GSR_STAMP(2);   // publish + digit-base scan
+    GSR_STAMP(1);   // loads issued + digit-base scan
 
-    // stable ranks: wave64 match groups + per-wave LDS counters
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // Stable ranks: wave64 match groups + per-wave LDS counters. Per digit bit one ballot and, per
+    // 32-lane half, one xor + or: a lane keeps the lanes whose bit equals its own. Every lane of a
+    // group reads the group's counter, the lowest lane then adds the group size (LDS operations
+    // of one wave execute in order, so the reads see the value before the update).
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        const uint32_t d = rd[i] >> 16;
-        unsigned long long peers = ~0ull;
+        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+        // padding of the last tile ranks after every real key: top digit, highest indices
+        const uint32_t d = (local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1);
+        uint32_t peers_lo = ~0u, peers_hi = ~0u;
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+            const int m = __builtin_amdgcn_sbfe((int)d, b, 1);                 // 0 or -1
+            const unsigned long long bal = __ballot(m != 0);
+            peers_lo &= ~((uint32_t)bal ^ (uint32_t)m);
+            peers_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)m);
         }
-        const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
-        uint32_t prior = 0;
-        if (below == 0) {
-            prior = wave_hist[wave][d];
-            wave_hist[wave][d] = prior + (uint32_t)__popcll(peers);
-        }
-        prior = __shfl(prior, __ffsll((long long)peers) - 1, kWave);
-        rd[i] |= prior + below;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(peers_hi, __builtin_amdgcn_mbcnt_lo(peers_lo, 0u));
+        const uint32_t prior = wave_hist[wave][d];
+        if (below == 0) wave_hist[wave][d] = prior + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
+        rd[i] = (d << 16) | (prior + below);
     }
-    GSR_STAMP(3);   // ranking
-    if (lb.active && !lb.found) {                // round 1 has had the whole ranking to arrive
-        const uint32_t used = lb.consume(lane);
-#ifdef GSR_SWEEP_STAMPS
-        if (threadIdx.x == 0) { dbg_[12] += 1; dbg_[13] += used; if (!used) dbg_[14] += 1; }
-#endif
-        if (!lb.found) lb.issue(status);         // round 2 flies during the scans and the staging
-    }
+    GSR_STAMP(2);   // key-load wait + ranking
     __syncthreads();
 
-    // per digit: exclusive offsets across waves, then across digits (padding sits in the top digit)
+    // per digit: exclusive offsets across waves (-> the tile's count), publish it, start the
+    // look-back, then the exclusive scan across digits (padding sits in the top digit)
+    LookBack<RADIX, kLanesPerDigit> lb;
+    lb.d = threadIdx.x / kLanesPerDigit;
+    lb.sub = threadIdx.x % kLanesPerDigit;
+    lb.t = tile;
+    lb.active = tile != 0 && threadIdx.x < RADIX * kLanesPerDigit && (uint32_t)lb.d < spec.nbins;
+#ifdef GSR_SWEEP_NO_LOOKBACK
+    lb.active = false;       // timing experiment only: every tile scatters from the digit base (wrong output)
+#endif
     {
         uint32_t acc = 0;
         if (threadIdx.x < RADIX) {
@@ -319,6 +297,13 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
                 wave_hist[w][threadIdx.x] = acc;
                 acc += c;
             }
+            // Padding keys were counted in the top digit: they are not published.
+            const uint32_t real = (threadIdx.x == RADIX - 1) ? acc - ((uint32_t)kSortTile - valid) : acc;
+            tile_hist[threadIdx.x] = real;
+            if (threadIdx.x < spec.nbins)
+                __hip_atomic_store(status + (size_t)tile * RADIX + threadIdx.x,
+                                   (tile == 0 ? kFlagPrefix : kFlagAggregate) | real, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         uint32_t incl = acc;
 #pragma unroll
@@ -328,6 +313,7 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         }
         if (lane == kWave - 1) scan_ws[wave] = incl;
         __syncthreads();
+        if (lb.active) lb.issue(status);         // round 1 flies during the slot computation
         uint32_t wbase = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w)
@@ -335,6 +321,7 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - acc;
     }
     __syncthreads();
+    GSR_STAMP(3);   // totals + publish + scans
     // final slot of every key inside the ranked tile (kept in the low half of rd)
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
@@ -366,6 +353,8 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     __syncthreads();
     GSR_STAMP(6);   // barrier: slowest digit's look-back
     if (s_fail) return;
+    if (threadIdx.x < RADIX) run_delta[threadIdx.x] = global_start[threadIdx.x] - run_start[threadIdx.x];
+    __syncthreads();
 
     // Slice r of the ranked tile: slots [r * kStageSlots, (r + 1) * kStageSlots) pass through LDS and
     // leave as contiguous runs per digit.
@@ -388,7 +377,7 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
             if (p < valid) {
                 const KeyT k = stage_keys[q];
                 const uint32_t d = digit_of<KeyT>(k, spec);
-                const uint32_t dst = global_start[d] + (p - run_start[d]);
+                const uint32_t dst = p + run_delta[d];                       // global start - start in tile
                 if (dst < n) {
                     keys_out[dst] = k;
                     vals_out[dst] = stage_vals[q];

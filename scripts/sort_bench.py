@@ -49,7 +49,7 @@ if os.environ.get("GSR_SHOW_STAMPS"):
     def al(v): return (v + 127) // 128 * 128
     off = al(8 * n) + al(4 * n) + tiles * 256 * 8
     raw = temp[off:off + tiles * 128].view(torch.int64).view(tiles, 16).sum(0).cpu().numpy()
-    names = ["ticket", "loadwait+tilehist", "publish+digitbase", "ranking", "scans+staging", "lookback rest(d0)",
+    names = ["ticket", "issue+digitbase", "loadwait+ranking", "totals+publish+scans", "slots", "lookback(d0)",
              "bar(slowest digit)", "write-out", "-"]
     d = tiles * passes * (reps + 2)
     tot = sum(int(raw[i]) for i in range(9))
