@@ -43,7 +43,7 @@ def parse_args():
     p.add_argument("--splats", type=int, default=5_834_784)
     p.add_argument("--scene", default="garden_like", choices=["garden_like", "stress", "isotropic"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=16, help="CPU baseline renders every k-th splat")
+    p.add_argument("--cpu-sample", type=int, default=4, help="CPU baseline renders every k-th splat")
     p.add_argument("--no-rebalance", action="store_true")
     return p.parse_args()
 
@@ -90,15 +90,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # GSR_FORCE_DIST=1 runs the sharded code path (RCCL broadcast, band all-gather, re-cut) even with one
+    # rank: the only way to exercise it on a single-GPU box.
+    distributed = world > 1 or os.environ.get("GSR_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
-    from gsrast_amd import camera
+    from gsrast_amd import _capi, camera
     from gsrast_amd.rasterizer import SplatRasterizer
 
     W, H = args.width, args.height
@@ -130,6 +135,7 @@ def main():
         if exch:
             exch.gather(frame)
             torch.cuda.current_stream(device).synchronize()
+            _capi.check(rast.lib.gsr_poll_async_error(), "gsr_forward (device side)")
         return frame
 
     def sync_all():
@@ -190,7 +196,7 @@ def main():
             "duplicate": 8 * N + 20 * n_visible + 12 * R,
             "sort_pass1": 24 * R,            # one onesweep launch: 12 B read + 12 B written per pair
             "sort_pass2": 24 * R,
-            "ranges": 8 * R + 16 * T_loc,
+            "ranges": 16 * T_loc * max(1, int(np.ceil(np.log2(max(R, 2))))) + 8 * T_loc,   # two binary searches per tile
             "blend": 40 * r_f + 20 * P_loc + 8 * T_loc,
         }
         kernels = {}
@@ -235,10 +241,12 @@ def main():
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)
-        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)          # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
