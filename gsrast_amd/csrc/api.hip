@@ -309,7 +309,7 @@ int gsr_forward(gsr_forward_args* a) {
         if (d.grid_y > 1) {
             DigitSpec sy;
             sy.mode = kDigitTileY; sy.shift = 0; sy.nbins = (uint32_t)d.grid_y; sy.grid_x = (uint32_t)d.grid_x;
-            sy.magic = (uint32_t)(0x100000000ull / (uint32_t)d.grid_x) + 1u;
+            sy.inv_grid_x = 1.0f / (float)d.grid_x;
             GSR_BEGIN(GSR_STAGE_SORT_PASS2);
             GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, sy, hist_y, bs.sweep, stream, true));
             GSR_END(GSR_STAGE_SORT_PASS2);

@@ -13,6 +13,8 @@
 //          a full-height rectangle becomes coalesced 512-byte key stores.
 //  tile_ranges_kernel — reference GSCuda.cu:504-538 (identifyTileRanges), including the
 //      placement of the "last element closes its tile" test inside the else branch.
+#include <stdlib.h>
+
 #include "gsr_common.hpp"
 
 namespace gsr {
@@ -170,92 +172,94 @@ __global__ __launch_bounds__(256) void column_count_kernel(int n, const uint32_t
     if (lds_hy[threadIdx.x]) atomicAdd(&hist_y[threadIdx.x], lds_hy[threadIdx.x]);
 }
 
-constexpr int kRunCap = 6144;     // (Gaussian, column) runs resolved per LDS round
+constexpr int kColsPerBlock = 16;  // tile columns one workgroup writes (its open output streams)
+constexpr int kSmallRect = 16;     // rectangle parts up to this many tiles are written by one lane
 
+// Workgroup (b, r): the 256 depth-consecutive Gaussians of chunk b, tile columns
+// [16 r, 16 r + 16). One lane per Gaussian. For each of the 16 columns a block-wide exclusive
+// prefix of "rows of the Gaussians covering it" gives every (Gaussian, column) run its place
+// behind the chunk's start for that column; the runs are then written wave-cooperatively.
+// Keeping a workgroup to 16 columns bounds the number of output streams it appends to (2 x 16
+// partially written cache lines), which is what the L2 needs to turn the many short runs into
+// full-line writes.
 __global__ __launch_bounds__(256) void emit_columns_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                            const uint32_t* __restrict__ sorted_idx,
                                                            const uint32_t* __restrict__ rect_packed,
                                                            const uint32_t* __restrict__ col_table_incl,
                                                            uint32_t num_blocks, int grid_x,
                                                            uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
-    __shared__ uint32_t s_rect[256], s_depth[256], s_idx[256];
-    __shared__ uint32_t s_rowptr[257];          // exclusive prefix of rectangle widths inside the workgroup
-    __shared__ uint32_t s_ws[4];
-    __shared__ uint32_t s_off[kRunCap];         // output index of the first key of every (Gaussian, column) run
+    __shared__ uint32_t s_off[256][kColsPerBlock + 1];   // +1: odd stride, conflict-free column walks
+    __shared__ uint32_t s_wsum[4][kColsPerBlock];
+    __shared__ uint32_t s_colbase[kColsPerBlock];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int r = blockIdx.x * 256 + threadIdx.x;
+    const int x_lo = blockIdx.y * kColsPerBlock;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
-    s_rect[threadIdx.x] = rect;
-    s_depth[threadIdx.x] = (r < n) ? sorted_depth[r] : 0u;
-    s_idx[threadIdx.x] = (r < n) ? sorted_idx[r] : 0u;
-    {   // block exclusive scan of the widths
-        const uint32_t wv = (rect >> 8) & 0xFFu;
-        uint32_t incl = wv;
+    const int x0 = (int)(rect & 0xFFu), w = (int)((rect >> 8) & 0xFFu);
+    const uint32_t y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
+    // part of the rectangle inside this workgroup's columns
+    const int cx0 = max(x0, x_lo), cx1 = min(x0 + w, min(x_lo + kColsPerBlock, grid_x));
+    const int wr = max(0, cx1 - cx0);
+    if (__syncthreads_or(wr > 0) == 0) return;           // nothing of this chunk in these columns
+    if ((int)threadIdx.x < kColsPerBlock) {
+        const int x = x_lo + (int)threadIdx.x;
+        uint32_t base = 0;
+        if (x < grid_x) {
+            const size_t cell = (size_t)x * num_blocks + blockIdx.x;
+            base = cell ? col_table_incl[cell - 1] : 0u;
+        }
+        s_colbase[threadIdx.x] = base;
+    }
+    // per column: exclusive prefix over the 256 Gaussians of the rows they contribute
+    uint32_t pre[kColsPerBlock];
+#pragma unroll
+    for (int j = 0; j < kColsPerBlock; ++j) {
+        const int x = x_lo + j;
+        const uint32_t v = (x >= cx0 && x < cx1) ? h : 0u;
+        uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, kWave);
             if (lane >= off) incl += o;
         }
-        if (lane == kWave - 1) s_ws[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int w = 0; w < wave; ++w) base += s_ws[w];
-        s_rowptr[threadIdx.x] = base + incl - wv;
-        if (threadIdx.x == 255) s_rowptr[256] = base + incl;
-    }
-    // running output index of this workgroup in column x (exclusive scan of the column-major table)
-    uint32_t col = 0;
-    if ((int)threadIdx.x < grid_x) {
-        const size_t cell = (size_t)threadIdx.x * num_blocks + blockIdx.x;
-        col = cell ? col_table_incl[cell - 1] : 0u;
+        if (lane == kWave - 1) s_wsum[wave][j] = incl;
+        pre[j] = incl - v;
     }
     __syncthreads();
-    const uint32_t total_runs = s_rowptr[256];
-    // Rounds of at most kRunCap runs: Gaussians [g_lo, g_hi) whose runs fit the LDS table.
-    int g_lo = 0;
-    while (g_lo < 256 && s_rowptr[g_lo] < total_runs) {
-        const uint32_t run_lo = s_rowptr[g_lo];
-        int g_hi = g_lo + 1;                    // at least one Gaussian per round (w <= 255 < kRunCap)
-        while (g_hi < 256 && s_rowptr[g_hi + 1] - run_lo <= (uint32_t)kRunCap) ++g_hi;
-        // 1. column threads walk the round's Gaussians in depth order and hand out offsets
-        if ((int)threadIdx.x < grid_x) {
-            const uint32_t x = threadIdx.x;
-            for (int g = g_lo; g < g_hi; ++g) {
-                const uint32_t rc = s_rect[g];
-                const uint32_t x0 = rc & 0xFFu, w = (rc >> 8) & 0xFFu;
-                if (x - x0 < w) {
-                    s_off[s_rowptr[g] - run_lo + (x - x0)] = col;
-                    col += rc >> 24;
-                }
-            }
+#pragma unroll
+    for (int j = 0; j < kColsPerBlock; ++j) {
+        uint32_t wbase = s_colbase[j];
+        for (int ww = 0; ww < wave; ++ww) wbase += s_wsum[ww][j];
+        s_off[threadIdx.x][j] = wbase + pre[j];
+    }
+    // (s_off rows are read only by the wave that wrote them: no barrier needed)
+    const uint32_t depth = (r < n) ? sorted_depth[r] : 0u;
+    const uint32_t idx = (wr > 0) ? sorted_idx[r] : 0u;
+    const uint32_t cnt = (uint32_t)wr * h;
+    // small parts: the owning lane walks its few tiles itself
+    if (cnt > 0 && cnt <= (uint32_t)kSmallRect) {
+        uint32_t c = 0, yy = 0, base = s_off[threadIdx.x][cx0 - x_lo];
+        for (uint32_t k = 0; k < cnt; ++k) {
+            emit(keys, values, base + yy, __umul24(y0 + yy, (uint32_t)grid_x) + (uint32_t)cx0 + c, depth, idx);
+            if (++yy == h) { yy = 0; ++c; if ((int)c < wr) base = s_off[threadIdx.x][cx0 - x_lo + (int)c]; }
         }
-        __syncthreads();
-        // 2. every wave takes Gaussians g = g_lo + wave, + 4, ...; lanes cover (column, row) patches
-        for (int g = g_lo + wave; g < g_hi; g += 4) {
-            const uint32_t rc = s_rect[g];
-            const uint32_t w = (rc >> 8) & 0xFFu, h = rc >> 24;
-            if (w == 0) continue;
-            const uint32_t x0 = rc & 0xFFu, y0 = (rc >> 16) & 0xFFu;
-            const uint32_t depth = s_depth[g], idx = s_idx[g];
-            const uint32_t first = s_rowptr[g] - run_lo;
-            // rows-per-column rounded up to a power of two: 64 / hp columns per wave step
-            uint32_t hp_log = 0;
-            while ((1u << hp_log) < h && hp_log < 6) ++hp_log;
-            const uint32_t cols_per_step = (h > 64) ? 1u : (64u >> hp_log);
-            for (uint32_t c0 = 0; c0 < w; c0 += cols_per_step) {
-                if (h > 64) {
-                    const uint32_t base = s_off[first + c0];
-                    for (uint32_t yy = lane; yy < h; yy += kWave)
-                        emit(keys, values, base + yy, (y0 + yy) * (uint32_t)grid_x + x0 + c0, depth, idx);
-                } else {
-                    const uint32_t c = c0 + ((uint32_t)lane >> hp_log), yy = (uint32_t)lane & ((1u << hp_log) - 1u);
-                    if (c < w && yy < h)
-                        emit(keys, values, s_off[first + c] + yy, (y0 + yy) * (uint32_t)grid_x + x0 + c, depth, idx);
-                }
-            }
+    }
+    // large parts: one at a time, the 64 lanes walk it column-major (k -> column k / h, row k % h)
+    unsigned long long big = __ballot(cnt > (uint32_t)kSmallRect);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t scx0 = (uint32_t)__shfl(cx0, src, kWave), sy0 = __shfl(y0, src, kWave), sh = __shfl(h, src, kWave);
+        const uint32_t scnt = __shfl(cnt, src, kWave), sdepth = __shfl(depth, src, kWave), sidx = __shfl(idx, src, kWave);
+        const uint32_t* off_row = &s_off[(wave << 6) + src][scx0 - (uint32_t)x_lo];
+        const float inv_h = 1.0f / (float)sh;
+        for (uint32_t k = (uint32_t)lane; k < scnt; k += kWave) {
+            uint32_t c = (uint32_t)((float)k * inv_h);              // k < 2^16: off by at most one
+            int yy = (int)k - (int)__umul24(c, sh);
+            if (yy < 0) { --c; yy += (int)sh; }
+            if (yy >= (int)sh) { ++c; yy -= (int)sh; }
+            emit(keys, values, off_row[c] + (uint32_t)yy, __umul24(sy0 + (uint32_t)yy, (uint32_t)grid_x) + scx0 + c, sdepth, sidx);
         }
-        __syncthreads();
-        g_lo = g_hi;
     }
 }
 
@@ -331,7 +335,9 @@ int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sor
 int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_packed,
                         const uint32_t* col_table_incl, int grid_x, uint64_t* keys, uint32_t* values, hipStream_t stream) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(emit_columns_kernel, dim3(blocks), dim3(256), 0, stream, n, sorted_depth, sorted_idx, rect_packed,
+    // Tuning aid: GSR_EMIT_DYN_LDS=<bytes> of unused dynamic LDS lowers the workgroups per CU.
+    static const unsigned dyn_lds = [] { const char* e = getenv("GSR_EMIT_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    hipLaunchKernelGGL(emit_columns_kernel, dim3(blocks, (unsigned)((grid_x + kColsPerBlock - 1) / kColsPerBlock)), dim3(256), dyn_lds, stream, n, sorted_depth, sorted_idx, rect_packed,
                        col_table_incl, blocks, grid_x, keys, values);
     GSR_LAUNCH_CHECK("emit_columns_kernel");
     return GSR_OK;

@@ -11,13 +11,13 @@ enum { kDigitBits = 0, kDigitTileX = 1, kDigitTileY = 2 };
 // How a pass takes its digit out of a key.
 //   kDigitBits : (key >> shift) & (nbins - 1), nbins a power of two
 //   kDigitTileX: (key >> 32) % grid_x      kDigitTileY: (key >> 32) / grid_x
-// (magic = 2^32 / grid_x + 1; exact while tile * grid_x < 2^32)
+// (inv_grid_x = 1.0f / grid_x; exact for grids up to 255 x 255, see digit_of)
 struct DigitSpec {
     int mode;
     int shift;
     uint32_t nbins;      // <= 256
     uint32_t grid_x;
-    uint32_t magic;
+    float inv_grid_x;
 };
 
 struct SweepScratch {
