@@ -38,6 +38,7 @@ inline size_t align128(size_t v) { return (v + 127) / 128 * 128; }
 struct GeoScratch {
     char* scan_temp;          // partial sums of the two prefix scans
     uint32_t* depth_key;      // u32[N] depth bits or ~0 (written by preprocess)
+    uint32_t* rect_idx;       // u32[N] packed band-clipped rectangle in index order (written by preprocess)
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     SweepScratch sweep;       // onesweep status words for the N-sized sort
@@ -50,6 +51,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     size_t off = 0;
     g.scan_temp = base + off; off += align128(scan_temp_bytes(n));
     g.depth_key = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.rect_idx = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
@@ -261,7 +263,8 @@ int gsr_forward(gsr_forward_args* a) {
     for (bool& r : g_rb.recorded) r = false;
 
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
-    GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, d, stream));                 // :744-768
+    const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
+    GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));                 // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
@@ -285,19 +288,17 @@ int gsr_forward(gsr_forward_args* a) {
     // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
     GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
     GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
-    GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, sizeof(uint32_t), stream));
+    GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
     GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
     // Tile grids up to 255 x 255: the tile-column pass is produced directly by a column-major
     // emission and only the tile-row pass runs as a sort. Larger grids: depth-ordered emission and
     // 8-bit digit passes over the tile bits.
-    const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (xy_plan) {
         const uint32_t num_blocks = (uint32_t)((n + 255) / 256);
         uint32_t* hist_y = bs.sweep.hist;
         uint32_t* rect_packed = gs.a_k;
-        GSR_HIP_TRY(hipMemsetAsync(hist_y, 0, 256 * sizeof(uint32_t), stream));
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_y, stream));
-        GSR_STEP(launch_column_count(n, gs.b_k, gs.b_v, geom, radii, a->rects, d, rect_packed, gs.col_table, hist_y, stream));
+        GSR_STEP(launch_column_count(n, gs.b_k, gs.b_v, gs.rect_idx, d, rect_packed, gs.col_table, hist_y, stream));
         GSR_STEP(launch_inclusive_scan(gs.col_table, gs.col_table, (size_t)d.grid_x * num_blocks, gs.col_scan_temp, stream));
         GSR_END(GSR_STAGE_DEPTH_ORDER);
         // one pass: with a single tile row the column-major list is already the sorted list

@@ -135,41 +135,44 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int n, const uint32_t* _
 // rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
 __global__ __launch_bounds__(256) void column_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                            const uint32_t* __restrict__ sorted_idx,
-                                                           const float2* __restrict__ means2D,
-                                                           const int32_t* __restrict__ radii,
-                                                           const int2* __restrict__ rects, FrameDims d,
+                                                           const uint32_t* __restrict__ rect_by_index, FrameDims d,
                                                            uint32_t* __restrict__ rect_packed,
                                                            uint32_t* __restrict__ col_table, uint32_t num_blocks,
                                                            uint32_t* __restrict__ hist_y) {
-    __shared__ uint32_t lds_hx[256], lds_hy[256];
+    // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows
+    // likewise), four LDS atomics per Gaussian; one block-wide prefix sum per array then gives the
+    // per-column / per-row key counts (u32 wrap-around keeps the sums exact).
+    __shared__ uint32_t lds_hx[257], lds_hy[257];
+    __shared__ uint32_t s_ws[2][4];
     lds_hx[threadIdx.x] = 0;
     lds_hy[threadIdx.x] = 0;
+    if (threadIdx.x == 0) lds_hx[256] = lds_hy[256] = 0;
     __syncthreads();
     const int r = blockIdx.x * 256 + threadIdx.x;
     uint32_t packed = 0;
-    if (r < n && sorted_depth[r] != 0xFFFFFFFFu) {
-        const uint32_t idx = sorted_idx[r];
-        const int rad = radii[idx];
-        const float2 p = means2D[idx];
-        int ex = rad, ey = rad;
-        if (rects) { const int2 e = rects[idx]; ex = e.x; ey = e.y; }
-        const int x0 = clampi((int)((p.x - (float)ex) / 16.0f), 0, d.grid_x);
-        int y0 = clampi((int)((p.y - (float)ey) / 16.0f), 0, d.grid_y);
-        const int x1 = clampi((int)((((p.x + (float)ex) + 16.0f) - 1.0f) / 16.0f), 0, d.grid_x);
-        int y1 = clampi((int)((((p.y + (float)ey) + 16.0f) - 1.0f) / 16.0f), 0, d.grid_y);
-        y0 = clampi(y0, d.row_begin, d.row_end);
-        y1 = clampi(y1, d.row_begin, d.row_end);
-        const int w = x1 - x0, h = y1 - y0;
-        if (w > 0 && h > 0) {
-            packed = (uint32_t)x0 | ((uint32_t)w << 8) | ((uint32_t)y0 << 16) | ((uint32_t)h << 24);
-            for (int x = x0; x < x1; ++x) atomicAdd(&lds_hx[x], (uint32_t)h);
-            for (int y = y0; y < y1; ++y) atomicAdd(&lds_hy[y], (uint32_t)w);
-        }
+    // one 4-byte gather per Gaussian: preprocess left the band-clipped rectangle in index order
+    if (r < n && sorted_depth[r] != 0xFFFFFFFFu) packed = rect_by_index[sorted_idx[r]];
+    if (packed) {
+        const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
+        atomicAdd(&lds_hx[x0], h);
+        atomicSub(&lds_hx[x0 + w], h);
+        atomicAdd(&lds_hy[y0], w);
+        atomicSub(&lds_hy[y0 + h], w);
     }
     if (r < n) rect_packed[r] = packed;
     __syncthreads();
-    if ((int)threadIdx.x < d.grid_x) col_table[(size_t)threadIdx.x * num_blocks + blockIdx.x] = lds_hx[threadIdx.x];
-    if (lds_hy[threadIdx.x]) atomicAdd(&hist_y[threadIdx.x], lds_hy[threadIdx.x]);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t ix = lds_hx[threadIdx.x], iy = lds_hy[threadIdx.x];
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t ox = __shfl_up(ix, off, kWave), oy = __shfl_up(iy, off, kWave);
+        if (lane >= off) { ix += ox; iy += oy; }
+    }
+    if (lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
+    __syncthreads();
+    for (int ww = 0; ww < wave; ++ww) { ix += s_ws[0][ww]; iy += s_ws[1][ww]; }
+    if ((int)threadIdx.x < d.grid_x) col_table[(size_t)threadIdx.x * num_blocks + blockIdx.x] = ix;
+    if (iy) atomicAdd(&hist_y[threadIdx.x], iy);
 }
 
 constexpr int kColsPerBlock = 16;  // tile columns one workgroup writes (its open output streams)
@@ -321,13 +324,11 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
     return GSR_OK;
 }
 
-int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const gsr_geometry_state& g,
-                        const int32_t* radii, const int32_t* rects, const FrameDims& d, uint32_t* rect_packed,
-                        uint32_t* col_table, uint32_t* hist_y, hipStream_t stream) {
+int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
+                        const FrameDims& d, uint32_t* rect_packed, uint32_t* col_table, uint32_t* hist_y, hipStream_t stream) {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(column_count_kernel, dim3(blocks), dim3(256), 0, stream, n, sorted_depth, sorted_idx,
-                       reinterpret_cast<const float2*>(g.means2D), radii, reinterpret_cast<const int2*>(rects), d, rect_packed,
-                       col_table, blocks, hist_y);
+    hipLaunchKernelGGL(column_count_kernel, dim3(blocks), dim3(256), 0, stream, n, sorted_depth, sorted_idx, rect_by_index, d,
+                       rect_packed, col_table, blocks, hist_y);
     GSR_LAUNCH_CHECK("column_count_kernel");
     return GSR_OK;
 }

@@ -40,7 +40,7 @@ struct FrameDims {
 
 // ---- stage launchers (each asynchronous on `stream`) ----
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      uint32_t* depth_keys, const FrameDims& d, hipStream_t stream);
+                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
 
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
 size_t scan_temp_bytes(size_t n);
@@ -56,11 +56,10 @@ int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_
 size_t sort_temp_bytes(size_t n);
 struct SweepScratch;
 int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                         const SweepScratch& sc, hipStream_t stream);
+                         const SweepScratch& sc, hipStream_t stream, bool hist_ready = false);
 
-int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const gsr_geometry_state& g,
-                        const int32_t* radii, const int32_t* rects, const FrameDims& d, uint32_t* rect_packed,
-                        uint32_t* col_table, uint32_t* hist_y, hipStream_t stream);
+int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
+                        const FrameDims& d, uint32_t* rect_packed, uint32_t* col_table, uint32_t* hist_y, hipStream_t stream);
 int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_packed,
                         const uint32_t* col_table_incl, int grid_x, uint64_t* keys, uint32_t* values, hipStream_t stream);
 

@@ -78,6 +78,7 @@ struct PreprocessParams {
     float4* conic_opacity;
     uint32_t* tiles_touched;
     uint32_t* depth_keys;          // depth bits of Gaussians with >= 1 tile in this call, else ~0
+    uint32_t* rect_packed;         // x0 | w << 8 | y0 << 16 | h << 24 of the band-clipped rectangle (grids <= 255), else 0
     int2* rects;
     FrameDims dims;
 };
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     if (idx >= p.n) return;
 
     int32_t out_radius = 0;
-    uint32_t out_tiles = 0;
+    uint32_t out_tiles = 0, out_rect = 0;
 
     // The two matrices are wave-uniform: they come in through the scalar cache.
     const float4 mean = p.means3D[idx];
@@ -194,18 +195,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
                 p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[idx]);
                 out_radius = (int)my_radius;
                 out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+                if (out_tiles)
+                    out_rect = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - y0) << 24);
             }
         }
     }
     p.radii[idx] = out_radius;
     p.tiles_touched[idx] = out_tiles;
-    p.depth_keys[idx] = out_tiles ? __float_as_uint(prz) : 0xFFFFFFFFu;
+    const uint32_t dkey = out_tiles ? __float_as_uint(prz) : 0xFFFFFFFFu;
+    p.depth_keys[idx] = dkey;
+    if (p.rect_packed) p.rect_packed[idx] = out_rect;
 }
 
 }  // namespace
 
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      uint32_t* depth_keys, const FrameDims& d, hipStream_t stream) {
+                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream) {
     PreprocessParams p;
     p.n = a.num_gaussians;
     p.means3D = reinterpret_cast<const float4*>(a.means3D);
@@ -229,6 +234,7 @@ int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, in
     p.conic_opacity = reinterpret_cast<float4*>(g.conic_opacity);
     p.tiles_touched = g.tiles_touched;
     p.depth_keys = depth_keys;
+    p.rect_packed = rect_packed;
     p.rects = reinterpret_cast<int2*>(a.rects);
     p.dims = d;
     const unsigned blocks = (unsigned)((a.num_gaussians + 255) / 256);

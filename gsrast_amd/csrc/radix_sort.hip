@@ -453,9 +453,9 @@ SweepScratch carve_sweep_scratch(char* base, size_t n) {
     const size_t tiles = (n + kSortTile - 1) / kSortTile;
     SweepScratch s;
     size_t off = 0;
-    s.status = reinterpret_cast<unsigned long long*>(base + off);
+    s.ticket = reinterpret_cast<uint32_t*>(base + off); off += 128;     // directly in front of the status
+    s.status = reinterpret_cast<unsigned long long*>(base + off);      // words: one clear covers both
     off += align_up(tiles * (256 * sizeof(unsigned long long) + kDebugPerTile), 128);
-    s.ticket = reinterpret_cast<uint32_t*>(base + off); off += 128;
     s.error_word = reinterpret_cast<uint32_t*>(base + off); off += 128;
     s.hist = reinterpret_cast<uint32_t*>(base + off); off += align_up(8 * 256 * sizeof(uint32_t), 128);
     return s;
@@ -466,8 +466,7 @@ SweepScratch carve_sweep_scratch(char* base, size_t n) {
 int sweep_clear(const SweepScratch& sc, uint32_t n, uint32_t nbins, hipStream_t stream) {
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
     const size_t status_bytes = (size_t)tiles * ((size_t)1 << radix_bits_for(nbins)) * sizeof(unsigned long long);
-    GSR_HIP_TRY(hipMemsetAsync(sc.status, 0, status_bytes, stream));
-    GSR_HIP_TRY(hipMemsetAsync(sc.ticket, 0, sizeof(uint32_t), stream));
+    GSR_HIP_TRY(hipMemsetAsync(sc.ticket, 0, 128 + status_bytes, stream));
     return GSR_OK;
 }
 
@@ -507,9 +506,9 @@ int histogram_bits_u64(const uint64_t* keys, size_t n, int begin_bit, int end_bi
 // ---- depth order: stable sort of N u32 keys carrying their own index ---------------------
 // in -> a -> b -> a -> b : the result (sorted keys, original indices) is in (b_k, b_v).
 int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                         const SweepScratch& sc, hipStream_t stream) {
+                         const SweepScratch& sc, hipStream_t stream, bool hist_ready) {
     if (n == 0) return GSR_OK;
-    int rc = histogram_bits_u32(keys_in, n, 0, 32, sc.hist, stream);
+    int rc = hist_ready ? GSR_OK : histogram_bits_u32(keys_in, n, 0, 32, sc.hist, stream);
     if (rc != GSR_OK) return rc;
     const uint32_t* src_k = keys_in;
     const uint32_t* src_v = nullptr;
