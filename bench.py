@@ -208,8 +208,8 @@ def main():
         dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"),
                   key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
-                     "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)", "blend": "blend_kernel",
-                     "duplicate": "duplicate_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
+                     "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)", "blend": "blend_wave_kernel",
+                     "duplicate": "emit_columns_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
 
         def roof(k, note):
             e = kernels.get(k, {"gbs": 0.0, "ms": 0.0, "alg_bytes": 0})
