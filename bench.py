@@ -211,10 +211,19 @@ def main():
                      "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)", "blend": "blend_wave_kernel",
                      "duplicate": "emit_columns_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
 
+        # HBM bytes per launch measured with PMC counters in separate rocprofv3 passes of this same
+        # command (profiles/): valid only for the default single-GPU workload they were taken on.
+        traffic = {}
+        default_frame = (not distributed and args.scene == "garden_like" and args.splats == 5_834_784 and (W, H) == (1920, 1080))
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
+        if default_frame and os.path.exists(tpath):
+            traffic = {k: v for k, v in json.load(open(tpath)).items() if not k.startswith("_")}
+
         def roof(k, note):
             e = kernels.get(k, {"gbs": 0.0, "ms": 0.0, "alg_bytes": 0})
             return {"bound": "hbm", "kernel": dom_names[k], "achieved": e["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(e["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(e["gbs"] / HBM_PEAK_GBS, 5), "traffic": traffic.get(k),
+                    "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc, separate passes)" if k in traffic else None,
                     "algorithmic_bytes_per_launch": e["alg_bytes"], "avg_launch_ms": e["ms"], "note": note}
 
         out = {
