@@ -31,7 +31,7 @@ namespace {
 #define GSR_SWEEP_THREADS 512
 #endif
 #ifndef GSR_SWEEP_ITEMS
-#define GSR_SWEEP_ITEMS 8
+#define GSR_SWEEP_ITEMS 16
 #endif
 #ifndef GSR_SWEEP_MIN_WAVES
 #define GSR_SWEEP_MIN_WAVES 1
