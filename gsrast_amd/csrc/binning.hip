@@ -26,8 +26,29 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, ma
 
 __device__ __forceinline__ void emit(uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t pos,
                                      uint32_t tile, uint32_t depth_bits, uint32_t idx) {
+#ifndef GSR_EMIT_NO_KEYS
     keys[pos] = ((uint64_t)tile << 32) | (uint64_t)depth_bits;
+#endif
+#ifndef GSR_EMIT_NO_VALUES
     values[pos] = idx;
+#endif
+}
+
+// Two consecutive rows of one column run in one go: a 16-byte key store and an 8-byte value store.
+// The destination is only 8-byte (keys) / 4-byte (values) aligned; gfx950 under HSA runs with
+// unaligned vector-memory access enabled, so dword-aligned wide stores are legal.
+struct __attribute__((packed, aligned(8))) KeyPair { uint64_t a, b; };
+struct __attribute__((packed, aligned(4))) ValPair { uint32_t a, b; };
+__device__ __forceinline__ void emit2(uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t pos,
+                                      uint32_t tile, uint32_t tile_step, uint32_t depth_bits, uint32_t idx) {
+    KeyPair k;
+    k.a = ((uint64_t)tile << 32) | (uint64_t)depth_bits;
+    k.b = ((uint64_t)(tile + tile_step) << 32) | (uint64_t)depth_bits;
+    *reinterpret_cast<KeyPair*>(keys + pos) = k;
+    ValPair v;
+    v.a = idx;
+    v.b = idx;
+    *reinterpret_cast<ValPair*>(values + pos) = v;
 }
 
 // Tiles covered by each depth-ordered Gaussian (0 for culled ones, whose depth key is ~0).
@@ -175,8 +196,14 @@ __global__ __launch_bounds__(256) void column_count_kernel(int n, const uint32_t
     if (iy) atomicAdd(&hist_y[threadIdx.x], iy);
 }
 
-constexpr int kColsPerBlock = 16;  // tile columns one workgroup writes (its open output streams)
-constexpr int kSmallRect = 16;     // rectangle parts up to this many tiles are written by one lane
+#ifndef GSR_EMIT_COLS
+#define GSR_EMIT_COLS 16
+#endif
+constexpr int kColsPerBlock = GSR_EMIT_COLS;  // tile columns one workgroup writes (its open output streams)
+#ifndef GSR_EMIT_SMALL
+#define GSR_EMIT_SMALL 16
+#endif
+constexpr int kSmallRect = GSR_EMIT_SMALL;     // rectangle parts up to this many tiles are written by one lane
 
 // Workgroup (b, r): the 256 depth-consecutive Gaussians of chunk b, tile columns
 // [16 r, 16 r + 16). One lane per Gaussian. For each of the 16 columns a block-wide exclusive
@@ -255,13 +282,20 @@ __global__ __launch_bounds__(256) void emit_columns_kernel(int n, const uint32_t
         const uint32_t scx0 = (uint32_t)__shfl(cx0, src, kWave), sy0 = __shfl(y0, src, kWave), sh = __shfl(h, src, kWave);
         const uint32_t scnt = __shfl(cnt, src, kWave), sdepth = __shfl(depth, src, kWave), sidx = __shfl(idx, src, kWave);
         const uint32_t* off_row = &s_off[(wave << 6) + src][scx0 - (uint32_t)x_lo];
-        const float inv_h = 1.0f / (float)sh;
-        for (uint32_t k = (uint32_t)lane; k < scnt; k += kWave) {
-            uint32_t c = (uint32_t)((float)k * inv_h);              // k < 2^16: off by at most one
-            int yy = (int)k - (int)__umul24(c, sh);
-            if (yy < 0) { --c; yy += (int)sh; }
-            if (yy >= (int)sh) { ++c; yy -= (int)sh; }
-            emit(keys, values, off_row[c] + (uint32_t)yy, __umul24(sy0 + (uint32_t)yy, (uint32_t)grid_x) + scx0 + c, sdepth, sidx);
+        // lanes take PAIRS of rows: pair k -> column k / hp, rows 2 (k % hp) and 2 (k % hp) + 1
+        const uint32_t hp = (sh + 1u) >> 1;
+        const uint32_t sw = scnt / sh, npairs = sw * hp;
+        const float inv_hp = 1.0f / (float)hp;
+        for (uint32_t k = (uint32_t)lane; k < npairs; k += kWave) {
+            uint32_t c = (uint32_t)((float)k * inv_hp);             // k < 2^16: off by at most one
+            int j = (int)k - (int)__umul24(c, hp);
+            if (j < 0) { --c; j += (int)hp; }
+            if (j >= (int)hp) { ++c; j -= (int)hp; }
+            const uint32_t yy = 2u * (uint32_t)j;
+            const uint32_t pos = off_row[c] + yy;
+            const uint32_t tile = __umul24(sy0 + yy, (uint32_t)grid_x) + scx0 + c;
+            if (yy + 1u < sh) emit2(keys, values, pos, tile, (uint32_t)grid_x, sdepth, sidx);
+            else emit(keys, values, pos, tile, sdepth, sidx);
         }
     }
 }
