@@ -172,6 +172,17 @@ size_t gsr_sort_temp_bytes(size_t n);
 int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
                            uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, void* stream);
 
+/* ---- scene loading (next row after the hot path) ---- */
+/* Header of a 3DGS .ply as the reference reads it (apps/gsrast/SplatData.cpp:114-145): vertex
+ * count = third token of the third line; data starts after the "end_header" line. Host only.
+ * Returns GSR_ERR_INVALID_ARG if the file cannot be opened or has no end_header. */
+int gsr_ply_parse_header(const char* path, int* num_splats, long long* data_offset);
+/* Activations of SplatData::loadFromPly (SplatData.cpp:28-66) on the GPU: raw_device holds n
+ * records of 62 floats (SplatData.hpp:17-25) in HBM; outputs are the SoA gsr_forward takes
+ * (means3D/scales/rotations vec4[n], opacities f32[n], shs f32[48 n]). Asynchronous on stream. */
+int gsr_ply_activate(const float* raw_device, int n, float* means3D, float* scales, float* rotations,
+                     float* opacities, float* shs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

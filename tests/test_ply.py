@@ -1,0 +1,72 @@
+"""The .ply loader row: header quirks on the CPU, activations on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from gsrast_amd import ply
+from oracle import ply_oracle
+
+
+def _random_scene(n, seed=3):
+    rng = np.random.default_rng(seed)
+    return dict(position=rng.normal(0, 1.5, (n, 3)).astype(np.float32), sh=rng.normal(0, 0.4, (n, 48)).astype(np.float32),
+                opacity_logit=rng.normal(0, 3, n).astype(np.float32), log_scale=rng.normal(-3.0, 0.8, (n, 3)).astype(np.float32),
+                rotation=rng.normal(0, 1, (n, 4)).astype(np.float32), normal=rng.normal(0, 1, (n, 3)).astype(np.float32))
+
+
+def test_header_is_read_the_way_the_reference_reads_it(tmp_path):
+    p = str(tmp_path / "a.ply")
+    ply.write_ply(p, **_random_scene(37))
+    n, off = ply.parse_header(p)
+    assert n == 37 and os.path.getsize(p) - off == 37 * 248
+    # the count is the third token of the third line, whatever the first two tokens say
+    q = str(tmp_path / "b.ply")
+    with open(q, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nfoo bar 5 trailing\ncomment anything\nend_header\n" + b"\0" * (5 * 248))
+    assert ply.parse_header(q) == (5, os.path.getsize(q) - 5 * 248)
+    with open(q, "wb") as f:
+        f.write(b"ply\nformat x\nelement vertex 5\nno terminator\n")
+    with pytest.raises(ValueError):
+        ply.parse_header(q)
+    o = ply_oracle.load(p)
+    assert o["means3D"].shape == (37, 4) and (o["means3D"][:, 3] == 1).all()
+    assert np.allclose(np.linalg.norm(o["rotations"], axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_activations_match_the_cpu_loader(tmp_path):
+    p = str(tmp_path / "scene.ply")
+    n = 100_003                                            # not a multiple of the wave / block size
+    ply.write_ply(p, **_random_scene(n, seed=9))
+    want = ply_oracle.load(p)
+    got = ply.load_ply(p)
+    assert np.array_equal(got["means3D"].cpu().numpy(), want["means3D"])
+    assert np.array_equal(got["shs"].cpu().numpy(), want["shs"])
+    assert np.array_equal(got["rotations"].cpu().numpy(), want["rotations"])          # IEEE sqrt / divide
+    for k in ("scales", "opacities"):                      # expf: device vs numpy, a few ulp at most
+        a, b = got[k].cpu().numpy(), want[k]
+        assert np.abs(a - b).max() <= 4e-7 * np.abs(b).max() + 1e-7 * 0 + 3 * np.spacing(np.abs(b)).max(), k
+    assert np.allclose(got["bbox_min"].cpu().numpy(), want["bbox_min"]) and np.allclose(got["center"].cpu().numpy(), want["center"], atol=1e-5)
+    with open(p, "r+b") as f:                               # a truncated file is rejected (SplatData.cpp:147-152)
+        f.truncate(os.path.getsize(p) - 100)
+    with pytest.raises(ValueError):
+        ply.load_ply(p)
+
+
+@pytest.mark.gpu
+def test_scene_loaded_from_ply_renders_like_the_in_memory_scene(tmp_path):
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    sc = scenes.isotropic_scene(1000, 42)
+    p = str(tmp_path / "iso.ply")
+    opac = np.clip(sc["opacities"].astype(np.float64), 1e-6, 1 - 1e-6)
+    ply.write_ply(p, sc["means3D"][:, :3], sc["shs"], np.log(opac / (1 - opac)), np.log(sc["scales"][:, :3]), sc["rotations"])
+    loaded = ply.load_ply(p)
+    cam = camera.default_camera(128, 128)
+    a, b = SplatRasterizer(128, 128), SplatRasterizer(128, 128)
+    a.configure_from_scene(sc)
+    b.configure_from_scene({k: loaded[k] for k in ("means3D", "scales", "rotations", "opacities", "shs")})
+    ia, ib = a.draw(cam).cpu().numpy(), b.draw(cam).cpu().numpy()
+    assert np.abs(ia - ib).max() <= 2e-3        # log/exp round trip of scales and opacities moves a few thresholds
+    assert abs(a.last_num_rendered - b.last_num_rendered) <= a.last_num_rendered // 200
