@@ -42,8 +42,7 @@ struct GeoScratch {
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     SweepScratch sweep;       // onesweep status words for the N-sized sort
-    uint32_t* col_table;      // [tile column][workgroup of 256 Gaussians] key counts, then their scan
-    char* col_scan_temp;
+    char* emit_scratch;       // column-major emission: [chunk][column] table, block partials, column starts
     size_t bytes;
 };
 GeoScratch carve_geo_scratch(char* base, size_t n) {
@@ -57,9 +56,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
-    const size_t col_cells = ((n + 255) / 256) * 256;       // up to 256 tile columns
-    g.col_table = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * col_cells);
-    g.col_scan_temp = base + off; off += align128(scan_temp_bytes(col_cells));
+    g.emit_scratch = base + off; off += align128(emit_scratch_bytes(n));
     g.bytes = off;
     return g;
 }
@@ -294,19 +291,21 @@ int gsr_forward(gsr_forward_args* a) {
     // emission and only the tile-row pass runs as a sort. Larger grids: depth-ordered emission and
     // 8-bit digit passes over the tile bits.
     if (xy_plan) {
-        const uint32_t num_blocks = (uint32_t)((n + 255) / 256);
         uint32_t* hist_y = bs.sweep.hist;
         uint32_t* rect_packed = gs.a_k;
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_y, stream));
-        GSR_STEP(launch_column_count(n, gs.b_k, gs.b_v, gs.rect_idx, d, rect_packed, gs.col_table, hist_y, stream));
-        GSR_STEP(launch_inclusive_scan(gs.col_table, gs.col_table, (size_t)d.grid_x * num_blocks, gs.col_scan_temp, stream));
-        GSR_END(GSR_STAGE_DEPTH_ORDER);
         // one pass: with a single tile row the column-major list is already the sorted list
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
         uint32_t* emit_v = d.grid_y > 1 ? bin.values_unsorted : bin.values;
-        GSR_BEGIN(GSR_STAGE_DUPLICATE);
-        GSR_STEP(launch_emit_columns(n, gs.b_k, gs.b_v, rect_packed, gs.col_table, d.grid_x, emit_k, emit_v, stream));   // :787
-        GSR_END(GSR_STAGE_DUPLICATE);
+        // the depth-order stage ends and the emission stage starts at an event inside the launcher
+        GSR_STEP(launch_emit_columns(n, gs.b_k, gs.b_v, gs.rect_idx, d.grid_x, d.grid_y, rect_packed, gs.emit_scratch, hist_y,
+                                     emit_k, emit_v, stream, profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
+                                     profile ? g_rb.ev[2 * GSR_STAGE_DUPLICATE] : nullptr));   // :787
+        if (profile) {
+            g_rb.recorded[GSR_STAGE_DEPTH_ORDER] = true;
+            GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], stream));
+            g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
+        }
         if (d.grid_y > 1) {
             DigitSpec sy;
             sy.mode = kDigitTileY; sy.shift = 0; sy.nbins = (uint32_t)d.grid_y; sy.grid_x = (uint32_t)d.grid_x;

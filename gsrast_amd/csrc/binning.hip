@@ -34,23 +34,6 @@ __device__ __forceinline__ void emit(uint64_t* __restrict__ keys, uint32_t* __re
 #endif
 }
 
-// Two consecutive rows of one column run in one go: a 16-byte key store and an 8-byte value store.
-// The destination is only 8-byte (keys) / 4-byte (values) aligned; gfx950 under HSA runs with
-// unaligned vector-memory access enabled, so dword-aligned wide stores are legal.
-struct __attribute__((packed, aligned(8))) KeyPair { uint64_t a, b; };
-struct __attribute__((packed, aligned(4))) ValPair { uint32_t a, b; };
-__device__ __forceinline__ void emit2(uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t pos,
-                                      uint32_t tile, uint32_t tile_step, uint32_t depth_bits, uint32_t idx) {
-    KeyPair k;
-    k.a = ((uint64_t)tile << 32) | (uint64_t)depth_bits;
-    k.b = ((uint64_t)(tile + tile_step) << 32) | (uint64_t)depth_bits;
-    *reinterpret_cast<KeyPair*>(keys + pos) = k;
-    ValPair v;
-    v.a = idx;
-    v.b = idx;
-    *reinterpret_cast<ValPair*>(values + pos) = v;
-}
-
 // Tiles covered by each depth-ordered Gaussian (0 for culled ones, whose depth key is ~0).
 __global__ __launch_bounds__(256) void gather_counts_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                             const uint32_t* __restrict__ sorted_idx,
@@ -142,164 +125,6 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int n, const uint32_t* _
     }
 }
 
-// ---- column-major emission (tile grids up to 255 x 255) -----------------------------------
-// The first of the two tile passes (stable sort on the tile column x) is not run as a sort at
-// all: its result is written directly. In depth order, the keys of column x are, Gaussian after
-// Gaussian, the h rows of the rectangle — so key (g, x, y) lands at
-//     start[x] + sum of h over earlier Gaussians covering x + (y - y0).
-// column_count_kernel gets the per-workgroup (256 depth-consecutive Gaussians) column sums, one
-// scan over the column-major table turns them into start offsets, emit_columns_kernel resolves
-// the order inside a workgroup in LDS and writes every (Gaussian, column) run as one burst.
-// What reaches the remaining pass (stable on the tile row y) is exactly what a stable x pass
-// over the depth-ordered list would have produced.
-
-// rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
-__global__ __launch_bounds__(256) void column_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
-                                                           const uint32_t* __restrict__ sorted_idx,
-                                                           const uint32_t* __restrict__ rect_by_index, FrameDims d,
-                                                           uint32_t* __restrict__ rect_packed,
-                                                           uint32_t* __restrict__ col_table, uint32_t num_blocks,
-                                                           uint32_t* __restrict__ hist_y) {
-    // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows
-    // likewise), four LDS atomics per Gaussian; one block-wide prefix sum per array then gives the
-    // per-column / per-row key counts (u32 wrap-around keeps the sums exact).
-    __shared__ uint32_t lds_hx[257], lds_hy[257];
-    __shared__ uint32_t s_ws[2][4];
-    lds_hx[threadIdx.x] = 0;
-    lds_hy[threadIdx.x] = 0;
-    if (threadIdx.x == 0) lds_hx[256] = lds_hy[256] = 0;
-    __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    uint32_t packed = 0;
-    // one 4-byte gather per Gaussian: preprocess left the band-clipped rectangle in index order
-    if (r < n && sorted_depth[r] != 0xFFFFFFFFu) packed = rect_by_index[sorted_idx[r]];
-    if (packed) {
-        const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
-        atomicAdd(&lds_hx[x0], h);
-        atomicSub(&lds_hx[x0 + w], h);
-        atomicAdd(&lds_hy[y0], w);
-        atomicSub(&lds_hy[y0 + h], w);
-    }
-    if (r < n) rect_packed[r] = packed;
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    uint32_t ix = lds_hx[threadIdx.x], iy = lds_hy[threadIdx.x];
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t ox = __shfl_up(ix, off, kWave), oy = __shfl_up(iy, off, kWave);
-        if (lane >= off) { ix += ox; iy += oy; }
-    }
-    if (lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
-    __syncthreads();
-    for (int ww = 0; ww < wave; ++ww) { ix += s_ws[0][ww]; iy += s_ws[1][ww]; }
-    if ((int)threadIdx.x < d.grid_x) col_table[(size_t)threadIdx.x * num_blocks + blockIdx.x] = ix;
-    if (iy) atomicAdd(&hist_y[threadIdx.x], iy);
-}
-
-#ifndef GSR_EMIT_COLS
-#define GSR_EMIT_COLS 16
-#endif
-constexpr int kColsPerBlock = GSR_EMIT_COLS;  // tile columns one workgroup writes (its open output streams)
-#ifndef GSR_EMIT_SMALL
-#define GSR_EMIT_SMALL 16
-#endif
-constexpr int kSmallRect = GSR_EMIT_SMALL;     // rectangle parts up to this many tiles are written by one lane
-
-// Workgroup (b, r): the 256 depth-consecutive Gaussians of chunk b, tile columns
-// [16 r, 16 r + 16). One lane per Gaussian. For each of the 16 columns a block-wide exclusive
-// prefix of "rows of the Gaussians covering it" gives every (Gaussian, column) run its place
-// behind the chunk's start for that column; the runs are then written wave-cooperatively.
-// Keeping a workgroup to 16 columns bounds the number of output streams it appends to (2 x 16
-// partially written cache lines), which is what the L2 needs to turn the many short runs into
-// full-line writes.
-__global__ __launch_bounds__(256) void emit_columns_kernel(int n, const uint32_t* __restrict__ sorted_depth,
-                                                           const uint32_t* __restrict__ sorted_idx,
-                                                           const uint32_t* __restrict__ rect_packed,
-                                                           const uint32_t* __restrict__ col_table_incl,
-                                                           uint32_t num_blocks, int grid_x,
-                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
-    __shared__ uint32_t s_off[256][kColsPerBlock + 1];   // +1: odd stride, conflict-free column walks
-    __shared__ uint32_t s_wsum[4][kColsPerBlock];
-    __shared__ uint32_t s_colbase[kColsPerBlock];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    const int x_lo = blockIdx.y * kColsPerBlock;
-    const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
-    const int x0 = (int)(rect & 0xFFu), w = (int)((rect >> 8) & 0xFFu);
-    const uint32_t y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
-    // part of the rectangle inside this workgroup's columns
-    const int cx0 = max(x0, x_lo), cx1 = min(x0 + w, min(x_lo + kColsPerBlock, grid_x));
-    const int wr = max(0, cx1 - cx0);
-    if (__syncthreads_or(wr > 0) == 0) return;           // nothing of this chunk in these columns
-    if ((int)threadIdx.x < kColsPerBlock) {
-        const int x = x_lo + (int)threadIdx.x;
-        uint32_t base = 0;
-        if (x < grid_x) {
-            const size_t cell = (size_t)x * num_blocks + blockIdx.x;
-            base = cell ? col_table_incl[cell - 1] : 0u;
-        }
-        s_colbase[threadIdx.x] = base;
-    }
-    // per column: exclusive prefix over the 256 Gaussians of the rows they contribute
-    uint32_t pre[kColsPerBlock];
-#pragma unroll
-    for (int j = 0; j < kColsPerBlock; ++j) {
-        const int x = x_lo + j;
-        const uint32_t v = (x >= cx0 && x < cx1) ? h : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += o;
-        }
-        if (lane == kWave - 1) s_wsum[wave][j] = incl;
-        pre[j] = incl - v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kColsPerBlock; ++j) {
-        uint32_t wbase = s_colbase[j];
-        for (int ww = 0; ww < wave; ++ww) wbase += s_wsum[ww][j];
-        s_off[threadIdx.x][j] = wbase + pre[j];
-    }
-    // (s_off rows are read only by the wave that wrote them: no barrier needed)
-    const uint32_t depth = (r < n) ? sorted_depth[r] : 0u;
-    const uint32_t idx = (wr > 0) ? sorted_idx[r] : 0u;
-    const uint32_t cnt = (uint32_t)wr * h;
-    // small parts: the owning lane walks its few tiles itself
-    if (cnt > 0 && cnt <= (uint32_t)kSmallRect) {
-        uint32_t c = 0, yy = 0, base = s_off[threadIdx.x][cx0 - x_lo];
-        for (uint32_t k = 0; k < cnt; ++k) {
-            emit(keys, values, base + yy, __umul24(y0 + yy, (uint32_t)grid_x) + (uint32_t)cx0 + c, depth, idx);
-            if (++yy == h) { yy = 0; ++c; if ((int)c < wr) base = s_off[threadIdx.x][cx0 - x_lo + (int)c]; }
-        }
-    }
-    // large parts: one at a time, the 64 lanes walk it column-major (k -> column k / h, row k % h)
-    unsigned long long big = __ballot(cnt > (uint32_t)kSmallRect);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t scx0 = (uint32_t)__shfl(cx0, src, kWave), sy0 = __shfl(y0, src, kWave), sh = __shfl(h, src, kWave);
-        const uint32_t scnt = __shfl(cnt, src, kWave), sdepth = __shfl(depth, src, kWave), sidx = __shfl(idx, src, kWave);
-        const uint32_t* off_row = &s_off[(wave << 6) + src][scx0 - (uint32_t)x_lo];
-        // lanes take PAIRS of rows: pair k -> column k / hp, rows 2 (k % hp) and 2 (k % hp) + 1
-        const uint32_t hp = (sh + 1u) >> 1;
-        const uint32_t sw = scnt / sh, npairs = sw * hp;
-        const float inv_hp = 1.0f / (float)hp;
-        for (uint32_t k = (uint32_t)lane; k < npairs; k += kWave) {
-            uint32_t c = (uint32_t)((float)k * inv_hp);             // k < 2^16: off by at most one
-            int j = (int)k - (int)__umul24(c, hp);
-            if (j < 0) { --c; j += (int)hp; }
-            if (j >= (int)hp) { ++c; j -= (int)hp; }
-            const uint32_t yy = 2u * (uint32_t)j;
-            const uint32_t pos = off_row[c] + yy;
-            const uint32_t tile = __umul24(sy0 + yy, (uint32_t)grid_x) + scx0 + c;
-            if (yy + 1u < sh) emit2(keys, values, pos, tile, (uint32_t)grid_x, sdepth, sidx);
-            else emit(keys, values, pos, tile, sdepth, sidx);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys, size_t n,
                                                           uint2* __restrict__ ranges) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -355,26 +180,6 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
                        reinterpret_cast<const float2*>(g.means2D), radii, reinterpret_cast<const int2*>(rects), d, keys,
                        values, hist_x, hist_y);
     GSR_LAUNCH_CHECK("duplicate_kernel");
-    return GSR_OK;
-}
-
-int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
-                        const FrameDims& d, uint32_t* rect_packed, uint32_t* col_table, uint32_t* hist_y, hipStream_t stream) {
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(column_count_kernel, dim3(blocks), dim3(256), 0, stream, n, sorted_depth, sorted_idx, rect_by_index, d,
-                       rect_packed, col_table, blocks, hist_y);
-    GSR_LAUNCH_CHECK("column_count_kernel");
-    return GSR_OK;
-}
-
-int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_packed,
-                        const uint32_t* col_table_incl, int grid_x, uint64_t* keys, uint32_t* values, hipStream_t stream) {
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    // Tuning aid: GSR_EMIT_DYN_LDS=<bytes> of unused dynamic LDS lowers the workgroups per CU.
-    static const unsigned dyn_lds = [] { const char* e = getenv("GSR_EMIT_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-    hipLaunchKernelGGL(emit_columns_kernel, dim3(blocks, (unsigned)((grid_x + kColsPerBlock - 1) / kColsPerBlock)), dim3(256), dyn_lds, stream, n, sorted_depth, sorted_idx, rect_packed,
-                       col_table_incl, blocks, grid_x, keys, values);
-    GSR_LAUNCH_CHECK("emit_columns_kernel");
     return GSR_OK;
 }
 

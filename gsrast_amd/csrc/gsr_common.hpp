@@ -58,10 +58,12 @@ struct SweepScratch;
 int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
                          const SweepScratch& sc, hipStream_t stream, bool hist_ready = false);
 
-int launch_column_count(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
-                        const FrameDims& d, uint32_t* rect_packed, uint32_t* col_table, uint32_t* hist_y, hipStream_t stream);
-int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_packed,
-                        const uint32_t* col_table_incl, int grid_x, uint64_t* keys, uint32_t* values, hipStream_t stream);
+// Column-major emission (emit.hip): count, column scan and emission. The two events (may be null)
+// are recorded between the N-sized preparation and the emission kernel, for stage timing.
+size_t emit_scratch_bytes(size_t n);
+int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
+                        int grid_x, int grid_y, uint32_t* rect_packed, char* scratch, uint32_t* hist_y, uint64_t* keys,
+                        uint32_t* values, hipStream_t stream, hipEvent_t mark_prep_end, hipEvent_t mark_emit_begin);
 
 int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, hipStream_t stream);
 
