@@ -15,6 +15,10 @@ __global__ void wr(uint64_t* k, uint32_t* v, size_t n, int run) {
     if (MODE == 4) { // unaligned runs: run r of length `run` starts at r*(run+3) (8-byte aligned only), lanes = consecutive elements
         for (; i < n; i += stride) { size_t r = i / run, o = i % run; size_t nr = n / (run + 3); size_t rr = (r * 2654435761ull) % nr; k[rr * (run + 3) + o] = i; v[rr * (run + 3) + o] = (uint32_t)i; }
     }
+    if (MODE == 5) { // like 4 but WITHOUT gaps: run r starts at r*run, runs visited in hashed order, element o of a run by lane o
+        size_t nr = n / run;
+        for (; i < n; i += stride) { size_t r = i / run, o = i % run; size_t rr = (r * 2654435761ull) % nr; k[rr * run + o] = i; v[rr * run + o] = (uint32_t)i; }
+    }
     if (MODE == 3) { for (; i < n; i += stride) { k[i] = i; } }                                          // keys only
 }
 int main() {
@@ -32,6 +36,7 @@ int main() {
         run("keys only 8B sequential", [&] { wr<3><<<blocks, 256>>>(k, v, n, 0); }, n * 8.0);
         for (int r : {8, 32, 128, 512}) { char nm[64]; snprintf(nm, 64, "scattered runs of %d", r); run(nm, [&] { wr<2><<<blocks, 256>>>(k, v, n, r); }, n * 12.0); }
         for (int r : {5, 13, 29, 61, 125}) { char nm[64]; snprintf(nm, 64, "UNALIGNED scattered runs of %d", r); run(nm, [&] { wr<4><<<blocks, 256>>>(k, v, n, r); }, n * 12.0); }
+        for (int r : {5, 13, 29, 61, 125}) { char nm[64]; snprintf(nm, 64, "gapless odd runs of %d (hashed order)", r); run(nm, [&] { wr<5><<<blocks, 256>>>(k, v, n, r); }, n * 12.0); }
     }
     return 0;
 }
