@@ -81,12 +81,29 @@ __global__ __launch_bounds__(kThreads) void histogram_bits_kernel(const KeyT* __
     for (int i = threadIdx.x; i < passes * 256; i += kThreads) lds[i] = 0;
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride) {
-        const KeyT k = keys[e];
+    const size_t rounds = (n + stride - 1) / stride;
+    for (size_t it = 0; it < rounds; ++it) {
+        const size_t e = it * stride + (size_t)blockIdx.x * kThreads + threadIdx.x;
+        const bool live = e < n;
+        const KeyT k = live ? keys[e] : (KeyT)0;
         for (int p = 0; p < passes; ++p) {
             const int shift = first_shift + 8 * p;
             const uint32_t mask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
-            atomicAdd(&lds[p * 256 + ((uint32_t)(k >> shift) & mask)], 1u);
+            const uint32_t d = (uint32_t)(k >> shift) & mask;
+            if (p == passes - 1 && passes > 1) {
+                // The top digit of real keys (float bit patterns, tile ids) takes few distinct values: one
+                // LDS atomic per distinct value and wave instead of 64 colliding on the same counter.
+                unsigned long long todo = __ballot(live);
+                while (todo) {
+                    const uint32_t v = (uint32_t)__shfl((int)d, __ffsll((long long)todo) - 1, kWave);
+                    const unsigned long long same = __ballot(live && d == v) & todo;
+                    if ((threadIdx.x & (kWave - 1)) == (uint32_t)(__ffsll((long long)same) - 1))
+                        atomicAdd(&lds[p * 256 + v], (uint32_t)__popcll(same));
+                    todo &= ~same;
+                }
+            } else if (live) {
+                atomicAdd(&lds[p * 256 + d], 1u);
+            }
         }
     }
     __syncthreads();
