@@ -23,6 +23,7 @@ GSR_ERR_INTERNAL = 6
 
 GSR_FLAG_PROFILE = 0x1
 GSR_FLAG_COUNT_STAGED = 0x2
+GSR_FLAG_SEMANTICS_INRIA = 0x4
 GSR_NUM_STAGES = 8
 STAGE_NAMES = ("preprocess", "scan", "depth_order", "duplicate", "sort_pass1", "sort_pass2", "ranges", "blend")
 

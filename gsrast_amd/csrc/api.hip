@@ -217,6 +217,9 @@ int gsr_forward(gsr_forward_args* a) {
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
     const bool count_staged = (a->flags & GSR_FLAG_COUNT_STAGED) != 0;
+    const bool inria = (a->flags & GSR_FLAG_SEMANTICS_INRIA) != 0;
+    if (inria && !a->cam_pos && !a->colors_precomp) return fail(GSR_ERR_INVALID_ARG);
+    const int32_t* rects_in = inria ? nullptr : a->rects;      // upstream rectangles are radius-based
     int rc;
     if ((rc = g_rb.ensure()) != GSR_OK) return fail(rc);
     if (profile && (rc = g_rb.ensure_events()) != GSR_OK) return fail(rc);
@@ -261,7 +264,10 @@ int gsr_forward(gsr_forward_args* a) {
 
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
-    GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));                 // :744-768
+    if (inria)
+        GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));
+    else
+        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));                 // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
@@ -272,7 +278,16 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_HIP_TRY(hipStreamSynchronize(stream));
     const uint32_t R = *g_rb.host;
     a->num_rendered = R;
-    if (R == 0) return fail(GSR_OK);                                                        // :775-778
+    const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
+    if (R == 0) {
+        if (!inria) return fail(GSR_OK);                                                    // :775-778
+        // upstream still runs the tile loop: every pixel gets the background
+        GSR_HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
+        GSR_STEP(launch_blend(d, img.ranges, nullptr, geom.means2D, a->colors_precomp ? a->colors_precomp : geom.rgb,
+                              geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color, nullptr,
+                              t_cutoff, stream));
+        return fail(GSR_OK);
+    }
 
     char* bin_chunk = a->binning_alloc(a->binning_user, gsr_required_binning(R) + 128);    // :782-784
     if (!bin_chunk) return fail(GSR_ERR_ALLOC);
@@ -323,7 +338,7 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_inclusive_scan(gs.a_k, gs.a_k, (size_t)n, gs.scan_temp, stream));
         GSR_END(GSR_STAGE_DEPTH_ORDER);
         GSR_BEGIN(GSR_STAGE_DUPLICATE);
-        GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, a->rects, d, bin.keys_unsorted,
+        GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, rects_in, d, bin.keys_unsorted,
                                   bin.values_unsorted, nullptr, nullptr, stream));         // :787
         GSR_END(GSR_STAGE_DUPLICATE);
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
@@ -333,14 +348,14 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_END(GSR_STAGE_SORT_PASS2);
     }
     GSR_BEGIN(GSR_STAGE_RANGES);
-    GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, stream));              // :800-801
+    GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, inria, stream));              // :800-801
     GSR_END(GSR_STAGE_RANGES);
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     GSR_BEGIN(GSR_STAGE_BLEND);
     GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                           img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                          stream));                                                        // :804-810
+                          t_cutoff, stream));                                                        // :804-810
     GSR_END(GSR_STAGE_BLEND);
 
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 1, gs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __rest
 // key of tile t and of tile t + 1 by two interleaved binary searches (2 x ~log2 R dependent loads).
 // Tiles that own no key keep (0, 0) and the R == 1 quirk (the lone tile is never closed) is kept.
 __global__ __launch_bounds__(256) void tile_ranges_search_kernel(const uint64_t* __restrict__ keys, uint32_t n,
-                                                                 uint2* __restrict__ ranges, uint32_t num_tiles) {
+                                                                 uint2* __restrict__ ranges, uint32_t num_tiles,
+                                                                 bool close_single) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= num_tiles) return;
     uint32_t lo_a = 0, hi_a = n, lo_b = 0, hi_b = n;      // lower bounds of tile t (a) and t + 1 (b)
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void tile_ranges_search_kernel(const uint64_t*
         if (lo_b < hi_b) { if (kb < t + 1) lo_b = mid_b + 1; else hi_b = mid_b; }
     }
     uint2 r = make_uint2(0u, 0u);
-    if (lo_b > lo_a && n > 1) r = make_uint2(lo_a, lo_b);
+    if (lo_b > lo_a && (n > 1 || close_single)) r = make_uint2(lo_a, lo_b);
     ranges[t] = r;
 }
 
@@ -183,15 +184,15 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
     return GSR_OK;
 }
 
-int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, hipStream_t stream) {
+int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream) {
     if (n == 0) {
         GSR_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, stream));
         return GSR_OK;
     }
     // One thread per tile beats one thread per key as soon as there are more keys than a few per tile.
-    if (n >= (size_t)num_tiles * 8 && n < 0xFFFFFFFFull) {
+    if ((n >= (size_t)num_tiles * 8 || close_single) && n < 0xFFFFFFFFull) {
         hipLaunchKernelGGL(tile_ranges_search_kernel, dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, stream, keys,
-                           (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles);
+                           (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles, close_single);
         GSR_LAUNCH_CHECK("tile_ranges_search_kernel");
         return GSR_OK;
     }

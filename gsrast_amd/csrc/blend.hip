@@ -35,6 +35,7 @@ struct BlendParams {
     const float* background;
     float* out_color;
     unsigned long long* staged_counter;
+    float t_cutoff;                // transmittance below which a pixel is finished (0.001 gscuda, 1e-4 upstream)
     FrameDims dims;
     int num_tiles;                 // tiles in [row_begin,row_end)
 };
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const BlendParams p) {
             const float alpha = fminf(0.99f, co.w * __expf(power));
             const bool live = candidate && !(alpha < 1.0f / 255.0f);
             const float test = T * (1.0f - alpha);
-            const bool stop = live && test < 0.001f;
+            const bool stop = live && test < p.t_cutoff;
             if (live && !stop) {
                 const float4 c = s_rgb[j];
                 cr += c.x * alpha * T;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
                     const float alpha = fminf(0.99f, co.w * __expf(power[k]));
                     const bool live = cand[k] && !(alpha < 1.0f / 255.0f);
                     const float test = T[k] * (1.0f - alpha);
-                    const bool stop = live && test < 0.001f;
+                    const bool stop = live && test < p.t_cutoff;
                     if (live && !stop) {
                         cr[k] += col.x * alpha * T[k];
                         cg[k] += col.y * alpha * T[k];
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
 int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
-                 unsigned long long* staged_counter, hipStream_t stream) {
+                 unsigned long long* staged_counter, float t_cutoff, hipStream_t stream) {
     BlendParams p;
     p.ranges = reinterpret_cast<const uint2*>(ranges);
     p.point_list = point_list;
@@ -252,6 +253,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     p.background = background;
     p.out_color = out_color;
     p.staged_counter = staged_counter;
+    p.t_cutoff = t_cutoff;
     p.dims = d;
     p.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
     if (p.num_tiles <= 0) return GSR_OK;

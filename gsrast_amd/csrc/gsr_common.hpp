@@ -42,6 +42,9 @@ struct FrameDims {
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
                       uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
 
+int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
+                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
+
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
 size_t scan_temp_bytes(size_t n);
 
@@ -65,11 +68,11 @@ int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sor
                         int grid_x, int grid_y, uint32_t* rect_packed, char* scratch, uint32_t* hist_y, uint64_t* keys,
                         uint32_t* values, hipStream_t stream, hipEvent_t mark_prep_end, hipEvent_t mark_emit_begin);
 
-int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, hipStream_t stream);
+int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream);
 
 int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
-                 unsigned long long* staged_counter, hipStream_t stream);
+                 unsigned long long* staged_counter, float t_cutoff, hipStream_t stream);
 
 }  // namespace gsr

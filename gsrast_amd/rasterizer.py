@@ -108,17 +108,21 @@ class SplatRasterizer:
     # -- one frame --------------------------------------------------------------------
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
-             sync: bool = True) -> torch.Tensor:
+             sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
-        performs after every call (CudaBuffer.hpp:8-12)."""
+        performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
+        rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3]."""
         if cam is not None:
             self.set_camera(cam)
         a = _capi.ForwardArgs()
         a.struct_size = C.sizeof(_capi.ForwardArgs)
-        a.flags = (_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
+        inria = semantics == "inria"
+        assert semantics in ("gscuda", "inria")
+        a.flags = ((_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
+                   | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0))
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
-        a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, 3, 16
+        a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()
         a.width, a.height = self.width, self.height
         a.means3D, a.shs = self.means3D.data_ptr(), self.shs.data_ptr()
@@ -132,7 +136,7 @@ class SplatRasterizer:
         a.prefiltered = 0
         a.out_color = self.out_color.data_ptr()
         a.radii = None
-        a.rects = self.rects.data_ptr() if self.rects is not None else None
+        a.rects = self.rects.data_ptr() if (self.rects is not None and not inria) else None
         a.box_min = a.box_max = None
         a.stream = torch.cuda.current_stream(self.device).cuda_stream
         if tile_rows is not None:

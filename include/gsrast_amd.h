@@ -98,6 +98,13 @@ enum {
 
 #define GSR_FLAG_PROFILE 0x1u   /* record HIP events around every stage into stage_ms       */
 #define GSR_FLAG_COUNT_STAGED 0x2u /* count records staged by the blend stage (R_f) into records_staged */
+/* Semantics profile of the UPSTREAM rasterizer (graphdeco-inria/diff-gaussian-rasterization) instead
+ * of the reference's gscuda variant (SURVEY.md §8a divergence table D1-D12, §8f-2): SH up to degree
+ * `sh_dims` on shs laid out [N][16][3], view-space depth keys, cull at view z <= 0.2, half-pixel
+ * centre, radius-based square rectangles (`rects` ignored), separate focal lengths, transmittance
+ * cut-off 1e-4, R == 1 renders, R == 0 still writes the background. cam_pos is read. Parity of this
+ * profile is unpinned (no upstream source in the reference tree). */
+#define GSR_FLAG_SEMANTICS_INRIA 0x4u
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
  * gscuda::forward (GSCuda.cuh:103-126); the rest are extensions with neutral defaults (0). */

@@ -187,7 +187,7 @@ def bin_and_sort(o, cam):
     return o
 
 
-def blend(o, cam, background=(0.0, 0.0, 0.0), out_init=None):
+def blend(o, cam, background=(0.0, 0.0, 0.0), out_init=None, t_cutoff=0.001):
     """Row a11 (GSCuda.cu:543-677): per tile, all 256 pixels advance together through
     the sorted list, one record at a time, with boolean masks for skip/done."""
     W, H = cam.width, cam.height
@@ -231,7 +231,7 @@ def blend(o, cam, background=(0.0, 0.0, 0.0), out_init=None):
                         alpha = np.minimum(F(0.99), con[3] * np.exp(power))
                         test = T * (F(1.0) - alpha)
                         live = act & ~(power > 0) & ~(alpha < F(1.0) / F(255.0))
-                        stop = live & (test < F(0.001))
+                        stop = live & (test < F(t_cutoff))
                         upd = live & ~stop
                         done |= stop
                         for c in range(3):
