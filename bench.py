@@ -45,6 +45,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=4, help="CPU baseline renders every k-th splat")
     p.add_argument("--no-rebalance", action="store_true")
+    p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
     return p.parse_args()
 
 
@@ -131,7 +132,7 @@ def main():
 
     def step(profile=False):
         rows = exch.my_tile_rows() if exch else None
-        frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not distributed)
+        frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not distributed, plan=args.plan)
         if exch:
             exch.gather(frame)
             torch.cuda.current_stream(device).synchronize()
@@ -156,7 +157,8 @@ def main():
             exch.rebalance(mine, floor_cost=0.02 * float(per_tile[b0:b1].mean() if b1 > b0 else 0.0) + 1.0)
 
     stage_sum = {}
-    staged_frame = rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None)
+    staged_frame = rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None, plan=args.plan)
+    plan_used = rast.last_plan
     r_f = rast.last_records_staged
     num_rendered = rast.last_num_rendered
     geo = rast.map_geometry_state()
@@ -190,11 +192,14 @@ def main():
         px_rows = min(rows[1] * 16, H) - min(rows[0] * 16, H)
         P_loc, T_loc = px_rows * W, (rows[1] - rows[0]) * grid_x
         N, R = n_splats, num_rendered
+        blocks = plan_used == "blocks"
         alg = {
             "preprocess": N * (52 + 12 + 8) + n_visible * 72,
             "scan": 8 * N,
-            "duplicate": 8 * N + 20 * n_visible + 12 * R,
-            "sort_pass1": 24 * R,            # one onesweep launch: 12 B read + 12 B written per pair
+            # sort plan: the emission kernel of SURVEY.md §8d. block plan: block_emit_kernel writes the
+            # SORTED pairs once (12 B each); its block-list reads (12 B per entry, E <= R) are not counted.
+            "duplicate": 12 * R if blocks else 8 * N + 20 * n_visible + 12 * R,
+            "sort_pass1": 0 if blocks else 24 * R,   # one onesweep launch: 12 B read + 12 B written per pair
             "sort_pass2": 24 * R,
             "ranges": 16 * T_loc * max(1, int(np.ceil(np.log2(max(R, 2))))) + 8 * T_loc,   # two binary searches per tile
             "blend": 40 * r_f + 20 * P_loc + 8 * T_loc,
@@ -209,7 +214,7 @@ def main():
                   key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
                      "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)", "blend": "blend_wave_kernel",
-                     "duplicate": "emit_columns_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
+                     "duplicate": "block_emit_kernel (sorted lists written directly)" if blocks else "emit_chunk_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
 
         # HBM bytes per launch measured with PMC counters in separate rocprofv3 passes of this same
         # command (profiles/): valid only for the default single-GPU workload they were taken on.
@@ -241,7 +246,7 @@ def main():
             "config": {"workload": f"{label}, {W}x{H} forward, fixed reference default camera",
                        "width": W, "height": H, "splats": n_splats, "visible": n_visible_total, "num_rendered": r_total,
                        "records_staged": r_f_total, "minstances_per_s": round(r_total / (ms_per_step * 1e-3) / 1e6, 2),
-                       "parallelism": f"tile-rows x{world}" if distributed else "single GPU",
+                       "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "binning_plan": plan_used,
                        "bands": exch.bounds if exch else None},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": roof(dom, "dominant kernel of this frame; HIP-event time of the launch on its own stream"),

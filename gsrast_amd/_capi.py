@@ -24,6 +24,9 @@ GSR_ERR_INTERNAL = 6
 GSR_FLAG_PROFILE = 0x1
 GSR_FLAG_COUNT_STAGED = 0x2
 GSR_FLAG_SEMANTICS_INRIA = 0x4
+GSR_FLAG_PLAN_SORT = 0x8
+GSR_FLAG_PLAN_BLOCKS = 0x10
+PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8
 STAGE_NAMES = ("preprocess", "scan", "depth_order", "duplicate", "sort_pass1", "sort_pass2", "ranges", "blend")
 
@@ -63,6 +66,7 @@ class ForwardArgs(C.Structure):
         ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
         ("num_rendered", C.c_uint32), ("records_staged", C.c_uint64),
         ("stage_ms", C.c_float * GSR_NUM_STAGES),
+        ("plan_used", C.c_uint32),
     ]
 
 

@@ -43,6 +43,7 @@ struct GeoScratch {
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     SweepScratch sweep;       // onesweep status words for the N-sized sort
     char* emit_scratch;       // column-major emission: [chunk][column] table, block partials, column starts
+    char* block_scratch;      // block binning: [chunk][block] table, partials, block meta, tile counts / starts
     size_t bytes;
 };
 GeoScratch carve_geo_scratch(char* base, size_t n) {
@@ -57,6 +58,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
     g.emit_scratch = base + off; off += align128(emit_scratch_bytes(n));
+    g.block_scratch = base + off; off += align128(blockbin_geo_bytes(n));
     g.bytes = off;
     return g;
 }
@@ -88,6 +90,8 @@ struct Readback {
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
     bool events = false;
     bool recorded[GSR_NUM_STAGES] = {};
+    int begin_of[GSR_NUM_STAGES] = {};        // event index a stage starts at (default 2s)
+    void ev_alias_begin(int stage, int after_stage) { begin_of[stage] = 2 * after_stage + 1; }
     int ensure() {
         if (!host) {
             GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocDefault));
@@ -146,7 +150,7 @@ char* gsr_binning_from_chunk(char* chunk, size_t size, gsr_binning_state* s) {
     obtain(chunk, s->keys, sizeof(uint64_t) * size);
     obtain(chunk, s->values_unsorted, sizeof(uint32_t) * size);
     obtain(chunk, s->values, sizeof(uint32_t) * size);
-    s->sorting_size = std::max(carve_bin_scratch(nullptr, size).bytes, sort_temp_bytes(size));
+    s->sorting_size = std::max(std::max(carve_bin_scratch(nullptr, size).bytes, sort_temp_bytes(size)), blockbin_bin_bytes(size));
     obtain(chunk, s->sorting_space, s->sorting_size);
     return chunk;
 }
@@ -205,6 +209,7 @@ int gsr_forward(gsr_forward_args* a) {
     if (!a || a->struct_size != sizeof(gsr_forward_args)) return fail(GSR_ERR_INVALID_ARG);
     a->num_rendered = 0;
     a->records_staged = 0;
+    a->plan_used = 0;
     memset(a->stage_ms, 0, sizeof(a->stage_ms));
     const int n = a->num_gaussians;
     if (n <= 0 || a->width <= 0 || a->height <= 0 || !a->geometry_alloc || !a->binning_alloc || !a->image_alloc ||
@@ -261,6 +266,7 @@ int gsr_forward(gsr_forward_args* a) {
     const GeoScratch gs = carve_geo_scratch(geom.scanning_space, (size_t)n);
     g_rb.host[1] = g_rb.host[2] = 0;
     for (bool& r : g_rb.recorded) r = false;
+    for (int s = 0; s < GSR_NUM_STAGES; ++s) g_rb.begin_of[s] = 2 * s;
 
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
@@ -305,7 +311,28 @@ int gsr_forward(gsr_forward_args* a) {
     // Tile grids up to 255 x 255: the tile-column pass is produced directly by a column-major
     // emission and only the tile-row pass runs as a sort. Larger grids: depth-ordered emission and
     // 8-bit digit passes over the tile bits.
-    if (xy_plan) {
+    // Two binning plans give the same sorted lists. "blocks": the lists are written directly by
+    // tile-block owners (blockbin.hip), nothing R-sized is sorted. "sort": column-major emission +
+    // one onesweep pass on the tile row. The block plan pays per (Gaussian, block) entry, so scenes
+    // of tiny splats (few tiles per Gaussian) stay on the sort plan unless a flag forces one.
+    bool use_blocks = xy_plan && blockbin_supported(d.grid_x, d.grid_y) && !(a->flags & GSR_FLAG_PLAN_SORT);
+    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 8ull * (uint64_t)n;
+    a->plan_used = use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC);
+    if (use_blocks) {
+        // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
+        GSR_STEP(launch_block_binning(n, gs.b_k, gs.b_v, gs.rect_idx, d.grid_x, d.grid_y, R, gs.a_k, gs.block_scratch,
+                                      bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, bin.keys, bin.values, stream,
+                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
+                                      profile ? g_rb.ev[2 * GSR_STAGE_SORT_PASS1 + 1] : nullptr));
+        if (profile) {
+            // depth order + block lists | unit counts + prefixes (recorded as "sort_pass1") | emission
+            g_rb.ev_alias_begin(GSR_STAGE_SORT_PASS1, GSR_STAGE_DEPTH_ORDER);
+            g_rb.ev_alias_begin(GSR_STAGE_DUPLICATE, GSR_STAGE_SORT_PASS1);
+            g_rb.recorded[GSR_STAGE_DEPTH_ORDER] = g_rb.recorded[GSR_STAGE_SORT_PASS1] = true;
+            GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], stream));
+            g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
+        }
+    } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
         uint32_t* rect_packed = gs.a_k;
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_y, stream));
@@ -370,7 +397,7 @@ int gsr_forward(gsr_forward_args* a) {
             for (int s = 0; s < GSR_NUM_STAGES; ++s) {
                 if (!g_rb.recorded[s]) continue;
                 float ms = 0.0f;
-                GSR_HIP_TRY(hipEventElapsedTime(&ms, g_rb.ev[2 * s], g_rb.ev[2 * s + 1]));
+                GSR_HIP_TRY(hipEventElapsedTime(&ms, g_rb.ev[g_rb.begin_of[s]], g_rb.ev[2 * s + 1]));
                 a->stage_ms[s] = ms;
             }
         }

@@ -79,6 +79,7 @@ class SplatRasterizer:
         self.use_rects = True
         self.last_num_rendered = 0
         self.last_records_staged = 0
+        self.last_plan = "none"
         self.last_stage_ms: dict[str, float] = {}
         self._view = torch.zeros(16, dtype=torch.float32, device=self.device)
         self._proj = torch.zeros(16, dtype=torch.float32, device=self.device)
@@ -108,11 +109,12 @@ class SplatRasterizer:
     # -- one frame --------------------------------------------------------------------
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
-             sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3) -> torch.Tensor:
+             sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto") -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
-        rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3]."""
+        rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3].
+        plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan."""
         if cam is not None:
             self.set_camera(cam)
         a = _capi.ForwardArgs()
@@ -120,7 +122,8 @@ class SplatRasterizer:
         inria = semantics == "inria"
         assert semantics in ("gscuda", "inria")
         a.flags = ((_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
-                   | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0))
+                   | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0)
+                   | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan])
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
         a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()
@@ -146,6 +149,7 @@ class SplatRasterizer:
         _capi.check(rc, "gsr_forward")
         self.last_num_rendered = int(a.num_rendered)
         self.last_records_staged = int(a.records_staged)
+        self.last_plan = _capi.PLAN_NAMES[int(a.plan_used)]
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()

@@ -87,9 +87,9 @@ size_t gsr_required_binning(size_t size);
 enum {
     GSR_STAGE_PREPROCESS = 0,   /* preprocess kernel                                             */
     GSR_STAGE_SCAN = 1,         /* inclusive scan of tiles touched (3 small kernels)             */
-    GSR_STAGE_DEPTH_ORDER = 2,  /* per-Gaussian depth sort + depth-ordered offsets (N-sized)     */
+    GSR_STAGE_DEPTH_ORDER = 2,  /* per-Gaussian depth sort + N-sized binning preparation         */
     GSR_STAGE_DUPLICATE = 3,    /* key emission kernel                                           */
-    GSR_STAGE_SORT_PASS1 = 4,   /* onesweep kernel, tile-column digit (or first generic pass)    */
+    GSR_STAGE_SORT_PASS1 = 4,   /* block plan: unit counts + prefixes; else unused               */
     GSR_STAGE_SORT_PASS2 = 5,   /* onesweep kernel, tile-row digit (remaining passes)            */
     GSR_STAGE_RANGES = 6,       /* clear + tile ranges kernel                                    */
     GSR_STAGE_BLEND = 7,        /* blend kernel                                                  */
@@ -105,6 +105,14 @@ enum {
  * cut-off 1e-4, R == 1 renders, R == 0 still writes the background. cam_pos is read. Parity of this
  * profile is unpinned (no upstream source in the reference tree). */
 #define GSR_FLAG_SEMANTICS_INRIA 0x4u
+/* Binning plan (both produce bit-identical sorted keys / values / ranges; default: chosen per frame
+ * from numRendered / numGaussians). PLAN_SORT: column-major key emission + one onesweep radix pass;
+ * keysUnsorted / valuesUnsorted then hold the reference's pairs in (tile column, depth) order.
+ * PLAN_BLOCKS: the sorted lists are written directly by tile-block owners, no R-sized sort;
+ * keysUnsorted / valuesUnsorted then hold that plan's block lists (scratch, as sortingSpace is). */
+#define GSR_FLAG_PLAN_SORT 0x8u
+#define GSR_FLAG_PLAN_BLOCKS 0x10u
+enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */ };
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
  * gscuda::forward (GSCuda.cuh:103-126); the rest are extensions with neutral defaults (0). */
@@ -145,6 +153,7 @@ typedef struct gsr_forward_args {
     uint32_t num_rendered;         /* R = sum of tiles touched (for the rows processed)    */
     uint64_t records_staged;       /* R_f, only with GSR_FLAG_COUNT_STAGED                 */
     float stage_ms[GSR_NUM_STAGES];/* only with GSR_FLAG_PROFILE                           */
+    uint32_t plan_used;            /* GSR_PLAN_* of this call (0 if R == 0)                */
 } gsr_forward_args;
 
 /* The forward pass. Calls geometry_alloc(required_geometry(N)), then

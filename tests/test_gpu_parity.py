@@ -22,8 +22,22 @@ def _gpu():
     return torch, SplatRasterizer
 
 
+PLAN = "auto"
+
+
+@pytest.fixture(autouse=True, params=["sort", "blocks"])
+def binning_plan(request):
+    """Every frame-level test runs under both binning plans (GSR_FLAG_PLAN_SORT / _BLOCKS): they must
+    give the same sorted keys / values / ranges / pixels."""
+    global PLAN
+    PLAN = request.param
+    yield
+    PLAN = "auto"
+
+
 def _run(scene, cam, bg=(0.0, 0.0, 0.0), use_rects=True, **kw):
     torch, SplatRasterizer = _gpu()
+    kw.setdefault("plan", PLAN)
     r = SplatRasterizer(cam.width, cam.height, background=bg)
     r.configure_from_scene(scene, use_rects=use_rects)
     # zero the chunks once so fields the reference leaves unwritten compare equal to the oracle's zeros
@@ -53,14 +67,19 @@ def _compare_all(r, img, exp, n):
         # The reference emits the pairs in index order. The HIP path sorts the depth half of the key
         # per Gaussian before duplication and writes the tile-column pass directly, so its
         # "unsorted" arrays hold the same multiset of pairs ordered by (tile column, depth) — or by
-        # depth alone on grids wider than 255 tiles.
-        ku, vu = b["keys_unsorted"].view(np.uint64), b["values_unsorted"].view(np.uint32)
-        o_g, o_e = np.lexsort((vu, ku)), np.lexsort((exp["values_unsorted"], exp["keys_unsorted"]))
-        assert np.array_equal(ku[o_g], exp["keys_unsorted"][o_e])
-        assert np.array_equal(vu[o_g], exp["values_unsorted"][o_e])
+        # depth alone on grids wider than 255 tiles. (The block plan writes the sorted lists
+        # directly and keeps its block lists in the two "unsorted" arrays: nothing to compare.)
         gx, gy = (r.width + 15) // 16, (r.height + 15) // 16
+        assert r.last_plan == ("generic" if (gx > 255 or gy > 255) else PLAN)
+        ku, vu = b["keys_unsorted"].view(np.uint64), b["values_unsorted"].view(np.uint32)
+        if r.last_plan != "blocks":
+            o_g, o_e = np.lexsort((vu, ku)), np.lexsort((exp["values_unsorted"], exp["keys_unsorted"]))
+            assert np.array_equal(ku[o_g], exp["keys_unsorted"][o_e])
+            assert np.array_equal(vu[o_g], exp["values_unsorted"][o_e])
         depth_half = (ku & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        if gx <= 255 and gy <= 255:
+        if r.last_plan == "blocks":
+            pass
+        elif gx <= 255 and gy <= 255:
             col = ((ku >> np.uint64(32)) % np.uint64(gx)).astype(np.int64)
             assert bool((np.diff(col) >= 0).all())
             same_col = np.diff(col) == 0
