@@ -13,10 +13,10 @@
 //       a 9 x 9 difference array in LDS
 //   block_prefix / tile_start : prefix of those counts down the units of a block, then over the
 //       tiles in tile order = where every (unit, tile) run starts in the sorted list
-//   block_emit   : one wavefront per unit walks its entries; lane (tx, ty) appends the entry to
-//       its tile's 32-slot LDS ring when the rectangle covers the tile, and every time a ring
-//       crosses a 32-key boundary of the OUTPUT index the wave stores those 32 keys / values as
-//       whole 128-byte lines. Only the first and last line of a (unit, tile) run are partial.
+//   block_emit   : one wavefront per unit: coverage bit masks (entries x tile columns / rows),
+//       transposed with v_writelane; then per tile the covered entries of each batch of 64 store
+//       their key / value compacted by v_mbcnt rank — every (unit, tile) run is written front to
+//       back by one wave.
 // The result is bit-identical to the stable 64-bit sort (same lists, same order inside a tile).
 // R-sized traffic: 12 R bytes written once (the reference's emit + 6-pass sort moves > 150 R).
 #include "gsr_common.hpp"
@@ -29,8 +29,6 @@ constexpr int kCoarse = 1024;            // Gaussians per workgroup of the coars
 constexpr int kUnit = 2048;              // block-list entries per emission unit
 constexpr int kScanRows = 64;            // table rows per workgroup of the block scan
 constexpr int kMaxBlocks = 512;          // 8 x 8-tile blocks per frame (4K: 30 x 17 = 510)
-constexpr int kRing = 32;                // keys staged per tile
-constexpr int kRingStride = 2 * kRing + 4;   // dwords per tile ring: 32 x {depth, idx} + pad (bank skew, 16-B aligned)
 
 struct BlockMeta {                       // u32 words in HBM
     // [0, nbp]            list_start : entry index where the list of block b starts (nbp + 1 words)
@@ -311,104 +309,130 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
 }
 
 // ---- emission ------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) Key2 { uint32_t d0, t0, d1, t1; };   // two consecutive 64-bit keys
-struct __attribute__((aligned(8))) Val2 { uint32_t a, b; };
-
-// Stores the staged keys of the tiles in `m` (one bit per lane = tile): the 32-key output line that
-// ends at the tile's write position (or holds it, for the final partial line). Four tiles per
-// iteration: 16 lanes per tile, two keys per lane — a 16-byte key store and an 8-byte value store.
-__device__ __forceinline__ void flush_lines(unsigned long long m, const uint32_t* ring, uint32_t pos, uint32_t base,
-                                            uint32_t tile, uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int grp = lane >> 4, sub = lane & 15;
-    while (m) {
-        int j = 64;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int jj = m ? (__ffsll((long long)m) - 1) : 64;
-            m &= m - 1ull;
-            if (grp == g) j = jj;
-        }
-        const bool valid = j < 64;
-        const int src = valid ? j : lane;
-        const uint32_t pj = (uint32_t)__shfl((int)pos, src, kWave);
-        const uint32_t bj = (uint32_t)__shfl((int)base, src, kWave);
-        const uint32_t tj = (uint32_t)__shfl((int)tile, src, kWave);
-        const uint32_t g0 = ((pj - 1u) & ~(uint32_t)(kRing - 1)) + 2u * (uint32_t)sub;
-        const uint4 q = *reinterpret_cast<const uint4*>(ring + src * kRingStride + 4 * sub);
-        const bool v0 = valid && g0 >= bj && g0 < pj;
-        const bool v1 = valid && g0 + 1u >= bj && g0 + 1u < pj;
-        if (v0 && v1) {
-            Key2 k;
-            k.d0 = q.x; k.t0 = tj; k.d1 = q.z; k.t1 = tj;
-            *reinterpret_cast<Key2*>(keys + g0) = k;
-            Val2 v;
-            v.a = q.y; v.b = q.w;
-            *reinterpret_cast<Val2*>(values + g0) = v;
-        } else {
-            if (v0) { keys[g0] = ((uint64_t)tj << 32) | q.x; values[g0] = q.y; }
-            if (v1) { keys[g0 + 1u] = ((uint64_t)tj << 32) | q.z; values[g0 + 1u] = q.w; }
-        }
-    }
+// One wavefront per unit (<= 2048 consecutive entries of one block list = 32 batches of 64).
+//   masks : lane = entry. Per batch, 16 ballots give, for each of the 8 tile columns and 8 tile rows
+//           of the block, which of the 64 entries cover it; v_writelane files them TRANSPOSED: lane w
+//           of register xm[c] / ym[r] holds the 64-entry mask of batch w. (coverage of tile (c, r) by
+//           batch w is xm[c] & ym[r]: rectangles are products of a column range and a row range)
+//   tiles : per tile two LDS reads and one AND leave lane w holding the tile's mask of batch w; bit
+//           counts + a 32-lane DPP prefix give where each batch's keys start in the tile's run. Then,
+//           batch by batch, EXEC = that mask and the covered entries store their key / value at
+//           start + v_mbcnt rank: compacted, in entry order, one contiguous burst per (tile, batch).
+// Every (unit, tile) run is therefore written front to back by one wave in consecutive bursts (whole
+// lines form in L2); there is no per-entry serial work and no staging of keys in LDS.
+// lane `lane_select` of lo / hi := the two halves of a 64-bit wave-uniform mask. (One scalar operand
+// per VALU instruction on gfx950: with the value in an SGPR the lane select has to sit in M0.)
+__device__ __forceinline__ void writelane_mask(uint32_t& lo, uint32_t& hi, unsigned long long mask, uint32_t lane_select) {
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0\n\t"
+        : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "s"(lane_select));
 }
 
-__global__ __launch_bounds__(kWave) void block_emit_kernel(BlockMeta meta, int nb, int nbx, int gx, int gy,
-                                                           const uint64_t* __restrict__ ent_rd,
-                                                           const uint32_t* __restrict__ ent_idx,
-                                                           const uint32_t* __restrict__ cnt,
-                                                           const uint32_t* __restrict__ tile_start,
-                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
-    __shared__ __attribute__((aligned(16))) uint32_t ring[kWave * kRingStride];
-    const int lane = threadIdx.x;
-    const uint32_t total = meta.unit_start()[meta.nbp];
-    uint32_t* my_ring = ring + lane * kRingStride;
+// inclusive prefix sum over lanes 0..31 (and, separately, 32..63): row_shr 1, 2, 4, 8 + row_bcast:15
+__device__ __forceinline__ uint32_t prefix32_inclusive(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    return v;
+}
+
+constexpr int kBatches = kUnit / kWave;      // 32: one lane per batch in the transposed masks
+constexpr int kEmitWaves = 4;                // independent waves per workgroup
+
+__global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta meta, int nb, int nbx, int gx, int gy,
+                                                                        const uint64_t* __restrict__ ent_rd,
+                                                                        const uint32_t* __restrict__ ent_idx,
+                                                                        const uint32_t* __restrict__ cnt,
+                                                                        const uint32_t* __restrict__ tile_start,
+                                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ values,
+                                                                        uint32_t r_total) {
+    __shared__ uint2 s_maskT[kEmitWaves][16][kBatches];      // [column 0..7 | row 0..7][batch]
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t total_units = meta.unit_start()[meta.nbp];
+    const uint32_t* ent_rd32 = reinterpret_cast<const uint32_t*>(ent_rd);
     for (;;) {
         uint32_t u = 0;
         if (lane == 0) u = atomicAdd(&meta.tickets()[1], 1u);
         u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-        if (u >= total) break;
+        if (u >= total_units) break;
         const UnitInfo ui = locate_unit(u, meta, nb, nbx);
-        const uint32_t tx = ui.bx * kBW + (uint32_t)(lane & 7), ty = ui.by * kBH + (uint32_t)(lane >> 3);
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e0);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e1);
+        const uint32_t bx0 = ui.bx * kBW, by0 = ui.by * kBH;
+        // lane = tile: where this unit's keys of the tile start in the sorted list
+        const uint32_t tx = bx0 + (uint32_t)(lane & 7), ty = by0 + (uint32_t)(lane >> 3);
         const bool in_grid = tx < (uint32_t)gx && ty < (uint32_t)gy;
-        const uint32_t tile = ty * (uint32_t)gx + tx;
-        const uint32_t base = in_grid ? tile_start[tile] + cnt[(size_t)u * 64 + lane] : 0u;
-        uint32_t pos = base;
-        uint32_t e = ui.e0;
-        // entries are fetched 64 at a time, one batch ahead of the one being walked
-        uint32_t ne = min(64u, ui.e1 - e);
-        uint64_t rd = ((uint32_t)lane < ne) ? ent_rd[e + lane] : 0ull;
-        uint32_t id = ((uint32_t)lane < ne) ? ent_idx[e + lane] : 0u;
-        while (ne) {
-            const uint32_t e_next = e + ne;
-            const uint32_t ne_next = min(64u, ui.e1 - e_next);
-            const uint64_t rd_next = ((uint32_t)lane < ne_next) ? ent_rd[e_next + lane] : 0ull;
-            const uint32_t id_next = ((uint32_t)lane < ne_next) ? ent_idx[e_next + lane] : 0u;
-            const uint32_t rect_v = (uint32_t)rd, depth_v = (uint32_t)(rd >> 32);
-            for (uint32_t j = 0; j < ne; ++j) {
-                const uint32_t rect = (uint32_t)__builtin_amdgcn_readlane((int)rect_v, (int)j);
-                const uint32_t depth = (uint32_t)__builtin_amdgcn_readlane((int)depth_v, (int)j);
-                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)id, (int)j);
-                const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
-                const bool cov = (tx - x0) < w && (ty - y0) < h;
-                bool full = false;
-                if (cov) {
-                    *reinterpret_cast<uint2*>(my_ring + 2u * (pos & (kRing - 1))) = make_uint2(depth, idx);
-                    ++pos;
-                    full = (pos & (kRing - 1)) == 0u;
-                }
-                const unsigned long long fm = __ballot(full);
-                if (fm) {
-                    __builtin_amdgcn_wave_barrier();
-                    flush_lines(fm, ring, pos, base, tile, keys, values);
-                    __builtin_amdgcn_wave_barrier();
+        const uint32_t tile_v = ty * (uint32_t)gx + tx;
+        const uint32_t base_v = in_grid ? tile_start[tile_v] + cnt[(size_t)u * 64 + lane] : 0u;
+
+        // ---- masks: lane = entry, one batch of 64 at a time ----
+        uint32_t m_lo[16], m_hi[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m_lo[k] = m_hi[k] = 0u;
+        const uint32_t nbatch = (e1 - e0 + kWave - 1) / kWave;
+        uint32_t rect_next = (e0 + (uint32_t)lane < e1) ? ent_rd32[2 * (size_t)(e0 + lane)] : 0u;
+        for (uint32_t w = 0; w < nbatch; ++w) {
+            const uint32_t rect = rect_next;
+            const uint32_t i_next = e0 + (w + 1) * kWave + (uint32_t)lane;
+            rect_next = (i_next < e1) ? ent_rd32[2 * (size_t)i_next] : 0u;
+            const uint32_t x0 = rect & 0xFFu, rw = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, rh = rect >> 24;
+            const uint32_t cx0 = max(x0, bx0) - bx0, cx1 = min(x0 + rw, bx0 + kBW) - bx0;
+            const uint32_t cy0 = max(y0, by0) - by0, cy1 = min(y0 + rh, by0 + kBH) - by0;
+            // bits 0..7: tile columns covered, bits 8..15: tile rows covered (0 for lanes past the end)
+            uint32_t bits = (((1u << (cx1 - cx0)) - 1u) << cx0) | (((1u << (cy1 - cy0)) - 1u) << (cy0 + 8u));
+            bits = rect ? bits : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned long long m = __ballot((bits >> k) & 1u);
+                writelane_mask(m_lo[k], m_hi[k], m, w);
+            }
+        }
+        if (lane < kBatches) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s_maskT[wave][k][lane] = make_uint2(m_lo[k], m_hi[k]);
+        }
+        // ---- the entries' depth bits and indices: lane = entry, register b = batch ----
+        uint32_t ed[kBatches], ei[kBatches];
+#pragma unroll
+        for (int b = 0; b < kBatches; ++b) {
+            const uint32_t i = min(e0 + (uint32_t)(b * kWave + lane), e1 - 1u);   // (entries past the end have empty masks)
+            ed[b] = ent_rd32[2 * (size_t)i + 1];
+            ei[b] = ent_idx[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- tiles ----
+        for (uint32_t t = 0; t < 64; ++t) {
+            const uint2 xm = s_maskT[wave][t & 7u][lane & (kBatches - 1)];
+            const uint2 ym = s_maskT[wave][8u + (t >> 3)][lane & (kBatches - 1)];
+            const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
+            const uint32_t c = (uint32_t)__popc(tm_lo) + (uint32_t)__popc(tm_hi);
+            const uint32_t incl = prefix32_inclusive(c);
+            const uint32_t pexcl = incl - c;
+            const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kBatches - 1);
+            if (run == 0u) continue;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)base_v, (int)t);
+            const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)tile_v, (int)t);
+            const uint32_t room = r_total - min(r_total, base);      // (never beyond the arrays)
+            char* kptr = reinterpret_cast<char*>(keys + base);
+            char* vptr = reinterpret_cast<char*>(values + base);
+#pragma unroll
+            for (int w = 0; w < kBatches; ++w) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
+                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                if (m == 0ull) continue;
+                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)pexcl, w);
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                    const uint32_t o = start + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                    if (o < room) {
+                        *reinterpret_cast<uint2*>(kptr + o * 8u) = make_uint2(ed[w], tile);
+                        *reinterpret_cast<uint32_t*>(vptr + o * 4u) = ei[w];
+                    }
                 }
             }
-            e = e_next; ne = ne_next; rd = rd_next; id = id_next;
         }
-        // the last, partial line of every tile
-        const unsigned long long tm = __ballot((pos & (kRing - 1)) != 0u && pos != base);
-        __builtin_amdgcn_wave_barrier();
-        if (tm) flush_lines(tm, ring, pos, base, tile, keys, values);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -483,9 +507,9 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     GSR_LAUNCH_CHECK("tile_start_kernel");
     if (ev_prefix_end) GSR_HIP_TRY(hipEventRecord(ev_prefix_end, stream));
 
-    const uint32_t emit_wgs = std::min<uint32_t>(max_units, 256u * 9u);
-    hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kWave), 0, stream, meta, nb, nbx, grid_x, grid_y, ent_rd, ent_idx,
-                       cnt, tile_start, keys, values);
+    const uint32_t emit_wgs = std::min<uint32_t>((max_units + kEmitWaves - 1) / kEmitWaves, 256u * 3u);
+    hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, meta, nb, nbx, grid_x, grid_y, ent_rd, ent_idx,
+                       cnt, tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");
     return GSR_OK;
 }

@@ -13,7 +13,7 @@ mkdir -p gpurun_out
 i=0
 for S in "${SETS[@]}"; do
   OUT=gpurun_out/pmc_${TAG}_$i
-  rocprofv3 --pmc $S --kernel-trace --output-format csv -d "$OUT" -o run -- python3 "$@" > gpurun_out/pmc_${TAG}_$i.log 2>&1
+  timeout -k 10 ${PMC_TIMEOUT:-180} rocprofv3 --pmc $S --kernel-trace --output-format csv -d "$OUT" -o run -- python3 "$@" > gpurun_out/pmc_${TAG}_$i.log 2>&1
   F=$(find "$OUT" -name '*counter_collection.csv' | head -1)
   echo "## counters: $S" >> gpurun_out/pmc_${TAG}.txt
   if [ -n "$F" ]; then
