@@ -9,14 +9,15 @@
 // 8 x 8 tile block:
 //   coarse_count / blockscan_* / coarse_emit : the depth-ordered list is split, stably, into one
 //       list per tile block (entries = rectangle, depth bits, index; 12 B, E <= R of them)
-//   unit_count   : a unit = 2048 consecutive entries of one block list; keys per (unit, tile) from
-//       a 9 x 9 difference array in LDS
+//   unit_masks   : a unit = 2048 consecutive entries of one block list; its coverage bit masks
+//       (entries x tile columns / rows, transposed with v_writelane) and, from their bit counts,
+//       the keys per (unit, tile)
 //   block_prefix / tile_start : prefix of those counts down the units of a block, then over the
 //       tiles in tile order = where every (unit, tile) run starts in the sorted list
-//   block_emit   : one wavefront per unit: coverage bit masks (entries x tile columns / rows),
-//       transposed with v_writelane; then per tile the covered entries of each batch of 64 store
-//       their key / value compacted by v_mbcnt rank — every (unit, tile) run is written front to
-//       back by one wave.
+//   block_emit   : one wavefront per unit: per tile, (column mask & row mask) says which entries of
+//       each batch of 64 cover it; they are compacted by v_mbcnt rank through a small LDS run
+//       buffer and stored as dense, line-aligned groups of 128 keys — every (unit, tile) run is
+//       written front to back by one wave.
 // The result is bit-identical to the stable 64-bit sort (same lists, same order inside a tile).
 // R-sized traffic: 12 R bytes written once (the reference's emit + 6-pass sort moves > 150 R).
 #include "gsr_common.hpp"
@@ -26,7 +27,10 @@ namespace {
 
 constexpr int kBW = 8, kBH = 8;          // tiles per block: one lane per tile
 constexpr int kCoarse = 1024;            // Gaussians per workgroup of the coarse passes
-constexpr int kUnit = 2048;              // block-list entries per emission unit
+#ifndef GSR_UNIT
+#define GSR_UNIT 2048
+#endif
+constexpr int kUnit = GSR_UNIT;          // block-list entries per emission unit
 constexpr int kScanRows = 64;            // table rows per workgroup of the block scan
 constexpr int kMaxBlocks = 512;          // 8 x 8-tile blocks per frame (4K: 30 x 17 = 510)
 
@@ -208,48 +212,94 @@ __device__ __forceinline__ UnitInfo locate_unit(uint32_t u, const BlockMeta& met
     return ui;
 }
 
-// Keys per (unit, tile of its block). Persistent waves, one unit at a time from a ticket counter.
-__global__ __launch_bounds__(256) void unit_count_kernel(BlockMeta meta, int nb, int nbx, const uint64_t* __restrict__ ent_rd,
-                                                         uint32_t* __restrict__ cnt) {
-    __shared__ uint32_t s_diff[4][96];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    uint32_t* diff = s_diff[wave];
+// lane `lane_select` of lo / hi := the two halves of a 64-bit wave-uniform mask. (One scalar operand
+// per VALU instruction on gfx950: with the value in an SGPR the lane select has to sit in M0.)
+__device__ __forceinline__ void writelane_mask(uint32_t& lo, uint32_t& hi, unsigned long long mask, uint32_t lane_select) {
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0\n\t"
+        : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "s"(lane_select));
+}
+
+// inclusive prefix sum over lanes 0..31 (and, separately, 32..63): row_shr 1, 2, 4, 8 + row_bcast:15
+__device__ __forceinline__ uint32_t prefix32_inclusive(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    return v;
+}
+
+constexpr int kBatches = kUnit / kWave;      // 32: one lane per batch in the transposed masks
+
+// Coverage masks of one unit, transposed. Lane = entry: per batch of 64 entries, 16 ballots give, for
+// each of the 8 tile columns and 8 tile rows of the block, which entries cover it; v_writelane files
+// them so that lane w of m_lo/m_hi[k] holds the 64-entry mask of batch w (k = column 0..7 | 8 + row).
+// Coverage of tile (c, r) by batch w is then m[c] & m[8 + r]: a rectangle is a column range x a row range.
+__device__ __forceinline__ void build_unit_masks(const uint32_t* __restrict__ ent_rd32, uint32_t e0, uint32_t e1, uint32_t bx0,
+                                                 uint32_t by0, uint32_t (&m_lo)[16], uint32_t (&m_hi)[16]) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m_lo[k] = m_hi[k] = 0u;
+    // all of the unit's rectangles are fetched up front: one memory round trip, not one per batch
+    const uint32_t nbatch = (e1 - e0 + kWave - 1) / kWave;
+    uint32_t rects[kBatches];
+#pragma unroll
+    for (int w = 0; w < kBatches; ++w) {
+        const uint32_t i = e0 + (uint32_t)w * kWave + lane;
+        rects[w] = (i < e1) ? ent_rd32[2 * (size_t)i] : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < kBatches; ++w) {
+        if ((uint32_t)w >= nbatch) break;
+        const uint32_t rect = rects[w];
+        const uint32_t x0 = rect & 0xFFu, rw = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, rh = rect >> 24;
+        const uint32_t cx0 = max(x0, bx0) - bx0, cx1 = min(x0 + rw, bx0 + kBW) - bx0;
+        const uint32_t cy0 = max(y0, by0) - by0, cy1 = min(y0 + rh, by0 + kBH) - by0;
+        // bits 0..7: tile columns covered, bits 8..15: tile rows covered (0 for lanes past the end)
+        uint32_t bits = (((1u << (cx1 - cx0)) - 1u) << cx0) | (((1u << (cy1 - cy0)) - 1u) << (cy0 + 8u));
+        bits = rect ? bits : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned long long m = __ballot((bits >> k) & 1u);
+            writelane_mask(m_lo[k], m_hi[k], m, w);
+        }
+    }
+}
+
+// Per unit: the transposed coverage masks (kept for the emission kernel, 4 KB per unit) and, from
+// their bit counts, the keys per tile of the block. Persistent waves, units from a ticket counter.
+__global__ __launch_bounds__(256) void unit_masks_kernel(BlockMeta meta, int nb, int nbx, const uint64_t* __restrict__ ent_rd,
+                                                         uint2* __restrict__ unit_masks, uint32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & (kWave - 1);
     const uint32_t total = meta.unit_start()[meta.nbp];
-    for (;;) {
-        uint32_t u = 0;
-        if (lane == 0) u = atomicAdd(&meta.tickets()[0], 1u);
-        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-        if (u >= total) break;
+    const uint32_t* ent_rd32 = reinterpret_cast<const uint32_t*>(ent_rd);
+    // units cost the same here (<= 2048 entries each): dealt round-robin, no work queue (thousands of
+    // waves taking tickets from one counter serialise on it for longer than the kernel's own work)
+    const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+    for (uint32_t u = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; u < total; u += nwaves) {
         const UnitInfo ui = locate_unit(u, meta, nb, nbx);
-        diff[lane] = 0;
-        if (lane < 32) diff[64 + lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t tx0 = ui.bx * kBW, ty0 = ui.by * kBH;
-        for (uint32_t e = ui.e0 + (uint32_t)lane; e < ui.e1; e += kWave) {
-            const uint32_t rect = (uint32_t)ent_rd[e];
-            const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
-            const uint32_t cx0 = max(x0, tx0) - tx0, cx1 = min(x0 + w, tx0 + kBW) - tx0;
-            const uint32_t cy0 = max(y0, ty0) - ty0, cy1 = min(y0 + h, ty0 + kBH) - ty0;
-            atomicAdd(&diff[cy0 * 9 + cx0], 1u);
-            atomicSub(&diff[cy0 * 9 + cx1], 1u);
-            atomicSub(&diff[cy1 * 9 + cx0], 1u);
-            atomicAdd(&diff[cy1 * 9 + cx1], 1u);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // 2-D inclusive prefix over the 8 x 8 cells: along x inside groups of 8 lanes, then along y
-        uint32_t v = diff[(lane >> 3) * 9 + (lane & 7)];
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e0);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e1);
+        uint32_t m_lo[16], m_hi[16];
+        build_unit_masks(ent_rd32, e0, e1, ui.bx * kBW, ui.by * kBH, m_lo, m_hi);
+        if (lane < kBatches) {
+            uint2* dst = unit_masks + (size_t)u * 16 * kBatches + lane;
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            const uint32_t o = __shfl_up(v, off, 8);
-            if ((lane & 7) >= off) v += o;
+            for (int k = 0; k < 16; ++k) dst[k * kBatches] = make_uint2(m_lo[k], m_hi[k]);
         }
+        // keys per tile = bits of (column mask & row mask) summed over the batches (lanes); two tiles of
+        // one tile row share a 32-lane DPP prefix, 16 bits each (<= 2048 keys per tile and unit)
+        uint32_t out = 0;
 #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(v, off, kWave);
-            if (lane >= off) v += o;
+        for (int p = 0; p < 32; ++p) {
+            const int c0 = (2 * p) & 7, r = 8 + ((2 * p) >> 3);
+            const uint32_t k0 = (uint32_t)__popc(m_lo[c0] & m_lo[r]) + (uint32_t)__popc(m_hi[c0] & m_hi[r]);
+            const uint32_t k1 = (uint32_t)__popc(m_lo[c0 + 1] & m_lo[r]) + (uint32_t)__popc(m_hi[c0 + 1] & m_hi[r]);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)prefix32_inclusive(k0 | (k1 << 16)), 31);
+            out = (lane == 2 * p) ? (tot & 0xFFFFu) : out;
+            out = (lane == 2 * p + 1) ? (tot >> 16) : out;
         }
-        cnt[(size_t)u * 64 + lane] = v;
-        __builtin_amdgcn_wave_barrier();
+        cnt[(size_t)u * 64 + lane] = out;
     }
 }
 
@@ -320,41 +370,66 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
 //           start + v_mbcnt rank: compacted, in entry order, one contiguous burst per (tile, batch).
 // Every (unit, tile) run is therefore written front to back by one wave in consecutive bursts (whole
 // lines form in L2); there is no per-entry serial work and no staging of keys in LDS.
-// lane `lane_select` of lo / hi := the two halves of a 64-bit wave-uniform mask. (One scalar operand
-// per VALU instruction on gfx950: with the value in an SGPR the lane select has to sit in M0.)
-__device__ __forceinline__ void writelane_mask(uint32_t& lo, uint32_t& hi, unsigned long long mask, uint32_t lane_select) {
-    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0\n\t"
-        : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "s"(lane_select));
-}
-
-// inclusive prefix sum over lanes 0..31 (and, separately, 32..63): row_shr 1, 2, 4, 8 + row_bcast:15
-__device__ __forceinline__ uint32_t prefix32_inclusive(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    return v;
-}
-
-constexpr int kBatches = kUnit / kWave;      // 32: one lane per batch in the transposed masks
 constexpr int kEmitWaves = 4;                // independent waves per workgroup
+constexpr uint32_t kGroup = 128;             // keys per dense store group: 8 key lines + 4 value lines
+constexpr uint32_t kRun = 512;               // slots of the per-wave run buffer (>= kGroup - 1 + 4 batches of 64)
+constexpr int kCheck = 4;                    // batches between two looks at the run buffer's fill
+
+struct __attribute__((aligned(16))) KeyPair { uint32_t d0, t0, d1, t1; };   // two consecutive 64-bit keys
+
+// Sparse path (first and last group of a run): keys [a, b) of the run buffer, one per lane.
+__device__ __forceinline__ void store_run_sparse(const uint2* run_buf, uint32_t a, uint32_t b, uint32_t tile,
+                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    for (uint32_t g = a + lane; g < b; g += kWave) {
+#ifdef GSR_EXP_NOSTORE      // timing experiment only: everything but the global stores
+        if (tile != 0xFFFFFFF0u) continue;
+#endif
+        const uint2 q = run_buf[g & (kRun - 1)];
+        keys[g] = ((uint64_t)tile << 32) | q.x;
+        values[g] = q.y;
+    }
+}
+// Dense path: the 128 keys [a, a + 128), a a multiple of 128: two keys per lane, whole lines only.
+__device__ __forceinline__ void store_run_group(const uint2* run_buf, uint32_t a, uint32_t tile, uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ values) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint4 q = *reinterpret_cast<const uint4*>(run_buf + ((a & (kRun - 1)) + 2u * lane));
+#ifdef GSR_EXP_NOSTORE
+    if (tile != 0xFFFFFFF0u) return;
+#endif
+    KeyPair k;
+    k.d0 = q.x; k.t0 = tile; k.d1 = q.z; k.t1 = tile;
+    *reinterpret_cast<KeyPair*>(keys + a + 2u * lane) = k;
+    *reinterpret_cast<uint2*>(values + a + 2u * lane) = make_uint2(q.y, q.w);
+}
 
 __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta meta, int nb, int nbx, int gx, int gy,
                                                                         const uint64_t* __restrict__ ent_rd,
                                                                         const uint32_t* __restrict__ ent_idx,
+                                                                        const uint2* __restrict__ unit_masks,
                                                                         const uint32_t* __restrict__ cnt,
                                                                         const uint32_t* __restrict__ tile_start,
                                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ values,
                                                                         uint32_t r_total) {
     __shared__ uint2 s_maskT[kEmitWaves][16][kBatches];      // [column 0..7 | row 0..7][batch]
+    __shared__ __attribute__((aligned(16))) uint2 s_run[kEmitWaves][kRun + kWave];   // {depth bits, index}, slot = output index mod 512; + one scrap slot per lane
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t total_units = meta.unit_start()[meta.nbp];
     const uint32_t* ent_rd32 = reinterpret_cast<const uint32_t*>(ent_rd);
+    uint2* run_buf = s_run[wave];
+    uint2* scrap = run_buf + kRun + lane;
+    // Units differ in key count, so they come from a work queue — except the first one of every wave
+    // (ticket = wave number): thousands of waves hitting one counter at launch would queue up on it.
+    const uint32_t nwaves = gridDim.x * kEmitWaves;
+    bool first = true;
     for (;;) {
-        uint32_t u = 0;
-        if (lane == 0) u = atomicAdd(&meta.tickets()[1], 1u);
-        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+        uint32_t u = blockIdx.x * kEmitWaves + (uint32_t)wave;
+        if (!first) {
+            if (lane == 0) u = nwaves + atomicAdd(&meta.tickets()[1], 1u);
+            u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+        }
+        first = false;
         if (u >= total_units) break;
         const UnitInfo ui = locate_unit(u, meta, nb, nbx);
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e0);
@@ -366,39 +441,19 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
         const uint32_t tile_v = ty * (uint32_t)gx + tx;
         const uint32_t base_v = in_grid ? tile_start[tile_v] + cnt[(size_t)u * 64 + lane] : 0u;
 
-        // ---- masks: lane = entry, one batch of 64 at a time ----
-        uint32_t m_lo[16], m_hi[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m_lo[k] = m_hi[k] = 0u;
-        const uint32_t nbatch = (e1 - e0 + kWave - 1) / kWave;
-        uint32_t rect_next = (e0 + (uint32_t)lane < e1) ? ent_rd32[2 * (size_t)(e0 + lane)] : 0u;
-        for (uint32_t w = 0; w < nbatch; ++w) {
-            const uint32_t rect = rect_next;
-            const uint32_t i_next = e0 + (w + 1) * kWave + (uint32_t)lane;
-            rect_next = (i_next < e1) ? ent_rd32[2 * (size_t)i_next] : 0u;
-            const uint32_t x0 = rect & 0xFFu, rw = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, rh = rect >> 24;
-            const uint32_t cx0 = max(x0, bx0) - bx0, cx1 = min(x0 + rw, bx0 + kBW) - bx0;
-            const uint32_t cy0 = max(y0, by0) - by0, cy1 = min(y0 + rh, by0 + kBH) - by0;
-            // bits 0..7: tile columns covered, bits 8..15: tile rows covered (0 for lanes past the end)
-            uint32_t bits = (((1u << (cx1 - cx0)) - 1u) << cx0) | (((1u << (cy1 - cy0)) - 1u) << (cy0 + 8u));
-            bits = rect ? bits : 0u;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const unsigned long long m = __ballot((bits >> k) & 1u);
-                writelane_mask(m_lo[k], m_hi[k], m, w);
-            }
-        }
+        // ---- the unit's transposed coverage masks (unit_masks_kernel): 4 KB, HBM -> LDS ----
         if (lane < kBatches) {
+            const uint2* src = unit_masks + (size_t)u * 16 * kBatches + lane;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s_maskT[wave][k][lane] = make_uint2(m_lo[k], m_hi[k]);
+            for (int k = 0; k < 16; ++k) s_maskT[wave][k][lane] = src[k * kBatches];
         }
-        // ---- the entries' depth bits and indices: lane = entry, register b = batch ----
-        uint32_t ed[kBatches], ei[kBatches];
+        // ---- the entries' {depth bits, index}: lane = entry, register pair b = batch ----
+        uint2 ent[kBatches];
 #pragma unroll
         for (int b = 0; b < kBatches; ++b) {
             const uint32_t i = min(e0 + (uint32_t)(b * kWave + lane), e1 - 1u);   // (entries past the end have empty masks)
-            ed[b] = ent_rd32[2 * (size_t)i + 1];
-            ei[b] = ent_idx[i];
+            ent[b].x = ent_rd32[2 * (size_t)i + 1];
+            ent[b].y = ent_idx[i];
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -409,31 +464,43 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
             const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
             const uint32_t c = (uint32_t)__popc(tm_lo) + (uint32_t)__popc(tm_hi);
             const uint32_t incl = prefix32_inclusive(c);
-            const uint32_t pexcl = incl - c;
             const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kBatches - 1);
             if (run == 0u) continue;
             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)base_v, (int)t);
             const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)tile_v, (int)t);
-            const uint32_t room = r_total - min(r_total, base);      // (never beyond the arrays)
-            char* kptr = reinterpret_cast<char*>(keys + base);
-            char* vptr = reinterpret_cast<char*>(values + base);
+            if (base + run > r_total || base + run < base) continue;      // (never beyond the arrays)
+            // The run is compacted through the run buffer: batch by batch the covered entries write
+            // {depth, index} at slot (output index mod 512), output index = where the batch starts +
+            // v_mbcnt rank; the other lanes write their scrap slot (v_cndmask on the mask: no EXEC
+            // change, no branch, so consecutive batches overlap freely). Every 4 batches the complete
+            // 128-aligned groups of the output are stored densely.
+            const uint32_t start_v = base + incl - c;                 // lane w: output index of batch w's first key
+            uint32_t flushed = base;
 #pragma unroll
             for (int w = 0; w < kBatches; ++w) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
+                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)start_v, w);
                 const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-                if (m == 0ull) continue;
-                const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)pexcl, w);
-                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                    const uint32_t o = start + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                    if (o < room) {
-                        *reinterpret_cast<uint2*>(kptr + o * 8u) = make_uint2(ed[w], tile);
-                        *reinterpret_cast<uint32_t*>(vptr + o * 4u) = ei[w];
+                const uint32_t o = start + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                uint2* dst = __builtin_amdgcn_inverse_ballot_w64(m) ? run_buf + (o & (kRun - 1)) : scrap;
+                *dst = ent[w];
+                if ((w % kCheck) == kCheck - 1) {
+                    const uint32_t end = base + (uint32_t)__builtin_amdgcn_readlane((int)incl, w);
+                    while (end >= (flushed & ~(kGroup - 1)) + kGroup) {
+                        const uint32_t boundary = (flushed & ~(kGroup - 1)) + kGroup;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((flushed & (kGroup - 1)) == 0u) store_run_group(run_buf, flushed, tile, keys, values);
+                        else store_run_sparse(run_buf, flushed, boundary, tile, keys, values);
+                        __builtin_amdgcn_wave_barrier();
+                        flushed = boundary;
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            store_run_sparse(run_buf, flushed, base + run, tile, keys, values);
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -455,8 +522,9 @@ size_t blockbin_geo_bytes(size_t n) {
     return blockbin_table_bytes(n) + blockbin_partial_bytes(n) + align128((2 * (kMaxBlocks + 1) + 2) * 4) +
            2 * align128((65536 + 1) * 4);
 }
-// per-instance scratch (binning chunk): keys per (unit, tile)
-size_t blockbin_bin_bytes(size_t r) { return align128((r / kUnit + kMaxBlocks + 1) * 64 * 4); }
+// per-instance scratch (binning chunk): keys per (unit, tile) + the units' transposed coverage masks
+static size_t blockbin_cnt_bytes(size_t r) { return align128((r / kUnit + kMaxBlocks + 1) * 64 * 4); }
+size_t blockbin_bin_bytes(size_t r) { return blockbin_cnt_bytes(r) + align128((r / kUnit + kMaxBlocks + 1) * 16 * kBatches * 8); }
 
 // rect_packed: out, u32[n] in depth order. ent_rd / ent_idx: R-sized scratch for the block lists.
 // ev_*: optional events recorded between the three groups of kernels (stage timing).
@@ -476,6 +544,7 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     uint32_t* tile_count = reinterpret_cast<uint32_t*>(p); p += align128((65536 + 1) * 4);
     uint32_t* tile_start = reinterpret_cast<uint32_t*>(p);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(bin_scratch);
+    uint2* unit_masks = reinterpret_cast<uint2*>(bin_scratch + blockbin_cnt_bytes(r_total));
 
     hipLaunchKernelGGL(coarse_count_kernel, dim3(chunks), dim3(kCoarse), 0, stream, n, sorted_depth, sorted_idx, rect_by_index,
                        nbx, nbp, rect_packed, table);
@@ -498,8 +567,8 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     // persistent grids: enough waves to fill the chip, never more than there can be units
     const uint32_t max_units = r_total / kUnit + (uint32_t)nb + 1u;
     const uint32_t count_wgs = std::min<uint32_t>((max_units + 3) / 4, 256u * 8u);
-    hipLaunchKernelGGL(unit_count_kernel, dim3(count_wgs), dim3(256), 0, stream, meta, nb, nbx, ent_rd, cnt);
-    GSR_LAUNCH_CHECK("unit_count_kernel");
+    hipLaunchKernelGGL(unit_masks_kernel, dim3(count_wgs), dim3(256), 0, stream, meta, nb, nbx, ent_rd, unit_masks, cnt);
+    GSR_LAUNCH_CHECK("unit_masks_kernel");
     GSR_HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
     hipLaunchKernelGGL(block_prefix_kernel, dim3(nb), dim3(256), 0, stream, meta, nbx, grid_x, grid_y, cnt, tile_count);
     GSR_LAUNCH_CHECK("block_prefix_kernel");
@@ -507,9 +576,12 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     GSR_LAUNCH_CHECK("tile_start_kernel");
     if (ev_prefix_end) GSR_HIP_TRY(hipEventRecord(ev_prefix_end, stream));
 
-    const uint32_t emit_wgs = std::min<uint32_t>((max_units + kEmitWaves - 1) / kEmitWaves, 256u * 3u);
+#ifndef GSR_EMIT_WGS_PER_CU
+#define GSR_EMIT_WGS_PER_CU 3
+#endif
+    const uint32_t emit_wgs = std::min<uint32_t>((max_units + kEmitWaves - 1) / kEmitWaves, 256u * GSR_EMIT_WGS_PER_CU);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, meta, nb, nbx, grid_x, grid_y, ent_rd, ent_idx,
-                       cnt, tile_start, keys, values, r_total);
+                       unit_masks, cnt, tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");
     return GSR_OK;
 }
