@@ -250,7 +250,7 @@ __device__ __forceinline__ void build_unit_masks(const uint32_t* __restrict__ en
     }
 #pragma unroll
     for (int w = 0; w < kBatches; ++w) {
-        if ((uint32_t)w >= nbatch) break;
+        if ((uint32_t)w >= nbatch) continue;
         const uint32_t rect = rects[w];
         const uint32_t x0 = rect & 0xFFu, rw = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, rh = rect >> 24;
         const uint32_t cx0 = max(x0, bx0) - bx0, cx1 = min(x0 + rw, bx0 + kBW) - bx0;
@@ -375,8 +375,6 @@ constexpr uint32_t kGroup = 128;             // keys per dense store group: 8 ke
 constexpr uint32_t kRun = 512;               // slots of the per-wave run buffer (>= kGroup - 1 + 4 batches of 64)
 constexpr int kCheck = 4;                    // batches between two looks at the run buffer's fill
 
-struct __attribute__((aligned(16))) KeyPair { uint32_t d0, t0, d1, t1; };   // two consecutive 64-bit keys
-
 // Sparse path (first and last group of a run): keys [a, b) of the run buffer, one per lane.
 __device__ __forceinline__ void store_run_sparse(const uint2* run_buf, uint32_t a, uint32_t b, uint32_t tile,
                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
@@ -398,10 +396,13 @@ __device__ __forceinline__ void store_run_group(const uint2* run_buf, uint32_t a
 #ifdef GSR_EXP_NOSTORE
     if (tile != 0xFFFFFFF0u) return;
 #endif
-    KeyPair k;
-    k.d0 = q.x; k.t0 = tile; k.d1 = q.z; k.t1 = tile;
-    *reinterpret_cast<KeyPair*>(keys + a + 2u * lane) = k;
-    *reinterpret_cast<uint2*>(values + a + 2u * lane) = make_uint2(q.y, q.w);
+    // streaming (nt) stores: 12 R bytes go out once and at most 1 % of them is read back by the blend
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x4 kk = {q.x, tile, q.z, tile};      // two consecutive 64-bit keys
+    const u32x2 vv = {q.y, q.w};
+    __builtin_nontemporal_store(kk, reinterpret_cast<u32x4*>(keys + a + 2u * lane));
+    __builtin_nontemporal_store(vv, reinterpret_cast<u32x2*>(values + a + 2u * lane));
 }
 
 __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta meta, int nb, int nbx, int gx, int gy,
@@ -577,7 +578,7 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     if (ev_prefix_end) GSR_HIP_TRY(hipEventRecord(ev_prefix_end, stream));
 
 #ifndef GSR_EMIT_WGS_PER_CU
-#define GSR_EMIT_WGS_PER_CU 3
+#define GSR_EMIT_WGS_PER_CU 2
 #endif
     const uint32_t emit_wgs = std::min<uint32_t>((max_units + kEmitWaves - 1) / kEmitWaves, 256u * GSR_EMIT_WGS_PER_CU);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, meta, nb, nbx, grid_x, grid_y, ent_rd, ent_idx,

@@ -39,11 +39,7 @@ def test_fullsize_lists_are_sorted_complete_and_ranged(garden):
     assert bool((keys[1:] >= keys[:-1]).all()), "sorted keys out of order"
     tie = keys[1:] == keys[:-1]
     assert bool((vals[1:][tie] > vals[:-1][tie]).all()), "equal keys must keep ascending Gaussian index"
-    # conservation: the sort is a permutation of what was emitted (checksum of checksums)
-    ku, vu = b["keys_unsorted"], b["values_unsorted"]
-    for f in (lambda k, v: k.sum(), lambda k, v: (k ^ (v.to(torch.int64) * 0x9E3779B1)).sum(),
-              lambda k, v: v.to(torch.int64).sum()):
-        assert int(f(ku, vu)) == int(f(keys, vals))
+    assert r.last_plan == "blocks"          # R / N = 46 here: the lists are written directly, nothing R-sized is sorted
     # every key's depth half is the depth of its Gaussian; its tile half lies inside the grid
     depth_bits = g["depths"].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     samp = torch.randint(0, R, (2_000_000,), device=keys.device)
@@ -56,6 +52,30 @@ def test_fullsize_lists_are_sorted_complete_and_ranged(garden):
     assert bool(((rg[:, 1] - rg[:, 0]) == counts).all())
     starts = torch.cumsum(counts, 0) - counts
     assert bool((rg[counts > 0, 0] == starts[counts > 0]).all())
+
+
+def test_fullsize_both_binning_plans_give_identical_lists(garden):
+    """The block plan (sorted lists written directly) against the sort plan (column-major emission + onesweep
+    pass): 267 M keys / values and all tile ranges bit for bit; under the sort plan the sort is a
+    permutation of what was emitted (checksum of checksums)."""
+    torch, r, cam, img = garden
+    r.draw(cam, plan="blocks")
+    assert r.last_plan == "blocks"
+    b = r.map_binning_state()
+    keys_b, vals_b = b["keys"].clone(), b["values"].clone()
+    ranges_b = r.map_image_state()["ranges"].clone()
+    img_s = r.draw(cam, plan="sort").clone()
+    assert r.last_plan == "sort"
+    b = r.map_binning_state()
+    assert torch.equal(b["keys"], keys_b) and torch.equal(b["values"], vals_b)
+    assert torch.equal(r.map_image_state()["ranges"], ranges_b)
+    assert torch.equal(img_s, img)
+    ku, vu = b["keys_unsorted"], b["values_unsorted"]
+    for f in (lambda k, v: k.sum(), lambda k, v: (k ^ (v.to(torch.int64) * 0x9E3779B1)).sum(),
+              lambda k, v: v.to(torch.int64).sum()):
+        assert int(f(ku, vu)) == int(f(b["keys"], b["values"]))
+    del keys_b, vals_b
+    r.draw(cam)
 
 
 def test_fullsize_frame_is_idempotent_and_band_sharding_is_bit_exact(garden):
