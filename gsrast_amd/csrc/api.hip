@@ -92,11 +92,13 @@ struct Readback {
     bool recorded[GSR_NUM_STAGES] = {};
     int begin_of[GSR_NUM_STAGES] = {};        // event index a stage starts at (default 2s)
     void ev_alias_begin(int stage, int after_stage) { begin_of[stage] = 2 * after_stage + 1; }
+    hipEvent_t ev_r = nullptr;                // "numRendered has landed in host memory"
     int ensure() {
         if (!host) {
             GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocDefault));
             staged_host = reinterpret_cast<unsigned long long*>(host + 8);
         }
+        if (!ev_r) GSR_HIP_TRY(hipEventCreateWithFlags(&ev_r, hipEventDisableTiming));
         return GSR_OK;
     }
     int ensure_staged() {
@@ -279,9 +281,18 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
                                    gs.scan_temp, stream));
     GSR_END(GSR_STAGE_SCAN);
-    // :772 — the pipeline's one device->host sync: the binning chunk is sized by R.
+    // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits
+    // for the copy only (an event), and the per-Gaussian depth sort — which does not depend on R — is
+    // queued first, so the device keeps working during the host round trip.
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP_TRY(hipStreamSynchronize(stream));
+    GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
+    // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
+    // half is the same for every key of a Gaussian, so those digit passes run once per
+    // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
+    GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
+    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
+    GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
+    GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     const uint32_t R = *g_rb.host;
     a->num_rendered = R;
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
@@ -301,13 +312,6 @@ int gsr_forward(gsr_forward_args* a) {
     gsr_binning_from_chunk(bin_chunk, R, &bin);
     const BinScratch bs = carve_bin_scratch(bin.sorting_space, R);
 
-    // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
-    // half is the same for every key of a Gaussian, so those digit passes run once per
-    // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
-    GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
-    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
-    GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
-    GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
     // Tile grids up to 255 x 255: the tile-column pass is produced directly by a column-major
     // emission and only the tile-row pass runs as a sort. Larger grids: depth-ordered emission and
     // 8-bit digit passes over the tile bits.
@@ -316,8 +320,11 @@ int gsr_forward(gsr_forward_args* a) {
     // one onesweep pass on the tile row. The block plan pays per (Gaussian, block) entry, so scenes
     // of tiny splats (few tiles per Gaussian) stay on the sort plan unless a flag forces one.
     bool use_blocks = xy_plan && blockbin_supported(d.grid_x, d.grid_y) && !(a->flags & GSR_FLAG_PLAN_SORT);
-    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 8ull * (uint64_t)n;
+    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 2ull * (uint64_t)n;   // measured: equal at R/N = 2.5, 1.9x faster at 46
     a->plan_used = use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC);
+    // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
+    if (!use_blocks)
+        GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(n, gs.b_k, gs.b_v, gs.rect_idx, d.grid_x, d.grid_y, R, gs.a_k, gs.block_scratch,
@@ -388,7 +395,8 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_END(GSR_STAGE_BLEND);
 
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 1, gs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 2, bs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!use_blocks)
+        GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 2, bs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (profile || count_staged) {
         if (count_staged)
             GSR_HIP_TRY(hipMemcpyAsync(g_rb.staged_host, g_rb.staged_dev, sizeof(unsigned long long),

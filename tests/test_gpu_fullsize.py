@@ -154,6 +154,32 @@ def test_1080p_midsize_frame_against_oracle():
     assert (nc != exp["nContrib"]).sum() <= 40
 
 
+def test_4k_frame_both_binning_plans_agree():
+    """3840 x 2160 (BASELINE config 3's resolution): 240 x 135 tiles = 510 tile blocks, the largest
+    block table the block plan takes (130 KB of LDS masks in coarse_emit). Lists, ranges and pixels must
+    match the sort plan bit for bit."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    scene = scenes.garden_like_scene(1_000_000, seed=47)
+    span = float(np.max(scene["means3D"][:, :3].max(0) - scene["means3D"][:, :3].min(0)))
+    cam = camera.default_camera(3840, 2160, near=0.001 * span, far=span)
+    r = SplatRasterizer(3840, 2160, background=(0.1, 0.0, 0.2))
+    r.configure_from_scene(scene)
+    img_b = r.draw(cam, plan="blocks").clone()
+    assert r.last_plan == "blocks" and r.last_num_rendered > 50_000_000
+    b = r.map_binning_state()
+    keys_b, vals_b = b["keys"].clone(), b["values"].clone()
+    ranges_b = r.map_image_state()["ranges"].clone()
+    img_s = r.draw(cam, plan="sort")
+    assert r.last_plan == "sort"
+    b = r.map_binning_state()
+    assert torch.equal(b["keys"], keys_b) and torch.equal(b["values"], vals_b)
+    assert torch.equal(r.map_image_state()["ranges"], ranges_b)
+    assert torch.equal(img_s, img_b)
+    assert bool((keys_b[1:] >= keys_b[:-1]).all())
+
+
 def test_cpp_harness_through_the_reference_signature(tmp_path):
     """A C++ caller using gscuda::forward(...) from include/gscuda_shim.hpp gets the golden image."""
     from helpers import load_golden
