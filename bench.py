@@ -222,7 +222,7 @@ def main():
         default_frame = (not distributed and args.scene == "garden_like" and args.splats == 5_834_784 and (W, H) == (1920, 1080))
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
         if default_frame and os.path.exists(tpath):
-            traffic = {k: v for k, v in json.load(open(tpath)).items() if not k.startswith("_")}
+            traffic = json.load(open(tpath)).get("blocks" if blocks else "sort", {})
 
         def roof(k, note):
             e = kernels.get(k, {"gbs": 0.0, "ms": 0.0, "alg_bytes": 0})
