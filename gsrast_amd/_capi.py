@@ -70,6 +70,23 @@ class ForwardArgs(C.Structure):
     ]
 
 
+class BackwardArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("flags", C.c_uint32),
+        ("num_gaussians", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("background", C.c_void_p),
+        ("means2D", C.c_void_p), ("conic_opacity", C.c_void_p), ("colors", C.c_void_p), ("cov3D", C.c_void_p),
+        ("radii", C.c_void_p), ("ranges", C.c_void_p), ("n_contrib", C.c_void_p), ("final_t", C.c_void_p),
+        ("point_list", C.c_void_p),
+        ("means3D", C.c_void_p), ("view_matrix", C.c_void_p), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+        ("dL_dout_color", C.c_void_p),
+        ("dL_dmean2D", C.c_void_p), ("dL_dconic_opacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
+        ("dL_dcov3D", C.c_void_p), ("dL_dshs", C.c_void_p),
+        ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
+        ("stage_ms", C.c_float * 2),
+    ]
+
+
 # name -> (restype, argtypes); this is also the list the symbol test checks against the header.
 SIGNATURES = {
     "gsr_geometry_from_chunk": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(GeometryState)]),
@@ -79,6 +96,7 @@ SIGNATURES = {
     "gsr_required_image": (C.c_size_t, [C.c_int]),
     "gsr_required_binning": (C.c_size_t, [C.c_size_t]),
     "gsr_forward": (C.c_int, [C.POINTER(ForwardArgs)]),
+    "gsr_backward": (C.c_int, [C.POINTER(BackwardArgs)]),
     "gsr_last_error": (C.c_int, []),
     "gsr_error_string": (C.c_char_p, [C.c_int]),
     "gsr_last_hip_error": (C.c_char_p, []),

@@ -18,6 +18,8 @@ void set_hip_error(hipError_t e, const char* what) {
     snprintf(g_hip_error, sizeof(g_hip_error), "%s: %s", what, hipGetErrorString(e));
 }
 
+int record_error(int code) { g_last_error = code; return code; }
+
 namespace {
 
 // obtain(): AuxBuffer.cu:13-21 — align the running pointer up, hand out `bytes`.

@@ -1,0 +1,322 @@
+// Backward pass of the forward rasterizer (BASELINE config 5): gradients of
+// L = sum(dL_dout * out_color) w.r.t. the per-Gaussian 2-D quantities the blend loop reads, then
+// through conic = inverse(cov2D) and cov2D = J W Sigma W^T J^T to the 3-D covariance, and through
+// colour = 0.5 + 0.4 DC to the DC harmonics.
+//
+// The reference has no backward pass (apps/gsrast/gscuda has none; the upstream submodule that has
+// one is empty), so this differentiates THIS library's forward, which restates the reference's:
+//   blend loop          apps/gsrast/gscuda/GSCuda.cu:623-676
+//   computeCov2D, conic GSCuda.cu:197-231, :329-335        colour  GSCuda.cu:362-366
+// Parity unpinned; oracle/backward_np.py (float64, checked against finite differences) is the checker.
+//
+// render_backward_kernel: one wavefront per 16 x 16 tile, four pixels per lane (the layout of
+// blend_wave_kernel). Every pixel walks its tile's list BACK TO FRONT from its own last contributor
+// (nContrib) starting at its final transmittance, re-deriving T_i = T_{i+1} / (1 - alpha_i); the nine
+// partial sums of a record are reduced over the wave with DPP row shifts / broadcasts and leave as
+// nine float atomics per (record, tile) — only records that some pixel of the tile composited.
+#include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "gsr_common.hpp"
+
+namespace gsr {
+namespace {
+
+struct RenderBackwardParams {
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float2* means2D;
+    const float* colors;
+    const float4* conic_opacity;
+    const float* final_t;
+    const uint32_t* n_contrib;
+    const float* background;
+    const float* dL_dout;
+    float* dL_dmean2D;          // vec2[N]
+    float* dL_dconic_opacity;   // vec4[N]: dA, dB, dC, dopacity
+    float* dL_dcolors;          // vec3[N]
+    FrameDims dims;
+    int num_tiles;
+};
+
+// sum over the 64 lanes, result in lane 63 (row_shr 1,2,4,8; row_bcast:15; row_bcast:31)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define GSR_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+    GSR_DPP_ADD(0x111, 0xf);
+    GSR_DPP_ADD(0x112, 0xf);
+    GSR_DPP_ADD(0x114, 0xf);
+    GSR_DPP_ADD(0x118, 0xf);
+    GSR_DPP_ADD(0x142, 0xa);
+    GSR_DPP_ADD(0x143, 0xc);
+#undef GSR_DPP_ADD
+    return v;
+}
+
+__global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwardParams p) {
+    __shared__ uint32_t s_id[kWave];
+    __shared__ float2 s_xy[kWave];
+    __shared__ float4 s_co[kWave];
+    __shared__ float4 s_rgb[kWave];
+
+    const int tile = p.dims.row_begin * p.dims.grid_x + (int)blockIdx.x;
+    const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
+    const int lane = threadIdx.x;
+    const int px = tx * kTile + (lane & 15), py0 = ty * kTile + (lane >> 4);
+    const float fx = (float)px;
+    const size_t plane = (size_t)p.dims.width * (size_t)p.dims.height;
+    const float bg0 = p.background[0], bg1 = p.background[1], bg2 = p.background[2];
+
+    uint32_t last[4];
+    float T[4], S[4], g0[4], g1[4], g2[4], fy[4];
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = py0 + 4 * k;
+        fy[k] = (float)py;
+        const bool inside = px < p.dims.width && py < p.dims.height;
+        last[k] = 0; T[k] = 1.0f; g0[k] = g1[k] = g2[k] = 0.0f;
+        if (inside) {
+            const size_t pid = (size_t)py * (size_t)p.dims.width + (size_t)px;
+            last[k] = p.n_contrib[pid];
+            T[k] = p.final_t[pid];
+            g0[k] = p.dL_dout[pid]; g1[k] = p.dL_dout[pid + plane]; g2[k] = p.dL_dout[pid + 2 * plane];
+        }
+        S[k] = T[k] * (bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k]);     // what lies behind, dotted with dL/dC
+        hi = max(hi, last[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, kWave));
+    if (hi == 0) return;
+    const uint2 range = p.ranges[tile];
+
+    for (int c = (int)((hi - 1) / kWave); c >= 0; --c) {
+        const uint32_t first = (uint32_t)c * kWave;
+        const uint32_t cnt = min((uint32_t)kWave, hi - first);
+        if ((uint32_t)lane < cnt) {
+            const uint32_t id = p.point_list[range.x + first + (uint32_t)lane];
+            s_id[lane] = id;
+            s_xy[lane] = p.means2D[id];
+            s_co[lane] = p.conic_opacity[id];
+            const float* col = p.colors + 3 * (size_t)id;
+            s_rgb[lane] = make_float4(col[0], col[1], col[2], 0.0f);
+        }
+        // wave-private LDS: the writes above and the reads below are ordered inside the wave
+        for (int j = (int)cnt - 1; j >= 0; --j) {
+            const uint32_t idx0 = first + (uint32_t)j;          // 0-based position in the tile's list
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - fx;
+            float a_mx = 0.0f, a_my = 0.0f, a_A = 0.0f, a_B = 0.0f, a_C = 0.0f, a_op = 0.0f, a_r = 0.0f, a_g = 0.0f, a_b = 0.0f;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (idx0 >= last[k]) continue;                   // behind this pixel's last contributor
+                const float dy = xy.y - fy[k];
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                if (power > 0.0f) continue;
+                const float G = __expf(power);                   // the forward's exp: same contributing set
+                const float raw = co.w * G;
+                const float alpha = fminf(0.99f, raw);
+                if (alpha < 1.0f / 255.0f) continue;
+                const float4 col = s_rgb[j];
+                const float inv = 1.0f / (1.0f - alpha);
+                T[k] = T[k] * inv;                               // transmittance in front of this record
+                const float cg = col.x * g0[k] + col.y * g1[k] + col.z * g2[k];
+                const float w = alpha * T[k];
+                a_r += w * g0[k]; a_g += w * g1[k]; a_b += w * g2[k];
+                const float dL_dalpha = T[k] * cg - S[k] * inv;
+                S[k] += cg * w;
+                any = true;
+                if (raw > 0.99f) continue;                       // clamped: alpha does not move with the parameters
+                a_op += G * dL_dalpha;
+                const float dpow = raw * dL_dalpha;
+                a_A += -0.5f * dx * dx * dpow;
+                a_B += -dx * dy * dpow;
+                a_C += -0.5f * dy * dy * dpow;
+                a_mx += (-co.x * dx - co.y * dy) * dpow;
+                a_my += (-co.z * dy - co.y * dx) * dpow;
+            }
+            if (__ballot(any) == 0ull) continue;
+            a_mx = wave_sum_to_lane63(a_mx); a_my = wave_sum_to_lane63(a_my);
+            a_A = wave_sum_to_lane63(a_A); a_B = wave_sum_to_lane63(a_B); a_C = wave_sum_to_lane63(a_C);
+            a_op = wave_sum_to_lane63(a_op);
+            a_r = wave_sum_to_lane63(a_r); a_g = wave_sum_to_lane63(a_g); a_b = wave_sum_to_lane63(a_b);
+            if (lane == kWave - 1) {
+                const size_t id = s_id[j];
+                unsafeAtomicAdd(p.dL_dmean2D + 2 * id, a_mx);
+                unsafeAtomicAdd(p.dL_dmean2D + 2 * id + 1, a_my);
+                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id, a_A);
+                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id + 1, a_B);
+                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id + 2, a_C);
+                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id + 3, a_op);
+                unsafeAtomicAdd(p.dL_dcolors + 3 * id, a_r);
+                unsafeAtomicAdd(p.dL_dcolors + 3 * id + 1, a_g);
+                unsafeAtomicAdd(p.dL_dcolors + 3 * id + 2, a_b);
+            }
+        }
+    }
+}
+
+// ---- per Gaussian: conic -> cov2D -> cov3D, colour -> DC harmonics -----------------------------------
+struct PreprocessBackwardParams {
+    int n;
+    const float4* means3D;
+    const float* cov3D;
+    const int32_t* radii;
+    const float* view;
+    float tan_fovx, tan_fovy, focal;
+    const float4* dL_dconic_opacity;
+    const float* dL_dcolors;
+    float* dL_dcov3D;       // f32[6 N]
+    float* dL_dshs;         // f32[48 N] or null; only the DC triple of every Gaussian is written
+};
+
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBackwardParams p) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.n) return;
+    float out[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const bool visible = p.radii[idx] > 0;
+    if (visible) {
+        const float* v = p.view;
+        const float4 mean = p.means3D[idx];
+        // t, clamped as in computeCov2D (GSCuda.cu:201-210)
+        float tx = (v[0] * mean.x + v[4] * mean.y) + (v[8] * mean.z + v[12] * 1.0f);
+        float ty = (v[1] * mean.x + v[5] * mean.y) + (v[9] * mean.z + v[13] * 1.0f);
+        const float tz = (v[2] * mean.x + v[6] * mean.y) + (v[10] * mean.z + v[14] * 1.0f);
+        const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
+        tx = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
+        // P = J W (2 x 3): cov2D = P Sigma P^T
+        const float j00 = p.focal / tz, j02 = -p.focal * tx / (tz * tz), j12 = -p.focal * ty / (tz * tz);
+        float P[2][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            P[0][c] = j00 * v[4 * c + 0] + j02 * v[4 * c + 2];
+            P[1][c] = j00 * v[4 * c + 1] + j12 * v[4 * c + 2];
+        }
+        const float* c3 = p.cov3D + 6 * (size_t)idx;
+        const float s[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+        float ps[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ps[r][c] = P[r][0] * s[0][c] + P[r][1] * s[1][c] + P[r][2] * s[2][c];
+        const float a = (ps[0][0] * P[0][0] + ps[0][1] * P[0][1] + ps[0][2] * P[0][2]) + 0.3f;
+        const float b = ps[0][0] * P[1][0] + ps[0][1] * P[1][1] + ps[0][2] * P[1][2];
+        const float cc = (ps[1][0] * P[1][0] + ps[1][1] * P[1][1] + ps[1][2] * P[1][2]) + 0.3f;
+        const float det = a * cc - b * b;
+        if (det != 0.0f) {
+            const float inv = 1.0f / det;
+            const float k00 = cc * inv, k01 = -b * inv, k11 = a * inv;         // K = cov2D^-1 = the conic
+            const float4 g = p.dL_dconic_opacity[idx];
+            const float q00 = g.x, q01 = 0.5f * g.y, q11 = g.z;                // gradient w.r.t. the full symmetric K
+            // gM = -K gK K
+            const float r00 = k00 * q00 + k01 * q01, r01 = k00 * q01 + k01 * q11;
+            const float r10 = k01 * q00 + k11 * q01, r11 = k01 * q01 + k11 * q11;
+            const float m00 = -(r00 * k00 + r01 * k01), m01 = -(r00 * k01 + r01 * k11);
+            const float m11 = -(r10 * k01 + r11 * k11);
+            // gS = P^T gM P, stored entries: off-diagonals appear twice in Sigma
+            float gp[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                gp[0][c] = m00 * P[0][c] + m01 * P[1][c];
+                gp[1][c] = m01 * P[0][c] + m11 * P[1][c];
+            }
+            auto gs = [&](int r, int c) { return P[0][r] * gp[0][c] + P[1][r] * gp[1][c]; };
+            out[0] = gs(0, 0); out[1] = 2.0f * gs(0, 1); out[2] = 2.0f * gs(0, 2);
+            out[3] = gs(1, 1); out[4] = 2.0f * gs(1, 2); out[5] = gs(2, 2);
+        }
+    }
+    float2* dst = reinterpret_cast<float2*>(p.dL_dcov3D + 6 * (size_t)idx);
+    dst[0] = make_float2(out[0], out[1]);
+    dst[1] = make_float2(out[2], out[3]);
+    dst[2] = make_float2(out[4], out[5]);
+    if (p.dL_dshs) {
+        const float* gc = p.dL_dcolors + 3 * (size_t)idx;
+        float* o = p.dL_dshs + 48 * (size_t)idx;
+        o[0] = visible ? 0.4f * gc[0] : 0.0f;           // colour = 0.5 + 0.4 DC (GSCuda.cu:362-366)
+        o[1] = visible ? 0.4f * gc[1] : 0.0f;
+        o[2] = visible ? 0.4f * gc[2] : 0.0f;
+    }
+}
+
+static thread_local hipEvent_t g_bw_ev[3] = {nullptr, nullptr, nullptr};
+
+}  // namespace
+}  // namespace gsr
+
+using namespace gsr;
+
+static int backward_impl(gsr_backward_args* a) {
+    if (!a || a->struct_size != sizeof(gsr_backward_args)) return GSR_ERR_INVALID_ARG;
+    a->stage_ms[0] = a->stage_ms[1] = 0.0f;
+    const int n = a->num_gaussians;
+    if (n <= 0 || a->width <= 0 || a->height <= 0 || !a->background || !a->means2D || !a->conic_opacity || !a->colors ||
+        !a->ranges || !a->point_list || !a->n_contrib || !a->final_t || !a->dL_dout_color || !a->dL_dmean2D ||
+        !a->dL_dconic_opacity || !a->dL_dcolors)
+        return GSR_ERR_INVALID_ARG;
+    if (a->dL_dcov3D && (!a->cov3D || !a->means3D || !a->view_matrix || !a->radii)) return GSR_ERR_INVALID_ARG;
+    if (a->flags & GSR_FLAG_SEMANTICS_INRIA) return GSR_ERR_INVALID_ARG;      // gscuda semantics only
+    hipStream_t stream = (hipStream_t)a->stream;
+    const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
+    if (profile && !g_bw_ev[0])
+        for (auto& e : g_bw_ev) GSR_HIP_TRY(hipEventCreate(&e));
+
+    FrameDims d;
+    d.width = a->width; d.height = a->height;
+    d.grid_x = (a->width + kTile - 1) / kTile; d.grid_y = (a->height + kTile - 1) / kTile;
+    d.row_begin = 0; d.row_end = d.grid_y;
+    if (a->tile_row_begin != 0 || a->tile_row_end != 0) {
+        if (a->tile_row_begin < 0 || a->tile_row_end > d.grid_y || a->tile_row_begin > a->tile_row_end) return GSR_ERR_INVALID_ARG;
+        d.row_begin = a->tile_row_begin; d.row_end = a->tile_row_end;
+    }
+    GSR_HIP_TRY(hipMemsetAsync(a->dL_dmean2D, 0, sizeof(float) * 2 * (size_t)n, stream));
+    GSR_HIP_TRY(hipMemsetAsync(a->dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)n, stream));
+    GSR_HIP_TRY(hipMemsetAsync(a->dL_dcolors, 0, sizeof(float) * 3 * (size_t)n, stream));
+    if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[0], stream));
+    RenderBackwardParams r;
+    r.ranges = reinterpret_cast<const uint2*>(a->ranges);
+    r.point_list = a->point_list;
+    r.means2D = reinterpret_cast<const float2*>(a->means2D);
+    r.colors = a->colors;
+    r.conic_opacity = reinterpret_cast<const float4*>(a->conic_opacity);
+    r.final_t = a->final_t;
+    r.n_contrib = a->n_contrib;
+    r.background = a->background;
+    r.dL_dout = a->dL_dout_color;
+    r.dL_dmean2D = a->dL_dmean2D;
+    r.dL_dconic_opacity = a->dL_dconic_opacity;
+    r.dL_dcolors = a->dL_dcolors;
+    r.dims = d;
+    r.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
+    if (r.num_tiles > 0) {
+        hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)r.num_tiles), dim3(kWave), 0, stream, r);
+        GSR_LAUNCH_CHECK("render_backward_kernel");
+    }
+    if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[1], stream));
+    if (a->dL_dcov3D) {
+        PreprocessBackwardParams q;
+        q.n = n;
+        q.means3D = reinterpret_cast<const float4*>(a->means3D);
+        q.cov3D = a->cov3D;
+        q.radii = a->radii;
+        q.view = a->view_matrix;
+        q.tan_fovx = a->tan_fovx; q.tan_fovy = a->tan_fovy;
+        q.focal = (float)a->height / (2.0f * a->tan_fovy);
+        q.dL_dconic_opacity = reinterpret_cast<const float4*>(a->dL_dconic_opacity);
+        q.dL_dcolors = a->dL_dcolors;
+        q.dL_dcov3D = a->dL_dcov3D;
+        q.dL_dshs = a->dL_dshs;
+        hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
+        GSR_LAUNCH_CHECK("preprocess_backward_kernel");
+    }
+    if (profile) {
+        GSR_HIP_TRY(hipEventRecord(g_bw_ev[2], stream));
+        GSR_HIP_TRY(hipStreamSynchronize(stream));
+        GSR_HIP_TRY(hipEventElapsedTime(&a->stage_ms[0], g_bw_ev[0], g_bw_ev[1]));
+        GSR_HIP_TRY(hipEventElapsedTime(&a->stage_ms[1], g_bw_ev[1], g_bw_ev[2]));
+    }
+    return GSR_OK;
+}
+
+extern "C" int gsr_backward(gsr_backward_args* a) { return record_error(backward_impl(a)); }

@@ -13,6 +13,8 @@ constexpr int kWave = 64;          // gfx950 wavefront
 
 // Records the failing HIP call for gsr_last_hip_error().
 void set_hip_error(hipError_t e, const char* what);
+// Sets the calling thread's sticky error (gsr_last_error) and returns `code`.
+int record_error(int code);
 
 #define GSR_HIP_TRY(expr)                                   \
     do {                                                    \

@@ -156,6 +156,51 @@ class SplatRasterizer:
             _capi.check(self.lib.gsr_poll_async_error(), "gsr_forward (device side)")
         return self.out_color
 
+    # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
+    def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
+                 tile_rows: tuple[int, int] | None = None) -> dict:
+        """Gradients of sum(dL_dout * out_color) of the LAST draw() (gscuda semantics) through gsr_backward.
+        Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3] and, with
+        with_cov3D, dL_dcov3D [N,6] and dL_dshs [N,48] (DC triple only)."""
+        n, dev = self.num_gaussians, self.device
+        g = dL_dout.to(device=dev, dtype=torch.float32).contiguous()
+        assert g.shape == (3, self.height, self.width)
+        gst, ist, bst = _capi.GeometryState(), _capi.ImageState(), _capi.BinningState()
+        self.lib.gsr_geometry_from_chunk(self.geom.base(), n, C.byref(gst))
+        self.lib.gsr_image_from_chunk(self.image.base(), self.width * self.height, C.byref(ist))
+        self.lib.gsr_binning_from_chunk(self.binning.base(), self.last_num_rendered, C.byref(bst))
+        out = {"dL_dmean2D": torch.empty((n, 2), dtype=torch.float32, device=dev),
+               "dL_dconic_opacity": torch.empty((n, 4), dtype=torch.float32, device=dev),
+               "dL_dcolors": torch.empty((n, 3), dtype=torch.float32, device=dev)}
+        if with_cov3D:
+            out["dL_dcov3D"] = torch.empty((n, 6), dtype=torch.float32, device=dev)
+            out["dL_dshs"] = torch.zeros((n, 48), dtype=torch.float32, device=dev)
+        a = _capi.BackwardArgs()
+        a.struct_size = C.sizeof(_capi.BackwardArgs)
+        a.flags = _capi.GSR_FLAG_PROFILE if profile else 0
+        a.num_gaussians, a.width, a.height = n, self.width, self.height
+        a.background = self.background.data_ptr()
+        a.means2D, a.conic_opacity, a.colors, a.cov3D = gst.means2D, gst.conic_opacity, gst.rgb, gst.cov3D
+        a.radii = gst.internal_radii
+        a.ranges, a.n_contrib, a.final_t = ist.ranges, ist.n_contrib, ist.accum_alpha
+        a.point_list = bst.values
+        a.means3D, a.view_matrix = self.means3D.data_ptr(), self._view.data_ptr()
+        a.tan_fovx, a.tan_fovy = self._tan
+        a.dL_dout_color = g.data_ptr()
+        a.dL_dmean2D, a.dL_dconic_opacity = out["dL_dmean2D"].data_ptr(), out["dL_dconic_opacity"].data_ptr()
+        a.dL_dcolors = out["dL_dcolors"].data_ptr()
+        a.dL_dcov3D = out["dL_dcov3D"].data_ptr() if with_cov3D else None
+        a.dL_dshs = out["dL_dshs"].data_ptr() if with_cov3D else None
+        a.stream = torch.cuda.current_stream(dev).cuda_stream
+        if tile_rows is not None:
+            a.tile_row_begin, a.tile_row_end = int(tile_rows[0]), int(tile_rows[1])
+        with torch.cuda.device(dev):
+            rc = self.lib.gsr_backward(C.byref(a))
+        _capi.check(rc, "gsr_backward")
+        self.last_backward_ms = (float(a.stage_ms[0]), float(a.stage_ms[1])) if profile else ()
+        torch.cuda.current_stream(dev).synchronize()
+        return out
+
     # -- state inspection (what the reference's Inspector does through fromChunk) ------
     def map_geometry_state(self) -> dict:
         st = _capi.GeometryState()

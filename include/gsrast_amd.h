@@ -188,6 +188,51 @@ size_t gsr_sort_temp_bytes(size_t n);
 int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
                            uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, void* stream);
 
+/* ---- backward pass (next row after the hot path: BASELINE config 5) ----
+ * Gradients of L = sum(dL_dout_color * out_color) of ONE gsr_forward call (gscuda semantics) w.r.t. the
+ * per-Gaussian quantities its blend loop reads, and on to the 3-D covariance and the DC harmonics. The
+ * reference has no backward pass (parity unpinned); conventions, checked by finite differences in
+ * oracle/backward_np.py:
+ *   dL_dmean2D        vec2[N]  w.r.t. the pixel-space centre (no NDC factor)
+ *   dL_dconic_opacity vec4[N]  w.r.t. (A, B, C) of power = -0.5 (A dx^2 + C dy^2) - B dx dy, and opacity
+ *   dL_dcolors        vec3[N]
+ *   dL_dcov3D         f32[6N]  w.r.t. the six stored covariance numbers (optional: NULL skips the chain)
+ *   dL_dshs           f32[48N] only the DC triple of every Gaussian is written (colour = 0.5 + 0.4 DC); optional
+ * Hard tests of the forward (power > 0, alpha < 1/255, transmittance cut-off) select a branch; where
+ * alpha is clamped to 0.99 its derivative w.r.t. the Gaussian's parameters is zero. The state pointers are
+ * those of the forward call's chunks (gsr_*_from_chunk): it must have run on the same inputs, same size. */
+typedef struct gsr_backward_args {
+    uint32_t struct_size;          /* = sizeof(gsr_backward_args) */
+    uint32_t flags;                /* GSR_FLAG_PROFILE */
+    int32_t num_gaussians, width, height;
+    const float* background;       /* device vec3 */
+    /* state of the forward call */
+    const float* means2D;          /* geometry chunk */
+    const float* conic_opacity;
+    const float* colors;           /* geometry rgb, or the colors_precomp the forward call was given */
+    const float* cov3D;            /* geometry cov3D, or the cov3D_precomp given (only with dL_dcov3D) */
+    const int32_t* radii;          /* internal_radii or the radii buffer given (only with dL_dcov3D) */
+    const uint32_t* ranges;        /* image chunk */
+    const uint32_t* n_contrib;
+    const float* final_t;          /* accum_alpha */
+    const uint32_t* point_list;    /* binning chunk: values */
+    /* inputs of the forward call that the covariance chain needs again (only with dL_dcov3D) */
+    const float* means3D;
+    const float* view_matrix;
+    float tan_fovx, tan_fovy;
+    const float* dL_dout_color;    /* device f32[3 W H], planar like out_color */
+    /* outputs (device) */
+    float* dL_dmean2D;
+    float* dL_dconic_opacity;
+    float* dL_dcolors;
+    float* dL_dcov3D;              /* or NULL */
+    float* dL_dshs;                /* or NULL */
+    void* stream;
+    int32_t tile_row_begin, tile_row_end;   /* as gsr_forward: the rows the forward call processed */
+    float stage_ms[2];             /* with GSR_FLAG_PROFILE: render backward, covariance / colour chain */
+} gsr_backward_args;
+int gsr_backward(gsr_backward_args* args);
+
 /* ---- scene loading (next row after the hot path) ---- */
 /* Header of a 3DGS .ply as the reference reads it (apps/gsrast/SplatData.cpp:114-145): vertex
  * count = third token of the third line; data starts after the "end_header" line. Host only.

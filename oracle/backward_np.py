@@ -1,0 +1,171 @@
+"""Gradient oracle of the forward rasterizer (BASELINE config 5), numpy float64.
+
+TEST INFRASTRUCTURE: imported by tests/ only, never by the product path.
+
+**Parity unpinned**: the reference has no backward pass (apps/gsrast/gscuda has none, and the
+upstream submodule that has one is an empty directory), so there is no reference gradient to
+compare with. What pins this oracle instead is the forward function itself: `blend_forward` restates
+the reference's blend loop (apps/gsrast/gscuda/GSCuda.cu:623-676) and `cov2d_conic` its
+computeCov2D / conic (GSCuda.cu:197-231, :329-335) in float64; the analytic gradients below are
+checked against central finite differences of exactly those functions (tests/test_backward_oracle.py).
+
+Conventions (also those of gsr_backward in include/gsrast_amd.h):
+  L = sum over pixels and channels of dL_dout * out_color
+  dL_dmean2D  [N,2]  w.r.t. the pixel-space centre means2D (the reference's pixel units, no NDC factor)
+  dL_dconic   [N,3]  w.r.t. the three stored numbers (A, B, C) of power = -0.5 (A dx^2 + C dy^2) - B dx dy
+  dL_dopacity [N]    w.r.t. conicOpacity.w
+  dL_dcolor   [N,3]
+  dL_dcov3D   [N,6]  w.r.t. the six stored numbers of the symmetric 3-D covariance (GSCuda.cu:189-194)
+  dL_ddc      [N,3]  w.r.t. the DC spherical-harmonic coefficients (colour = 0.5 + 0.4 DC, GSCuda.cu:362-366)
+The forward function is piecewise smooth: the hard tests (power > 0, alpha < 1/255, alpha clamp at 0.99,
+transmittance cut-off) select a branch and contribute no derivative of their own; where alpha is clamped
+to 0.99 its derivative w.r.t. the Gaussian's parameters is zero.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE = 16
+
+
+def _pixel_lists(ranges, point_list, width, height):
+    gx = (width + TILE - 1) // TILE
+    for py in range(height):
+        for px in range(width):
+            t = (py // TILE) * gx + (px // TILE)
+            a, b = int(ranges[t, 0]), int(ranges[t, 1])
+            yield px, py, point_list[a:b] if b > a else point_list[0:0]
+
+
+def blend_forward(means2D, conic_opacity, colors, ranges, point_list, width, height, background, t_cutoff=0.001):
+    """GSCuda.cu:623-676 per pixel, float64. Returns out[3,H,W], finalT[H,W], n_contrib[H,W]."""
+    m = np.asarray(means2D, np.float64)
+    co = np.asarray(conic_opacity, np.float64)
+    col = np.asarray(colors, np.float64)
+    bg = np.asarray(background, np.float64)
+    out = np.zeros((3, height, width))
+    final_t = np.ones((height, width))
+    n_contrib = np.zeros((height, width), np.int64)
+    for px, py, ids in _pixel_lists(ranges, point_list, width, height):
+        T, C, last = 1.0, np.zeros(3), 0
+        for k, g in enumerate(ids):
+            dx, dy = m[g, 0] - px, m[g, 1] - py
+            power = -0.5 * (co[g, 0] * dx * dx + co[g, 2] * dy * dy) - co[g, 1] * dx * dy
+            if power > 0.0:
+                continue
+            alpha = min(0.99, co[g, 3] * np.exp(power))
+            if alpha < 1.0 / 255.0:
+                continue
+            test = T * (1.0 - alpha)
+            if test < t_cutoff:
+                break
+            C = C + col[g] * alpha * T
+            T = test
+            last = k + 1
+        out[:, py, px] = C + T * bg
+        final_t[py, px] = T
+        n_contrib[py, px] = last
+    return out, final_t, n_contrib
+
+
+def blend_backward(means2D, conic_opacity, colors, ranges, point_list, n_contrib, final_t, width, height, background,
+                   dL_dout):
+    """Analytic gradients of sum(dL_dout * out) through the blend loop, walking each pixel's list back to
+    front from its last contributor (the quantities a GPU backward pass has: nContrib, finalT)."""
+    m = np.asarray(means2D, np.float64)
+    co = np.asarray(conic_opacity, np.float64)
+    col = np.asarray(colors, np.float64)
+    bg = np.asarray(background, np.float64)
+    g_out = np.asarray(dL_dout, np.float64)
+    n = m.shape[0]
+    d_mean, d_conic, d_op, d_col = np.zeros((n, 2)), np.zeros((n, 3)), np.zeros(n), np.zeros((n, 3))
+    for px, py, ids in _pixel_lists(ranges, point_list, width, height):
+        gp = g_out[:, py, px]
+        T = float(final_t[py, px])
+        S = T * float(bg @ gp)                 # what lies behind the current record, dotted with dL/dC
+        for k in range(int(n_contrib[py, px]) - 1, -1, -1):
+            g = ids[k]
+            dx, dy = m[g, 0] - px, m[g, 1] - py
+            A, B, Cc, op = co[g]
+            power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+            if power > 0.0:
+                continue
+            G = np.exp(power)
+            raw = op * G
+            alpha = min(0.99, raw)
+            if alpha < 1.0 / 255.0:
+                continue
+            T = T / (1.0 - alpha)              # transmittance in front of this record
+            cg = float(col[g] @ gp)
+            d_col[g] += alpha * T * gp
+            dL_dalpha = T * cg - S / (1.0 - alpha)
+            S += cg * alpha * T
+            if raw > 0.99:                     # clamped: alpha does not move with the Gaussian's parameters
+                continue
+            d_op[g] += G * dL_dalpha
+            dL_dpower = op * G * dL_dalpha
+            d_conic[g, 0] += -0.5 * dx * dx * dL_dpower
+            d_conic[g, 1] += -dx * dy * dL_dpower
+            d_conic[g, 2] += -0.5 * dy * dy * dL_dpower
+            d_mean[g, 0] += (-A * dx - B * dy) * dL_dpower
+            d_mean[g, 1] += (-Cc * dy - B * dx) * dL_dpower
+    return {"dL_dmean2D": d_mean, "dL_dconic": d_conic, "dL_dopacity": d_op, "dL_dcolor": d_col}
+
+
+# ---- cov3D -> conic (computeCov2D + inverse), and its gradient ------------------------------------
+def _jw(mean3, view, focal, tan_fovx, tan_fovy):
+    """The 2 x 3 matrix P with cov2D = P Sigma P^T (GSCuda.cu:201-225). view: 16 floats, column-major."""
+    v = np.asarray(view, np.float64)
+    t = np.array([v[0] * mean3[0] + v[4] * mean3[1] + v[8] * mean3[2] + v[12],
+                  v[1] * mean3[0] + v[5] * mean3[1] + v[9] * mean3[2] + v[13],
+                  v[2] * mean3[0] + v[6] * mean3[1] + v[10] * mean3[2] + v[14]])
+    limx, limy = 1.3 * tan_fovx, 1.3 * tan_fovy
+    tx = min(limx, max(-limx, t[0] / t[2])) * t[2]
+    ty = min(limy, max(-limy, t[1] / t[2])) * t[2]
+    J = np.array([[focal / t[2], 0.0, -focal * tx / (t[2] * t[2])],
+                  [0.0, focal / t[2], -focal * ty / (t[2] * t[2])]])
+    W = np.array([[v[0], v[4], v[8]], [v[1], v[5], v[9]], [v[2], v[6], v[10]]])   # rotation rows of the view matrix
+    return J @ W
+
+
+def _sigma(c3):
+    return np.array([[c3[0], c3[1], c3[2]], [c3[1], c3[3], c3[4]], [c3[2], c3[4], c3[5]]], np.float64)
+
+
+def cov2d_conic(c3, mean3, view, focal, tan_fovx, tan_fovy):
+    """(A, B, C) of the conic from the 6 stored covariance numbers (GSCuda.cu:197-231, :329-335)."""
+    P = _jw(mean3, view, focal, tan_fovx, tan_fovy)
+    cov = P @ _sigma(c3) @ P.T
+    a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+    det = a * c - b * b
+    return np.array([c / det, -b / det, a / det])
+
+
+def conic_backward(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic):
+    """dL/d(6 covariance numbers) from dL/d(A, B, C)."""
+    P = _jw(mean3, view, focal, tan_fovx, tan_fovy)
+    cov = P @ _sigma(c3) @ P.T
+    a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+    det = a * c - b * b
+    K = np.array([[c, -b], [-b, a]]) / det
+    gA, gB, gC = dL_dconic
+    gK = np.array([[gA, 0.5 * gB], [0.5 * gB, gC]])        # gradient w.r.t. the full symmetric matrix entries
+    gM = -K @ gK @ K                                        # d(M^-1) = -M^-1 dM M^-1
+    gS = P.T @ gM @ P                                       # w.r.t. the full 3 x 3 Sigma entries
+    return np.array([gS[0, 0], 2.0 * gS[0, 1], 2.0 * gS[0, 2], gS[1, 1], 2.0 * gS[1, 2], gS[2, 2]])
+
+
+def finite_difference(f, x, eps):
+    """Central differences of the scalar function f at x (flattened), one coordinate at a time."""
+    x = np.array(x, np.float64)
+    g = np.zeros_like(x)
+    flat, gf = x.reshape(-1), g.reshape(-1)
+    for i in range(flat.size):
+        old = flat[i]
+        flat[i] = old + eps
+        hi = f(x)
+        flat[i] = old - eps
+        lo = f(x)
+        flat[i] = old
+        gf[i] = (hi - lo) / (2.0 * eps)
+    return g

@@ -1,0 +1,76 @@
+"""CPU: the gradient oracle (oracle/backward_np.py) is pinned by central finite differences of the forward
+functions it differentiates — the float64 restatement of the reference's blend loop (GSCuda.cu:623-676) and
+of computeCov2D + conic (GSCuda.cu:197-231, :329-335). The reference has no backward pass to compare with."""
+import numpy as np
+
+from oracle import backward_np as B
+
+
+def _toy(seed=0, n=14, w=24, h=20):
+    rng = np.random.default_rng(seed)
+    means = np.stack([rng.uniform(-2, w + 2, n), rng.uniform(-2, h + 2, n)], 1)
+    # positive-definite conics of mixed size; a few nearly opaque splats so that alpha clamps and pixels terminate
+    s = rng.uniform(0.02, 0.4, (n, 2))
+    rho = rng.uniform(-0.6, 0.6, n)
+    conic = np.stack([s[:, 0], rho * np.sqrt(s[:, 0] * s[:, 1]), s[:, 1]], 1)
+    op = rng.uniform(0.05, 1.0, n)
+    op[:3] = [1.0, 0.999, 0.97]
+    conic[:3] *= 0.05
+    co = np.concatenate([conic, op[:, None]], 1)
+    col = rng.uniform(-0.2, 1.2, (n, 3))
+    gx, gy = (w + 15) // 16, (h + 15) // 16
+    order = rng.permutation(n)
+    plist = np.tile(order, gx * gy).astype(np.int64)
+    ranges = np.array([[t * n, (t + 1) * n] for t in range(gx * gy)], np.int64)
+    g_out = rng.normal(size=(3, h, w))
+    return means, co, col, ranges, plist, w, h, np.array([0.3, 0.1, 0.7]), g_out
+
+
+def test_blend_gradients_match_finite_differences():
+    means, co, col, ranges, plist, w, h, bg, g_out = _toy()
+    out, ft, nc = B.blend_forward(means, co, col, ranges, plist, w, h, bg)
+    assert nc.max() > 3 and (ft < 0.05).any() and (nc < len(means)).any()      # some pixels terminate early
+    g = B.blend_backward(means, co, col, ranges, plist, nc, ft, w, h, bg, g_out)
+
+    def loss_of(m=means, c=co, k=col):
+        return float((B.blend_forward(m, c, k, ranges, plist, w, h, bg)[0] * g_out).sum())
+
+    fd_mean = B.finite_difference(lambda x: loss_of(m=x), means, 1e-6)
+    fd_co = B.finite_difference(lambda x: loss_of(c=x), co, 1e-7)
+    fd_col = B.finite_difference(lambda x: loss_of(k=x), col, 1e-6)
+    scale = max(1.0, np.abs(fd_mean).max())
+    assert np.abs(g["dL_dmean2D"] - fd_mean).max() <= 2e-5 * scale
+    assert np.abs(g["dL_dconic"] - fd_co[:, :3]).max() <= 2e-5 * max(1.0, np.abs(fd_co[:, :3]).max())
+    assert np.abs(g["dL_dopacity"] - fd_co[:, 3]).max() <= 2e-5 * max(1.0, np.abs(fd_co[:, 3]).max())
+    assert np.abs(g["dL_dcolor"] - fd_col).max() <= 1e-6 * max(1.0, np.abs(fd_col).max())
+    # the clamped splat (opacity * G > 0.99 near its centre) still receives colour gradient
+    assert np.abs(g["dL_dcolor"][0]).sum() > 0
+
+
+def test_background_and_empty_tiles():
+    means, co, col, ranges, plist, w, h, bg, g_out = _toy(seed=3)
+    ranges = ranges.copy()
+    ranges[1] = (0, 0)                                   # a tile nothing touches: out = background, no gradient
+    out, ft, nc = B.blend_forward(means, co, col, ranges, plist, w, h, bg)
+    assert np.allclose(out[:, 0:16, 16:24], bg[:, None, None]) and (nc[0:16, 16:24] == 0).all()
+    g = B.blend_backward(means, co, col, ranges, plist, nc, ft, w, h, bg, g_out)
+    fd = B.finite_difference(lambda x: float((B.blend_forward(means, co, x, ranges, plist, w, h, bg)[0] * g_out).sum()),
+                             col, 1e-6)
+    assert np.abs(g["dL_dcolor"] - fd).max() <= 1e-6 * max(1.0, np.abs(fd).max())
+
+
+def test_cov3d_to_conic_gradient_matches_finite_differences():
+    rng = np.random.default_rng(5)
+    from gsrast_amd import camera
+    cam = camera.default_camera(640, 480)
+    focal = 480 / (2.0 * cam.tan_fovy)
+    for _ in range(6):
+        a = rng.normal(size=(3, 3)) * 0.2
+        sig = a @ a.T + 0.01 * np.eye(3)
+        c3 = np.array([sig[0, 0], sig[0, 1], sig[0, 2], sig[1, 1], sig[1, 2], sig[2, 2]])
+        mean3 = rng.uniform(-1.5, 1.5, 3)
+        gk = rng.normal(size=3)
+        f = lambda x: float(B.cov2d_conic(x, mean3, cam.view, focal, cam.tan_fovx, cam.tan_fovy) @ gk)
+        fd = B.finite_difference(f, c3, 1e-7)
+        an = B.conic_backward(c3, mean3, cam.view, focal, cam.tan_fovx, cam.tan_fovy, gk)
+        assert np.abs(an - fd).max() <= 1e-5 * max(1.0, np.abs(fd).max()), (an, fd)

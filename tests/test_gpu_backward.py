@@ -1,0 +1,112 @@
+"""GPU: gsr_backward (render backward + covariance / colour chain) against the float64 gradient oracle
+(oracle/backward_np.py, itself pinned by finite differences in tests/test_backward_oracle.py). The oracle
+re-runs the blend loop in float64 on the GPU's own forward state (means2D, conics, colours, sorted lists)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-4       # float32 accumulation in atomics (order varies) against a float64 sum
+
+
+def _close(got, exp, what, rtol=RTOL):
+    scale = max(1e-6, float(np.abs(exp).max()))
+    err = float(np.abs(got - exp).max())
+    assert err <= rtol * scale, f"{what}: max abs err {err} at scale {scale}"
+
+
+def _forward_state(r):
+    g = {k: v.cpu().numpy() for k, v in r.map_geometry_state().items()}
+    im = {k: v.cpu().numpy() for k, v in r.map_image_state().items()}
+    b = {k: v.cpu().numpy() for k, v in r.map_binning_state().items()}
+    return g, im, b
+
+
+@pytest.mark.parametrize("w,h,n,seed,bg", [(64, 48, 300, 1, (0.0, 0.0, 0.0)), (100, 70, 1200, 2, (0.2, 0.5, 0.9))])
+def test_backward_matches_float64_oracle(w, h, n, seed, bg):
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    from oracle import backward_np as B
+    scene = scenes.garden_like_scene(n, seed=seed)
+    scene["means3D"][:, :3] *= 0.25
+    cam = camera.default_camera(w, h, near=0.05, far=50.0)
+    r = SplatRasterizer(w, h, background=bg)
+    r.configure_from_scene(scene)
+    img = r.draw(cam).cpu().numpy()
+    assert r.last_num_rendered > 0
+    g, im, b = _forward_state(r)
+    rng = np.random.default_rng(seed)
+    dL = rng.normal(size=(3, h, w)).astype(np.float32)
+    got = {k: v.cpu().numpy() for k, v in r.backward(torch.from_numpy(dL)).items()}
+
+    ranges = im["ranges"].view(np.uint32).astype(np.int64)
+    plist = b["values"].view(np.uint32).astype(np.int64)
+    out64, ft64, nc64 = B.blend_forward(g["means2D"], g["conicOpacity"], g["rgb"], ranges, plist, w, h, bg)
+    assert np.abs(out64 - img).max() <= 1e-4
+    # the contributing set must be the same one (threshold flips between exp implementations would show here)
+    assert (nc64 != im["nContrib"].view(np.uint32)).sum() <= 2
+    exp = B.blend_backward(g["means2D"], g["conicOpacity"], g["rgb"], ranges, plist, nc64, ft64, w, h, bg, dL)
+    _close(got["dL_dmean2D"], exp["dL_dmean2D"], "dL_dmean2D")
+    _close(got["dL_dconic_opacity"][:, :3], exp["dL_dconic"], "dL_dconic")
+    _close(got["dL_dconic_opacity"][:, 3], exp["dL_dopacity"], "dL_dopacity")
+    _close(got["dL_dcolors"], exp["dL_dcolor"], "dL_dcolors")
+    assert np.abs(exp["dL_dmean2D"]).max() > 0 and np.abs(exp["dL_dconic"]).max() > 0
+
+    # covariance / colour chain, Gaussian by Gaussian, fed with the GPU's own dL_dconic
+    focal = h / (2.0 * cam.tan_fovy)
+    vis = np.nonzero(g["radii"] > 0)[0]
+    exp_cov = np.zeros((n, 6))
+    for i in vis:
+        exp_cov[i] = B.conic_backward(g["cov3D"][i].astype(np.float64), scene["means3D"][i, :3].astype(np.float64), cam.view,
+                                      focal, cam.tan_fovx, cam.tan_fovy, got["dL_dconic_opacity"][i, :3].astype(np.float64))
+    # float32 chain through a 2x2 inverse: compare per Gaussian relative to its own magnitude
+    err = np.abs(got["dL_dcov3D"] - exp_cov).max(1)
+    mag = np.maximum(np.abs(exp_cov).max(1), 1e-3 * np.abs(exp_cov).max())
+    assert (err <= 2e-3 * mag).all(), float((err / mag).max())
+    assert (got["dL_dcov3D"][g["radii"] <= 0] == 0).all()
+    sh = got["dL_dshs"]
+    assert np.allclose(sh[:, :3], 0.4 * got["dL_dcolors"] * (g["radii"] > 0)[:, None], rtol=1e-6, atol=0)
+    assert (sh[:, 3:] == 0).all()
+
+
+def test_backward_of_a_single_gaussian_closed_form():
+    """One isotropic Gaussian on the optical axis, dL_dout = 1 on one channel: the colour gradient is the sum of
+    alpha over the pixels, the opacity gradient the sum of G * c (no transmittance in front, nothing behind)."""
+    import torch
+    from helpers import single_gaussian_scene
+    from gsrast_amd import camera
+    from gsrast_amd.rasterizer import SplatRasterizer
+    scene = single_gaussian_scene(pos=(0.0, 0.0, 0.0), scale=0.2, opacity=0.6, dc=(1.0, 0.0, 0.0), n=2)
+    scene["means3D"][1, :3] = (0.0, 0.0, -50.0)          # second one behind the camera: culled, zero gradients
+    cam = camera.default_camera(64, 64)
+    r = SplatRasterizer(64, 64)
+    r.configure_from_scene(scene)
+    r.draw(cam)
+    st = r.map_geometry_state()
+    m, co, col = st["means2D"][0].cpu().numpy(), st["conicOpacity"][0].cpu().numpy(), st["rgb"][0].cpu().numpy()
+    dL = torch.zeros((3, 64, 64)); dL[0] = 1.0
+    got = {k: v.cpu().numpy() for k, v in r.backward(dL).items()}
+    ys, xs = np.mgrid[0:64, 0:64].astype(np.float64)
+    dx, dy = m[0] - xs, m[1] - ys
+    power = -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy
+    G = np.exp(power)
+    alpha = np.minimum(0.99, co[3] * G)
+    live = (power <= 0) & (alpha >= 1.0 / 255.0)
+    assert abs(got["dL_dcolors"][0, 0] - (alpha * live).sum()) <= 1e-4 * (alpha * live).sum()
+    exp_op = (G * col[0] * live).sum()
+    assert abs(got["dL_dconic_opacity"][0, 3] - exp_op) <= 1e-4 * exp_op
+    assert abs(got["dL_dmean2D"][0]).max() <= 1e-3 * exp_op     # symmetric footprint around an integer-aligned centre
+    for k in ("dL_dmean2D", "dL_dconic_opacity", "dL_dcolors", "dL_dcov3D"):
+        assert (got[k][1] == 0).all()
+
+
+def test_backward_rejects_bad_arguments():
+    import ctypes as C
+    from gsrast_amd import _capi
+    L = _capi.lib()
+    a = _capi.BackwardArgs()
+    a.struct_size = C.sizeof(_capi.BackwardArgs) - 4
+    assert L.gsr_backward(C.byref(a)) == _capi.GSR_ERR_INVALID_ARG
+    a.struct_size = C.sizeof(_capi.BackwardArgs)
+    assert L.gsr_backward(C.byref(a)) == _capi.GSR_ERR_INVALID_ARG and L.gsr_last_error() == _capi.GSR_ERR_INVALID_ARG
