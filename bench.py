@@ -45,6 +45,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=4, help="CPU baseline renders every k-th splat")
     p.add_argument("--no-rebalance", action="store_true")
+    p.add_argument("--backward", action="store_true",
+                   help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
     p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
     return p.parse_args()
 
@@ -130,9 +132,20 @@ def main():
     grid_x, grid_y = (W + 15) // 16, (H + 15) // 16
     exch = sharding.RowBandExchange(W, H, device) if distributed else None
 
+    dl_dout = None
+    if args.backward:
+        assert not distributed, "--backward is a single-GPU configuration"
+        dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
+    bw_ms = [0.0, 0.0]
+
     def step(profile=False):
         rows = exch.my_tile_rows() if exch else None
         frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not distributed, plan=args.plan)
+        if dl_dout is not None:
+            rast.backward(dl_dout, profile=profile)
+            if profile:
+                bw_ms[0] += rast.last_backward_ms[0]
+                bw_ms[1] += rast.last_backward_ms[1]
         if exch:
             exch.gather(frame)
             torch.cuda.current_stream(device).synchronize()
@@ -231,8 +244,11 @@ def main():
                     "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc, separate passes)" if k in traffic else None,
                     "algorithmic_bytes_per_launch": e["alg_bytes"], "avg_launch_ms": e["ms"], "note": note}
 
+        if args.backward:
+            stage_ms["render_backward"] = bw_ms[0] / args.steps
+            stage_ms["chain_backward"] = bw_ms[1] / args.steps
         out = {
-            "metric": "forward_msplats_per_s",
+            "metric": "forward_backward_msplats_per_s" if args.backward else "forward_msplats_per_s",
             "value": round(n_splats / (ms_per_step * 1e-3) / 1e6, 3),
             "unit": "Msplats/s",
             "fps": round(1e3 / ms_per_step, 2),
