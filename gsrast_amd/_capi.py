@@ -70,6 +70,10 @@ class ForwardArgs(C.Structure):
     ]
 
 
+class PointsImageState(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("out_color", C.c_void_p), ("default_depth", C.c_void_p), ("winner", C.c_void_p)]
+
+
 class BackwardArgs(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32),
@@ -97,6 +101,9 @@ SIGNATURES = {
     "gsr_required_binning": (C.c_size_t, [C.c_size_t]),
     "gsr_forward": (C.c_int, [C.POINTER(ForwardArgs)]),
     "gsr_backward": (C.c_int, [C.POINTER(BackwardArgs)]),
+    "gsr_points_image_from_chunk": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(PointsImageState)]),
+    "gsr_required_points_image": (C.c_size_t, [C.c_int]),
+    "gsr_forward_points": (C.c_int, [C.POINTER(ForwardArgs)]),
     "gsr_last_error": (C.c_int, []),
     "gsr_error_string": (C.c_char_p, [C.c_int]),
     "gsr_last_hip_error": (C.c_char_p, []),

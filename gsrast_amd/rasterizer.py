@@ -156,6 +156,40 @@ class SplatRasterizer:
             _capi.check(self.lib.gsr_poll_async_error(), "gsr_forward (device side)")
         return self.out_color
 
+    # -- point-splat path (gscuda::forwardPoints, GSCuda.cu:110-155) -----------------------------
+    def draw_points(self, cam: Camera | None = None, sync: bool = True) -> torch.Tensor:
+        """One gsr_forward_points call: every centre lands on one pixel, the nearest wins. The image chunk
+        then holds pc::ImageState (depth, temporary image); see map_points_image_state."""
+        if cam is not None:
+            self.set_camera(cam)
+        if getattr(self, "_means3", None) is None or self._means3.shape[0] != self.num_gaussians:
+            self._means3 = self.means3D[:, :3].contiguous()        # this path reads a stride of three floats
+        a = _capi.ForwardArgs()
+        a.struct_size = C.sizeof(_capi.ForwardArgs)
+        a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
+        a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, 3, 16
+        a.background = self.background.data_ptr()
+        a.width, a.height = self.width, self.height
+        a.means3D, a.shs = self._means3.data_ptr(), self.shs.data_ptr()
+        a.view_matrix, a.proj_matrix, a.cam_pos = self._view.data_ptr(), self._proj.data_ptr(), self._cam_pos.data_ptr()
+        a.tan_fovx, a.tan_fovy = self._tan
+        a.out_color = self.out_color.data_ptr()
+        a.stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.gsr_forward_points(C.byref(a))
+        _capi.check(rc, "gsr_forward_points")
+        if sync:
+            torch.cuda.current_stream(self.device).synchronize()
+        return self.out_color
+
+    def map_points_image_state(self) -> dict:
+        st = _capi.PointsImageState()
+        P = self.width * self.height
+        self.lib.gsr_points_image_from_chunk(self.image.base(), P, C.byref(st))
+        v = self.image.view
+        return {"depth": v(st.depth, P, torch.float32).view(self.height, self.width),
+                "outColor": v(st.out_color, 3 * P, torch.float32).view(3, self.height, self.width)}
+
     # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
     def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
                  tile_rows: tuple[int, int] | None = None) -> dict:

@@ -170,6 +170,69 @@ inline void forward(std::function<char*(size_t)> geometryBuffer,
     detail::last_error_slot() = gsr_forward(&a);
 }
 
+// gscuda::forwardPoints (GSCuda.cuh:19-42): same parameter list as forward; means3D has a stride of
+// three floats on this path (GSCuda.cu:65).
+inline void forwardPoints(std::function<char*(size_t)> geometryBuffer,
+                          std::function<char*(size_t)> binningBuffer,
+                          std::function<char*(size_t)> imageBuffer,
+                          int numGaussians, int shDims, int M,
+                          const float* background,
+                          int width, int height,
+                          const float* means3D,
+                          const float* shs,
+                          const float* colorsPrecomp,
+                          const float* opacities,
+                          const float* scales,
+                          float scaleModifier,
+                          const float* rotations,
+                          const float* cov3DPrecomp,
+                          const float* viewMatrix,
+                          const float* projMatrix,
+                          const float* camPos,
+                          float tanFOVx, float tanFOVy,
+                          bool prefiltered,
+                          float* outColor,
+                          int* radii,
+                          int* rects,
+                          float* boxMin,
+                          float* boxMax) {
+    gsr_forward_args a{};
+    a.struct_size = sizeof(a);
+    a.geometry_alloc = detail::trampoline; a.geometry_user = &geometryBuffer;
+    a.binning_alloc = detail::trampoline;  a.binning_user = &binningBuffer;
+    a.image_alloc = detail::trampoline;    a.image_user = &imageBuffer;
+    a.num_gaussians = numGaussians; a.sh_dims = shDims; a.M = M;
+    a.background = background;
+    a.width = width; a.height = height;
+    a.means3D = means3D; a.shs = shs; a.colors_precomp = colorsPrecomp;
+    a.opacities = opacities; a.scales = scales; a.scale_modifier = scaleModifier;
+    a.rotations = rotations; a.cov3D_precomp = cov3DPrecomp;
+    a.view_matrix = viewMatrix; a.proj_matrix = projMatrix; a.cam_pos = camPos;
+    a.tan_fovx = tanFOVx; a.tan_fovy = tanFOVy;
+    a.prefiltered = prefiltered ? 1 : 0;
+    a.out_color = outColor;
+    a.radii = radii; a.rects = rects;
+    a.box_min = boxMin; a.box_max = boxMax;
+    a.stream = nullptr;
+    detail::last_error_slot() = gsr_forward_points(&a);
+}
+
+namespace pc {
+struct GeometryState {        // empty in the reference (AuxBuffer.cuh:21-24)
+    static GeometryState fromChunk(char*&, int) { return GeometryState{}; }
+};
+struct ImageState {
+    float* depth;
+    float* outColor;
+    float* defaultDepth;
+    static ImageState fromChunk(char*& chunk, int size) {
+        gsr_points_image_state c;
+        chunk = gsr_points_image_from_chunk(chunk, size, &c);
+        return ImageState{c.depth, c.out_color, c.default_depth};
+    }
+};
+}  // namespace pc
+
 }  // namespace gscuda
 
 // The alternate spelling the reference can be switched to at compile time

@@ -233,6 +233,22 @@ typedef struct gsr_backward_args {
 } gsr_backward_args;
 int gsr_backward(gsr_backward_args* args);
 
+/* ---- point-splat path (gscuda::forwardPoints, GSCuda.cuh:19-42 / GSCuda.cu:26-155; the reference never
+ * calls it) ---- Same argument struct as gsr_forward; read: num_gaussians, width, height, background,
+ * means3D (a stride of THREE floats here, GSCuda.cu:65), shs, proj_matrix, out_color, geometry_alloc (asked for
+ * 32 bytes, as the reference does for its empty pc::GeometryState), image_alloc, stream. Every centre inside
+ * NDC [-1,1]^2 x [0,1] lands on one pixel; the nearest wins (the lowest index among equal depths — the
+ * reference's unordered colour write makes its own result timing dependent). */
+typedef struct gsr_points_image_state {   /* pc::ImageState (AuxBuffer.cuh:26-33), `size` = width*height */
+    float*    depth;           /* f32[size] NDC z of the winner, 1.0 where none   */
+    float*    out_color;       /* f32[3 size] planar temporary image              */
+    float*    default_depth;   /* f32[1] = 1.0                                    */
+    uint64_t* winner;          /* u64[size] (depth bits << 32 | index), this library's depth-test table */
+} gsr_points_image_state;
+char* gsr_points_image_from_chunk(char* chunk, int size, gsr_points_image_state* out);
+size_t gsr_required_points_image(int size);
+int gsr_forward_points(gsr_forward_args* args);
+
 /* ---- scene loading (next row after the hot path) ---- */
 /* Header of a 3DGS .ply as the reference reads it (apps/gsrast/SplatData.cpp:114-145): vertex
  * count = third token of the third line; data starts after the "end_header" line. Host only.
