@@ -86,6 +86,8 @@ class BackwardArgs(C.Structure):
         ("dL_dout_color", C.c_void_p),
         ("dL_dmean2D", C.c_void_p), ("dL_dconic_opacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
         ("dL_dcov3D", C.c_void_p), ("dL_dshs", C.c_void_p),
+        ("proj_matrix", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("scale_modifier", C.c_float),
+        ("dL_dmeans3D", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
         ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
         ("stage_ms", C.c_float * 2),
     ]

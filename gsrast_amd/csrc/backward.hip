@@ -169,12 +169,23 @@ struct PreprocessBackwardParams {
     const float* dL_dcolors;
     float* dL_dcov3D;       // f32[6 N]
     float* dL_dshs;         // f32[48 N] or null; only the DC triple of every Gaussian is written
+    // chain down to the inputs (each output optional)
+    const float* proj;
+    const float4* scales;
+    const float4* rotations;
+    float scale_modifier;
+    int width, height;
+    const float2* dL_dmean2D;
+    float4* dL_dmeans3D;    // vec4[N] (x, y, z, 0): the layout of means3D
+    float4* dL_dscales;     // vec4[N] (x, y, z, 0)
+    float4* dL_drotations;  // vec4[N], w.r.t. the quaternion as given (not normalised)
 };
 
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBackwardParams p) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.n) return;
     float out[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float gmean[3] = {0.0f, 0.0f, 0.0f};
     const bool visible = p.radii[idx] > 0;
     if (visible) {
         const float* v = p.view;
@@ -184,8 +195,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         float ty = (v[1] * mean.x + v[5] * mean.y) + (v[9] * mean.z + v[13] * 1.0f);
         const float tz = (v[2] * mean.x + v[6] * mean.y) + (v[10] * mean.z + v[14] * 1.0f);
         const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
-        tx = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
-        ty = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
+        const float rx = tx / tz, ry = ty / tz;
+        const float cx = fminf(limx, fmaxf(-limx, rx)), cy = fminf(limy, fmaxf(-limy, ry));
+        tx = cx * tz;
+        ty = cy * tz;
         // P = J W (2 x 3): cov2D = P Sigma P^T
         const float j00 = p.focal / tz, j02 = -p.focal * tx / (tz * tz), j12 = -p.focal * ty / (tz * tz);
         float P[2][3];
@@ -225,7 +238,93 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             auto gs = [&](int r, int c) { return P[0][r] * gp[0][c] + P[1][r] * gp[1][c]; };
             out[0] = gs(0, 0); out[1] = 2.0f * gs(0, 1); out[2] = 2.0f * gs(0, 2);
             out[3] = gs(1, 1); out[4] = 2.0f * gs(1, 2); out[5] = gs(2, 2);
+            if (p.dL_dmeans3D) {
+                // through the Jacobian J(t): cov2D = J Mw J^T with Mw = W Sigma W^T; gJ = 2 gcov J Mw
+                float ws[3][3], mw[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ws[r][c] = v[0 + r] * s[0][c] + v[4 + r] * s[1][c] + v[8 + r] * s[2][c];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) mw[r][c] = ws[r][0] * v[0 + c] + ws[r][1] * v[4 + c] + ws[r][2] * v[8 + c];
+                const float J[2][3] = {{j00, 0.0f, j02}, {0.0f, j00, j12}};
+                float jm[2][3], gJ[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) jm[r][c] = J[r][0] * mw[0][c] + J[r][1] * mw[1][c] + J[r][2] * mw[2][c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gJ[0][c] = 2.0f * (m00 * jm[0][c] + m01 * jm[1][c]);
+                    gJ[1][c] = 2.0f * (m01 * jm[0][c] + m11 * jm[1][c]);
+                }
+                const float f_tz2 = p.focal / (tz * tz);
+                const float g_tx = -gJ[0][2] * f_tz2, g_ty = -gJ[1][2] * f_tz2;
+                const float g_tz = -(gJ[0][0] + gJ[1][1]) * f_tz2 + (gJ[0][2] * tx + gJ[1][2] * ty) * (2.0f * p.focal / (tz * tz * tz));
+                const bool clx = rx != cx, cly = ry != cy;          // clamped: t.x (t.y) no longer moves the entry, t.z does
+                const float gt0 = clx ? 0.0f : g_tx, gt1 = cly ? 0.0f : g_ty;
+                const float gt2 = g_tz + (clx ? g_tx * cx : 0.0f) + (cly ? g_ty * cy : 0.0f);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) gmean[j] = v[4 * j + 0] * gt0 + v[4 * j + 1] * gt1 + v[4 * j + 2] * gt2;
+            }
         }
+        if (p.dL_dmeans3D) {
+            // pixel-space centre: pix = ((proj mean).x / ((proj mean).w + 0.001) * 0.5 + 0.5) * W (GSCuda.cu:302-305, :342)
+            const float* pm = p.proj;
+            const float hx = (pm[0] * mean.x + pm[4] * mean.y) + (pm[8] * mean.z + pm[12] * mean.w);
+            const float hy = (pm[1] * mean.x + pm[5] * mean.y) + (pm[9] * mean.z + pm[13] * mean.w);
+            const float wp = 0.001f + ((pm[3] * mean.x + pm[7] * mean.y) + (pm[11] * mean.z + pm[15] * mean.w));
+            const float2 g2 = p.dL_dmean2D[idx];
+            const float iw = 1.0f / wp, iw2 = iw * iw;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float dx = 0.5f * (float)p.width * (pm[4 * j + 0] * iw - hx * pm[4 * j + 3] * iw2);
+                const float dy = 0.5f * (float)p.height * (pm[4 * j + 1] * iw - hy * pm[4 * j + 3] * iw2);
+                gmean[j] += dx * g2.x + dy * g2.y;
+            }
+        }
+    }
+    if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4(gmean[0], gmean[1], gmean[2], 0.0f);
+    if (p.dL_dscales) {
+        // Sigma = M M^T, M = R diag(mod s): gM = 2 gSigma M (off-diagonal stored gradients split over both entries)
+        float gsc[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (visible) {
+            const float4 sc = p.scales[idx];
+            const float4 rot = p.rotations[idx];
+            const float nrm = sqrtf((rot.x * rot.x + rot.y * rot.y) + (rot.z * rot.z + rot.w * rot.w));
+            const float inv = 1.0f / nrm;
+            const float x = rot.x * inv, y = rot.y * inv, z = rot.z * inv, w = rot.w * inv;
+            const float R[3][3] = {{2.0f * (x * x + y * y) - 1.0f, 2.0f * (y * z - x * w), 2.0f * (y * w + x * z)},
+                                   {2.0f * (y * z + x * w), 2.0f * (x * x + z * z) - 1.0f, 2.0f * (z * w - x * y)},
+                                   {2.0f * (y * w - x * z), 2.0f * (z * w + x * y), 2.0f * (x * x + w * w) - 1.0f}};
+            const float sv[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
+            const float gS[3][3] = {{out[0], 0.5f * out[1], 0.5f * out[2]}, {0.5f * out[1], out[3], 0.5f * out[4]},
+                                    {0.5f * out[2], 0.5f * out[4], out[5]}};
+            float gM[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    gM[r][c] = 2.0f * (gS[r][0] * R[0][c] + gS[r][1] * R[1][c] + gS[r][2] * R[2][c]) * sv[c];
+            float gR[3][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                gsc[c] = p.scale_modifier * (R[0][c] * gM[0][c] + R[1][c] * gM[1][c] + R[2][c] * gM[2][c]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gR[r][c] = gM[r][c] * sv[c];
+            }
+            // dR/dq for the normalised quaternion (x = real part), then through the normalisation
+            const float gx = 4.0f * x * (gR[0][0] + gR[1][1] + gR[2][2]) + 2.0f * (w * (gR[1][0] - gR[0][1]) + z * (gR[0][2] - gR[2][0]) + y * (gR[2][1] - gR[1][2]));
+            const float gy = 4.0f * y * gR[0][0] + 2.0f * (z * (gR[0][1] + gR[1][0]) + w * (gR[0][2] + gR[2][0]) + x * (gR[2][1] - gR[1][2]));
+            const float gz = 4.0f * z * gR[1][1] + 2.0f * (y * (gR[0][1] + gR[1][0]) + w * (gR[1][2] + gR[2][1]) + x * (gR[0][2] - gR[2][0]));
+            const float gw = 4.0f * w * gR[2][2] + 2.0f * (y * (gR[0][2] + gR[2][0]) + z * (gR[1][2] + gR[2][1]) + x * (gR[1][0] - gR[0][1]));
+            const float dot = x * gx + y * gy + z * gz + w * gw;
+            gq[0] = (gx - x * dot) * inv; gq[1] = (gy - y * dot) * inv; gq[2] = (gz - z * dot) * inv; gq[3] = (gw - w * dot) * inv;
+        }
+        p.dL_dscales[idx] = make_float4(gsc[0], gsc[1], gsc[2], 0.0f);
+        if (p.dL_drotations) p.dL_drotations[idx] = make_float4(gq[0], gq[1], gq[2], gq[3]);
     }
     float2* dst = reinterpret_cast<float2*>(p.dL_dcov3D + 6 * (size_t)idx);
     dst[0] = make_float2(out[0], out[1]);
@@ -256,6 +355,9 @@ static int backward_impl(gsr_backward_args* a) {
         !a->dL_dconic_opacity || !a->dL_dcolors)
         return GSR_ERR_INVALID_ARG;
     if (a->dL_dcov3D && (!a->cov3D || !a->means3D || !a->view_matrix || !a->radii)) return GSR_ERR_INVALID_ARG;
+    if ((a->dL_dmeans3D || a->dL_dscales || a->dL_drotations) && !a->dL_dcov3D) return GSR_ERR_INVALID_ARG;
+    if (a->dL_dmeans3D && !a->proj_matrix) return GSR_ERR_INVALID_ARG;
+    if ((a->dL_dscales || a->dL_drotations) && (!a->scales || !a->rotations || !a->dL_dscales)) return GSR_ERR_INVALID_ARG;
     if (a->flags & GSR_FLAG_SEMANTICS_INRIA) return GSR_ERR_INVALID_ARG;      // gscuda semantics only
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
@@ -307,6 +409,15 @@ static int backward_impl(gsr_backward_args* a) {
         q.dL_dcolors = a->dL_dcolors;
         q.dL_dcov3D = a->dL_dcov3D;
         q.dL_dshs = a->dL_dshs;
+        q.proj = a->proj_matrix;
+        q.scales = reinterpret_cast<const float4*>(a->scales);
+        q.rotations = reinterpret_cast<const float4*>(a->rotations);
+        q.scale_modifier = a->scale_modifier;
+        q.width = a->width; q.height = a->height;
+        q.dL_dmean2D = reinterpret_cast<const float2*>(a->dL_dmean2D);
+        q.dL_dmeans3D = reinterpret_cast<float4*>(a->dL_dmeans3D);
+        q.dL_dscales = reinterpret_cast<float4*>(a->dL_dscales);
+        q.dL_drotations = reinterpret_cast<float4*>(a->dL_drotations);
         hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
         GSR_LAUNCH_CHECK("preprocess_backward_kernel");
     }

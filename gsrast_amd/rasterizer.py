@@ -192,10 +192,10 @@ class SplatRasterizer:
 
     # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
     def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
-                 tile_rows: tuple[int, int] | None = None) -> dict:
+                 tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0) -> dict:
         """Gradients of sum(dL_dout * out_color) of the LAST draw() (gscuda semantics) through gsr_backward.
         Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3] and, with
-        with_cov3D, dL_dcov3D [N,6] and dL_dshs [N,48] (DC triple only)."""
+        with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (DC triple only), dL_dmeans3D / dL_dscales / dL_drotations [N,4]."""
         n, dev = self.num_gaussians, self.device
         g = dL_dout.to(device=dev, dtype=torch.float32).contiguous()
         assert g.shape == (3, self.height, self.width)
@@ -209,6 +209,8 @@ class SplatRasterizer:
         if with_cov3D:
             out["dL_dcov3D"] = torch.empty((n, 6), dtype=torch.float32, device=dev)
             out["dL_dshs"] = torch.zeros((n, 48), dtype=torch.float32, device=dev)
+            for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
+                out[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
         a = _capi.BackwardArgs()
         a.struct_size = C.sizeof(_capi.BackwardArgs)
         a.flags = _capi.GSR_FLAG_PROFILE if profile else 0
@@ -225,6 +227,11 @@ class SplatRasterizer:
         a.dL_dcolors = out["dL_dcolors"].data_ptr()
         a.dL_dcov3D = out["dL_dcov3D"].data_ptr() if with_cov3D else None
         a.dL_dshs = out["dL_dshs"].data_ptr() if with_cov3D else None
+        if with_cov3D:
+            a.proj_matrix, a.scales, a.rotations = self._proj.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr()
+            a.scale_modifier = scale_modifier
+            a.dL_dmeans3D, a.dL_dscales = out["dL_dmeans3D"].data_ptr(), out["dL_dscales"].data_ptr()
+            a.dL_drotations = out["dL_drotations"].data_ptr()
         a.stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_rows is not None:
             a.tile_row_begin, a.tile_row_end = int(tile_rows[0]), int(tile_rows[1])

@@ -198,6 +198,9 @@ int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const ui
  *   dL_dcolors        vec3[N]
  *   dL_dcov3D         f32[6N]  w.r.t. the six stored covariance numbers (optional: NULL skips the chain)
  *   dL_dshs           f32[48N] only the DC triple of every Gaussian is written (colour = 0.5 + 0.4 DC); optional
+ *   dL_dmeans3D       vec4[N]  (x, y, z, 0) through the pixel-space centre and through the Jacobian of cov2D; optional
+ *   dL_dscales        vec4[N]  (x, y, z, 0);  dL_drotations vec4[N] w.r.t. the quaternion as given; optional
+ *                              (both need dL_dcov3D; not available when the forward call took cov3D_precomp)
  * Hard tests of the forward (power > 0, alpha < 1/255, transmittance cut-off) select a branch; where
  * alpha is clamped to 0.99 its derivative w.r.t. the Gaussian's parameters is zero. The state pointers are
  * those of the forward call's chunks (gsr_*_from_chunk): it must have run on the same inputs, same size. */
@@ -227,6 +230,14 @@ typedef struct gsr_backward_args {
     float* dL_dcolors;
     float* dL_dcov3D;              /* or NULL */
     float* dL_dshs;                /* or NULL */
+    /* chain down to the inputs (all optional; need dL_dcov3D) */
+    const float* proj_matrix;      /* inputs of the forward call */
+    const float* scales;
+    const float* rotations;
+    float scale_modifier;
+    float* dL_dmeans3D;            /* or NULL */
+    float* dL_dscales;             /* or NULL */
+    float* dL_drotations;          /* or NULL (needs dL_dscales) */
     void* stream;
     int32_t tile_row_begin, tile_row_end;   /* as gsr_forward: the rows the forward call processed */
     float stage_ms[2];             /* with GSR_FLAG_PROFILE: render backward, covariance / colour chain */

@@ -169,3 +169,93 @@ def finite_difference(f, x, eps):
         flat[i] = old
         gf[i] = (hi - lo) / (2.0 * eps)
     return g
+
+
+# ---- the per-Gaussian chain down to the inputs: means3D, scales, rotations ---------------------------
+# Forward functions restated in float64 from the reference (and from csrc/preprocess.hip, which keeps
+# its operation order): projection to the pixel-space centre GSCuda.cu:302-305, :342; quatToMat
+# :157-162; computeCov3D :168-195; computeCov2D :197-231.
+def project_mean2d(mean3, proj, width, height):
+    p = np.asarray(proj, np.float64)
+    hx = p[0] * mean3[0] + p[4] * mean3[1] + p[8] * mean3[2] + p[12]
+    hy = p[1] * mean3[0] + p[5] * mean3[1] + p[9] * mean3[2] + p[13]
+    hw = p[3] * mean3[0] + p[7] * mean3[1] + p[11] * mean3[2] + p[15]
+    ow = 1.0 / (0.001 + hw)
+    return np.array([(hx * ow * 0.5 + 0.5) * width, (hy * ow * 0.5 + 0.5) * height])
+
+
+def project_mean2d_backward(mean3, proj, width, height, g2):
+    p = np.asarray(proj, np.float64)
+    hx = p[0] * mean3[0] + p[4] * mean3[1] + p[8] * mean3[2] + p[12]
+    hy = p[1] * mean3[0] + p[5] * mean3[1] + p[9] * mean3[2] + p[13]
+    wp = 0.001 + (p[3] * mean3[0] + p[7] * mean3[1] + p[11] * mean3[2] + p[15])
+    g = np.zeros(3)
+    for j in range(3):
+        dx = 0.5 * width * (p[4 * j + 0] / wp - hx * p[4 * j + 3] / (wp * wp))
+        dy = 0.5 * height * (p[4 * j + 1] / wp - hy * p[4 * j + 3] / (wp * wp))
+        g[j] = dx * g2[0] + dy * g2[1]
+    return g
+
+
+def quat_to_mat(q):
+    """Rotation matrix (math rows / columns) of the normalised quaternion, real part first (GSCuda.cu:157-162)."""
+    x, y, z, w = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([[2 * (x * x + y * y) - 1, 2 * (y * z - x * w), 2 * (y * w + x * z)],
+                     [2 * (y * z + x * w), 2 * (x * x + z * z) - 1, 2 * (z * w - x * y)],
+                     [2 * (y * w - x * z), 2 * (z * w + x * y), 2 * (x * x + w * w) - 1]])
+
+
+def cov3d(scale, rot, mod=1.0):
+    m = quat_to_mat(rot) @ np.diag(mod * np.asarray(scale, np.float64)[:3])
+    s = m @ m.T
+    return np.array([s[0, 0], s[0, 1], s[0, 2], s[1, 1], s[1, 2], s[2, 2]])
+
+
+def cov3d_backward(scale, rot, mod, g6):
+    """dL/dscale[3], dL/drot[4] (w.r.t. the un-normalised quaternion) from dL/d(6 covariance numbers)."""
+    q = np.asarray(rot, np.float64)
+    n = np.linalg.norm(q)
+    x, y, z, w = q / n
+    R = quat_to_mat(rot)
+    s = mod * np.asarray(scale, np.float64)[:3]
+    M = R @ np.diag(s)
+    gS = np.array([[g6[0], 0.5 * g6[1], 0.5 * g6[2]], [0.5 * g6[1], g6[3], 0.5 * g6[4]], [0.5 * g6[2], 0.5 * g6[4], g6[5]]])
+    gM = 2.0 * gS @ M
+    g_scale = mod * (R * gM).sum(0)
+    gR = gM * s[None, :]
+    dR = {"x": np.array([[4 * x, -2 * w, 2 * z], [2 * w, 4 * x, -2 * y], [-2 * z, 2 * y, 4 * x]]),
+          "y": np.array([[4 * y, 2 * z, 2 * w], [2 * z, 0, -2 * x], [2 * w, 2 * x, 0]]),
+          "z": np.array([[0, 2 * y, 2 * x], [2 * y, 4 * z, 2 * w], [-2 * x, 2 * w, 0]]),
+          "w": np.array([[0, -2 * x, 2 * y], [2 * x, 0, 2 * z], [2 * y, 2 * z, 4 * w]])}
+    gq_hat = np.array([(gR * dR[k]).sum() for k in "xyzw"])
+    qh = q / n
+    return g_scale, (gq_hat - qh * (qh @ gq_hat)) / n
+
+
+def conic_backward_mean(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic):
+    """dL/dmean3 through the dependence of cov2D on the view-space position t (the Jacobian J)."""
+    v = np.asarray(view, np.float64)
+    t = np.array([v[0] * mean3[0] + v[4] * mean3[1] + v[8] * mean3[2] + v[12],
+                  v[1] * mean3[0] + v[5] * mean3[1] + v[9] * mean3[2] + v[13],
+                  v[2] * mean3[0] + v[6] * mean3[1] + v[10] * mean3[2] + v[14]])
+    limx, limy = 1.3 * tan_fovx, 1.3 * tan_fovy
+    rx, ry = t[0] / t[2], t[1] / t[2]
+    cx, cy = min(limx, max(-limx, rx)), min(limy, max(-limy, ry))
+    tx, ty, tz = cx * t[2], cy * t[2], t[2]
+    J = np.array([[focal / tz, 0.0, -focal * tx / (tz * tz)], [0.0, focal / tz, -focal * ty / (tz * tz)]])
+    W = np.array([[v[0], v[4], v[8]], [v[1], v[5], v[9]], [v[2], v[6], v[10]]])
+    Mw = W @ _sigma(c3) @ W.T
+    cov = J @ Mw @ J.T
+    a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+    det = a * c - b * b
+    K = np.array([[c, -b], [-b, a]]) / det
+    gA, gB, gC = dL_dconic
+    gcov = -K @ np.array([[gA, 0.5 * gB], [0.5 * gB, gC]]) @ K
+    gJ = 2.0 * gcov @ J @ Mw
+    g_tx = gJ[0, 2] * (-focal / (tz * tz))
+    g_ty = gJ[1, 2] * (-focal / (tz * tz))
+    g_tz = (gJ[0, 0] + gJ[1, 1]) * (-focal / (tz * tz)) + (gJ[0, 2] * tx + gJ[1, 2] * ty) * (2.0 * focal / (tz ** 3))
+    clamped_x, clamped_y = rx != cx, ry != cy
+    gt = np.array([0.0 if clamped_x else g_tx, 0.0 if clamped_y else g_ty,
+                   g_tz + (g_tx * cx if clamped_x else 0.0) + (g_ty * cy if clamped_y else 0.0)])
+    return W.T @ gt

@@ -74,3 +74,29 @@ def test_cov3d_to_conic_gradient_matches_finite_differences():
         fd = B.finite_difference(f, c3, 1e-7)
         an = B.conic_backward(c3, mean3, cam.view, focal, cam.tan_fovx, cam.tan_fovy, gk)
         assert np.abs(an - fd).max() <= 1e-5 * max(1.0, np.abs(fd).max()), (an, fd)
+
+
+def test_input_chain_gradients_match_finite_differences():
+    """means3D -> pixel centre, (scale, rotation) -> cov3D, means3D -> conic (through the Jacobian)."""
+    rng = np.random.default_rng(11)
+    from gsrast_amd import camera
+    cam = camera.default_camera(640, 480)
+    focal = 480 / (2.0 * cam.tan_fovy)
+    for trial in range(8):
+        mean3 = rng.uniform(-1.5, 1.5, 3)
+        if trial >= 6:
+            mean3 = np.array([9.0, -7.0, 0.5])            # far off axis: t.x / t.z and t.y / t.z are clamped
+        scale, rot = np.exp(rng.uniform(-3, -1, 3)), rng.normal(size=4)
+        g2, g6, gk = rng.normal(size=2), rng.normal(size=6), rng.normal(size=3)
+        fd = B.finite_difference(lambda m: float(B.project_mean2d(m, cam.proj, 640, 480) @ g2), mean3, 1e-6)
+        an = B.project_mean2d_backward(mean3, cam.proj, 640, 480, g2)
+        assert np.abs(an - fd).max() <= 1e-6 * max(1.0, np.abs(fd).max())
+        f = lambda s, r: float(B.cov3d(s, r, 1.3) @ g6)
+        gs, gr = B.cov3d_backward(scale, rot, 1.3, g6)
+        assert np.abs(gs - B.finite_difference(lambda s: f(s, rot), scale, 1e-7)).max() <= 1e-6 * max(1.0, np.abs(gs).max())
+        assert np.abs(gr - B.finite_difference(lambda r: f(scale, r), rot, 1e-7)).max() <= 1e-6 * max(1.0, np.abs(gr).max())
+        c3 = B.cov3d(scale, rot)
+        fdm = B.finite_difference(lambda m: float(B.cov2d_conic(c3, m, cam.view, focal, cam.tan_fovx, cam.tan_fovy) @ gk),
+                                  mean3, 1e-6)
+        anm = B.conic_backward_mean(c3, mean3, cam.view, focal, cam.tan_fovx, cam.tan_fovy, gk)
+        assert np.abs(anm - fdm).max() <= 2e-5 * max(1.0, np.abs(fdm).max()), (trial, anm, fdm)
