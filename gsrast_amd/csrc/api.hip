@@ -43,7 +43,8 @@ struct GeoScratch {
     uint32_t* rect_idx;       // u32[N] packed band-clipped rectangle in index order (written by preprocess)
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
-    SweepScratch sweep;       // onesweep status words for the N-sized sort
+    SweepScratch sweep;       // onesweep status words for the N-sized sort: pass 0 (+ error word, digit histograms)
+    SweepScratch sweep_more[3];   // passes 1-3: their own look-back words, so one clear up front covers all four
     char* emit_scratch;       // column-major emission: [chunk][column] table, block partials, column starts
     char* block_scratch;      // block binning: [chunk][block] table, partials, block meta, tile counts / starts
     size_t bytes;
@@ -59,6 +60,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
+    for (auto& sw : g.sweep_more) { sw = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n); }
     g.emit_scratch = base + off; off += align128(emit_scratch_bytes(n));
     g.block_scratch = base + off; off += align128(blockbin_geo_bytes(n));
     g.bytes = off;
@@ -292,8 +294,13 @@ int gsr_forward(gsr_forward_args* a) {
     // half is the same for every key of a Gaussian, so those digit passes run once per
     // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
     GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
-    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.error_word, 0, sizeof(uint32_t), stream));
-    GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, gs.sweep, stream));
+    // one clear for the four passes' look-back words, tickets, the error word and the digit histograms
+    // (the four scratch areas are adjacent in the chunk)
+    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, 4 * sweep_scratch_bytes((size_t)n), stream));
+    {
+        const SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
+        GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, stream));
+    }
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     const uint32_t R = *g_rb.host;
     a->num_rendered = R;

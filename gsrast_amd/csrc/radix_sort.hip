@@ -523,10 +523,13 @@ int histogram_bits_u64(const uint64_t* keys, size_t n, int begin_bit, int end_bi
 // ---- depth order: stable sort of N u32 keys carrying their own index ---------------------
 // in -> a -> b -> a -> b : the result (sorted keys, original indices) is in (b_k, b_v).
 int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                         const SweepScratch& sc, hipStream_t stream, bool hist_ready) {
+                         const SweepScratch* sc4, hipStream_t stream) {
     if (n == 0) return GSR_OK;
-    int rc = hist_ready ? GSR_OK : histogram_bits_u32(keys_in, n, 0, 32, sc.hist, stream);
-    if (rc != GSR_OK) return rc;
+    // digit counts of all four passes from one read of the keys (the histogram area is already zero)
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + kSortTile - 1) / kSortTile, 2048);
+    hipLaunchKernelGGL((histogram_bits_kernel<uint32_t>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, stream, keys_in, (size_t)n, 4,
+                       0, 32, sc4[0].hist);
+    GSR_LAUNCH_CHECK("histogram_bits_kernel");
     const uint32_t* src_k = keys_in;
     const uint32_t* src_v = nullptr;
     for (int p = 0; p < 4; ++p) {
@@ -534,7 +537,9 @@ int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uin
         uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
         DigitSpec spec;
         spec.mode = kDigitBits; spec.shift = 8 * p; spec.nbins = 256; spec.grid_x = 1; spec.inv_grid_x = 1.0f;
-        rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc.hist + 256 * p, sc, stream);
+        SweepScratch sc = sc4[p];
+        sc.error_word = sc4[0].error_word;
+        const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true);
         if (rc != GSR_OK) return rc;
         src_k = dst_k;
         src_v = dst_v;

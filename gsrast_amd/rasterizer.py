@@ -81,9 +81,11 @@ class SplatRasterizer:
         self.last_records_staged = 0
         self.last_plan = "none"
         self.last_stage_ms: dict[str, float] = {}
-        self._view = torch.zeros(16, dtype=torch.float32, device=self.device)
-        self._proj = torch.zeros(16, dtype=torch.float32, device=self.device)
-        self._cam_pos = torch.zeros(3, dtype=torch.float32, device=self.device)
+        # view (16) | proj (16) | cam_pos (3): one device buffer, uploaded with one async copy from pinned memory
+        self._cam_dev = torch.zeros(35, dtype=torch.float32, device=self.device)
+        self._cam_host = torch.zeros(35, dtype=torch.float32).pin_memory()
+        self._view, self._proj, self._cam_pos = self._cam_dev[0:16], self._cam_dev[16:32], self._cam_dev[32:35]
+        self._last_cam = None
 
     # -- scene upload -----------------------------------------------------------------
     def configure_from_scene(self, scene: dict, use_rects: bool = True) -> None:
@@ -100,11 +102,18 @@ class SplatRasterizer:
                       if use_rects else None)
 
     def set_camera(self, cam: Camera) -> None:
+        """Uploads the 35 camera floats (the reference's caller copies view / proj per frame,
+        GSGaussians.cpp:157-176). The same Camera object again is not re-uploaded."""
         assert cam.width == self.width and cam.height == self.height
-        self._view.copy_(torch.from_numpy(np.ascontiguousarray(cam.view, np.float32)))
-        self._proj.copy_(torch.from_numpy(np.ascontiguousarray(cam.proj, np.float32)))
-        self._cam_pos.copy_(torch.from_numpy(np.ascontiguousarray(cam.cam_pos, np.float32)))
+        if cam is self._last_cam:
+            return
+        h = self._cam_host.numpy()
+        h[0:16] = np.asarray(cam.view, np.float32).reshape(16)
+        h[16:32] = np.asarray(cam.proj, np.float32).reshape(16)
+        h[32:35] = np.asarray(cam.cam_pos, np.float32).reshape(3)
+        self._cam_dev.copy_(self._cam_host, non_blocking=True)     # stream-ordered before the next forward call
         self._tan = (float(cam.tan_fovx), float(cam.tan_fovy))
+        self._last_cam = cam
 
     # -- one frame --------------------------------------------------------------------
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
