@@ -246,3 +246,45 @@ def test_sort_matches_stable_argsort():
             assert np.array_equal(v2.cpu().numpy().view(np.uint32), vals[o2]), (n, bits, "tile half")
         assert np.array_equal(ko.cpu().numpy().view(np.uint64), keys[order]), (n, bits)
         assert np.array_equal(vo.cpu().numpy().view(np.uint32), vals[order]), (n, bits)
+
+
+def test_block_lists_longer_than_one_unit_with_ties_everywhere():
+    """6000 coincident Gaussians over a 3 x 3-tile footprint straddling four 8 x 8-tile blocks: every block list
+    has several 2048-entry units, every key of a tile is equal — the order inside a tile must still be the
+    ascending Gaussian index, across unit and batch boundaries."""
+    from gsrast_amd import camera
+    from oracle import cpu_oracle
+    n = 6000
+    scene = single_gaussian_scene(pos=(0.02, -0.03, 0.0), scale=0.035, opacity=0.02, n=n)
+    scene["shs"][:, 1] = np.linspace(-1, 1, n)
+    cam = camera.default_camera(256, 256)          # 16 x 16 tiles = 2 x 2 blocks, the splat sits on their corner
+    exp = cpu_oracle.forward(scene, cam)
+    tiles = np.unique(exp["keys"] >> np.uint64(32))
+    assert len(tiles) >= 4 and len({(int(t) % 16) // 8 + 2 * ((int(t) // 16) // 8) for t in tiles}) == 4
+    r, img = _run(scene, cam)
+    _compare_all(r, img, exp, n)
+    v = r.map_binning_state()["values"].cpu().numpy()
+    k = r.map_binning_state()["keys"].cpu().numpy()
+    same = k[1:] == k[:-1]
+    assert same.sum() >= n and bool((v[1:][same] > v[:-1][same]).all())
+
+
+def test_one_splat_over_every_block_and_many_small_ones():
+    """A Gaussian whose rectangle covers the whole 40 x 23-tile grid (15 blocks, partial ones at the right and
+    bottom edge) among small ones; band-limited call included."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.garden_like_scene(3000, seed=21)
+    scene["means3D"][:, :3] *= 0.25
+    scene["means3D"][0, :3] = (0.0, 0.0, -2.0)
+    scene["scales"][0, :3] = 3.0
+    cam = camera.default_camera(640, 360, near=0.05, far=50.0)
+    exp = cpu_oracle.forward(scene, cam, (0.3, 0.3, 0.3))
+    assert exp["tilesTouched"][0] == 40 * 23
+    r, img = _run(scene, cam, (0.3, 0.3, 0.3))
+    _compare_all(r, img, exp, 3000)
+    full = img.copy()
+    r.out_color.fill_(-1.0)
+    for rows in ((0, 7), (7, 8), (8, 23)):
+        r.draw(cam, tile_rows=rows, plan=PLAN)
+    assert np.array_equal(r.out_color.cpu().numpy(), full)
