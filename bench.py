@@ -181,11 +181,20 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
+    # every stage cost a few tens of microseconds per frame, which the timed frames do not pay).
+    prof_steps = max(5, min(args.steps, 20))
+    bw_ms[0] = bw_ms[1] = 0.0
+    t1 = time.perf_counter()
+    for _ in range(prof_steps):
         step(profile=True)
         for k, v in rast.last_stage_ms.items():
             stage_sum[k] = stage_sum.get(k, 0.0) + v
     sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed_profiled = time.perf_counter() - t1
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +207,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+        stage_ms = {k: v / prof_steps for k, v in stage_sum.items()}
         # ALGORITHMIC bytes per launch on THIS rank (SURVEY.md §8d / BASELINE.md §2). N splats,
         # V visible, R instances, R_f records staged by the blend, P pixels, T tiles of this rank.
         rows = exch.my_tile_rows() if exch else (0, grid_y)
@@ -245,8 +254,8 @@ def main():
                     "algorithmic_bytes_per_launch": e["alg_bytes"], "avg_launch_ms": e["ms"], "note": note}
 
         if args.backward:
-            stage_ms["render_backward"] = bw_ms[0] / args.steps
-            stage_ms["chain_backward"] = bw_ms[1] / args.steps
+            stage_ms["render_backward"] = bw_ms[0] / prof_steps
+            stage_ms["chain_backward"] = bw_ms[1] / prof_steps
         out = {
             "metric": "forward_backward_msplats_per_s" if args.backward else "forward_msplats_per_s",
             "value": round(n_splats / (ms_per_step * 1e-3) / 1e6, 3),
@@ -265,6 +274,9 @@ def main():
                        "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "binning_plan": plan_used,
                        "bands": exch.bounds if exch else None},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {prof_steps} "
+                                f"frames of the same workload run right after the timed region; those frames took "
+                                f"{elapsed_profiled / prof_steps * 1e3:.4f} ms each with the events in place"),
             "roofline": roof(dom, "dominant kernel of this frame; HIP-event time of the launch on its own stream"),
             "roofline_blend": roof("blend", "the kernel BASELINE.json names; VALU-bound (~100 flop/B), fraction as measured"),
             "kernels": kernels,
