@@ -41,6 +41,7 @@ struct GeoScratch {
     char* scan_temp;          // partial sums of the two prefix scans
     uint32_t* depth_key;      // u32[N] depth bits or ~0 (written by preprocess)
     uint32_t* rect_idx;       // u32[N] packed band-clipped rectangle in index order (written by preprocess)
+    uint32_t* top_digits;     // one word: distinct top-byte digits (< 255) of the depth keys
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     SweepScratch sweep;       // onesweep status words for the N-sized sort: pass 0 (+ error word, digit histograms)
@@ -55,6 +56,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.scan_temp = base + off; off += align128(scan_temp_bytes(n));
     g.depth_key = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.rect_idx = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.top_digits = reinterpret_cast<uint32_t*>(base + off); off += 128;
     g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
@@ -285,11 +287,6 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
                                    gs.scan_temp, stream));
     GSR_END(GSR_STAGE_SCAN);
-    // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits
-    // for the copy only (an event), and the per-Gaussian depth sort — which does not depend on R — is
-    // queued first, so the device keeps working during the host round trip.
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
     // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
@@ -297,11 +294,24 @@ int gsr_forward(gsr_forward_args* a) {
     // one clear for the four passes' look-back words, tickets, the error word and the digit histograms
     // (the four scratch areas are adjacent in the chunk)
     GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, 4 * sweep_scratch_bytes((size_t)n), stream));
-    {
-        const SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
-        GSR_STEP(launch_sort_u32_iota(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, stream));
-    }
+    const SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
+    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, four, gs.top_digits, stream));
+    // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits
+    // for the two copies only (an event); the first three depth passes — which do not depend on R — are
+    // queued first, so the device keeps working during the host round trip. The second word says
+    // whether the fourth pass is needed: depth keys are float bits, and when every visible Gaussian
+    // has the same top byte (NDC z in [0.5, 1), the usual case) that pass would move nothing.
+    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.top_digits, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
+    GSR_STEP(sort_u32_passes(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
+    const bool four_passes = g_rb.host[3] > 1u;
+    if (four_passes) GSR_STEP(sort_u32_passes(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream));
+    // depth-sorted keys / indices, and the other pair of buffers (free from here on)
+    uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k;
+    uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v;
+    uint32_t* const spare_k = four_passes ? gs.a_k : gs.b_k;
     const uint32_t R = *g_rb.host;
     a->num_rendered = R;
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
@@ -336,7 +346,7 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
-        GSR_STEP(launch_block_binning(n, gs.b_k, gs.b_v, gs.rect_idx, d.grid_x, d.grid_y, R, gs.a_k, gs.block_scratch,
+        GSR_STEP(launch_block_binning(n, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, R, spare_k, gs.block_scratch,
                                       bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, bin.keys, bin.values, stream,
                                       profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
                                       profile ? g_rb.ev[2 * GSR_STAGE_SORT_PASS1 + 1] : nullptr));
@@ -350,13 +360,13 @@ int gsr_forward(gsr_forward_args* a) {
         }
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
-        uint32_t* rect_packed = gs.a_k;
+        uint32_t* rect_packed = spare_k;
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_y, stream));
         // one pass: with a single tile row the column-major list is already the sorted list
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
         uint32_t* emit_v = d.grid_y > 1 ? bin.values_unsorted : bin.values;
         // the depth-order stage ends and the emission stage starts at an event inside the launcher
-        GSR_STEP(launch_emit_columns(n, gs.b_k, gs.b_v, gs.rect_idx, d.grid_x, d.grid_y, rect_packed, gs.emit_scratch, hist_y,
+        GSR_STEP(launch_emit_columns(n, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, rect_packed, gs.emit_scratch, hist_y,
                                      emit_k, emit_v, stream, profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
                                      profile ? g_rb.ev[2 * GSR_STAGE_DUPLICATE] : nullptr));   // :787
         if (profile) {
@@ -377,11 +387,11 @@ int gsr_forward(gsr_forward_args* a) {
             GSR_HIP_TRY(hipMemcpyAsync(bin.values_unsorted, bin.values, 4 * (size_t)R, hipMemcpyDeviceToDevice, stream));
         }
     } else {
-        GSR_STEP(launch_gather_counts(n, gs.b_k, gs.b_v, geom.tiles_touched, gs.a_k, stream));
-        GSR_STEP(launch_inclusive_scan(gs.a_k, gs.a_k, (size_t)n, gs.scan_temp, stream));
+        GSR_STEP(launch_gather_counts(n, sorted_k, sorted_v, geom.tiles_touched, spare_k, stream));
+        GSR_STEP(launch_inclusive_scan(spare_k, spare_k, (size_t)n, gs.scan_temp, stream));
         GSR_END(GSR_STAGE_DEPTH_ORDER);
         GSR_BEGIN(GSR_STAGE_DUPLICATE);
-        GSR_STEP(launch_duplicate(n, gs.b_k, gs.b_v, gs.a_k, geom, radii, rects_in, d, bin.keys_unsorted,
+        GSR_STEP(launch_duplicate(n, sorted_k, sorted_v, spare_k, geom, radii, rects_in, d, bin.keys_unsorted,
                                   bin.values_unsorted, nullptr, nullptr, stream));         // :787
         GSR_END(GSR_STAGE_DUPLICATE);
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791

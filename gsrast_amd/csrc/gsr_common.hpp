@@ -60,10 +60,11 @@ int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_
                       uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream);
 size_t sort_temp_bytes(size_t n);
 struct SweepScratch;
-// sc4: one scratch area per pass, already zeroed by the caller (look-back words, tickets, error word, histograms);
-// the error word and the digit histograms live in sc4[0].
-int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                         const SweepScratch* sc4, hipStream_t stream);
+// Depth order (radix_sort.hip). sc4: one scratch area per pass, already zeroed by the caller (look-back words,
+// tickets, error word, histograms); the error word and the digit histograms live in sc4[0].
+int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, const SweepScratch* sc4, uint32_t* top_digits, hipStream_t stream);
+int sort_u32_passes(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
+                    const SweepScratch* sc4, int first, int last, hipStream_t stream);
 
 // Column-major emission (emit.hip): count, column scan and emission. The two events (may be null)
 // are recorded between the N-sized preparation and the emission kernel, for stage timing.

@@ -522,17 +522,36 @@ int histogram_bits_u64(const uint64_t* keys, size_t n, int begin_bit, int end_bi
 
 // ---- depth order: stable sort of N u32 keys carrying their own index ---------------------
 // in -> a -> b -> a -> b : the result (sorted keys, original indices) is in (b_k, b_v).
-int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                         const SweepScratch* sc4, hipStream_t stream) {
+namespace {
+// How many distinct digits, other than 255, the top byte of the keys takes (one thread per digit).
+__global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __restrict__ hist_top, uint32_t* __restrict__ out) {
+    const int c = __syncthreads_count(threadIdx.x < 255 && hist_top[threadIdx.x] != 0u);
+    if (threadIdx.x == 0) *out = (uint32_t)c;
+}
+}  // namespace
+
+// Digit counts of the four passes from one read of the keys, plus (top_digits, device word) the number
+// of distinct top-byte digits below 255: with at most one, and 0xFFFFFFFF the only key whose top byte
+// is 255 (the caller's sentinel), the fourth pass would move nothing — three passes already sort the keys.
+int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, const SweepScratch* sc4, uint32_t* top_digits, hipStream_t stream) {
     if (n == 0) return GSR_OK;
-    // digit counts of all four passes from one read of the keys (the histogram area is already zero)
     const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + kSortTile - 1) / kSortTile, 2048);
     hipLaunchKernelGGL((histogram_bits_kernel<uint32_t>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, stream, keys_in, (size_t)n, 4,
                        0, 32, sc4[0].hist);
     GSR_LAUNCH_CHECK("histogram_bits_kernel");
-    const uint32_t* src_k = keys_in;
-    const uint32_t* src_v = nullptr;
-    for (int p = 0; p < 4; ++p) {
+    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, top_digits);
+    GSR_LAUNCH_CHECK("top_digit_count_kernel");
+    return GSR_OK;
+}
+
+// Passes [first, last) of the stable sort of N u32 keys carrying their own index:
+// in -> a -> b -> a -> b. After P passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
+int sort_u32_passes(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
+                    const SweepScratch* sc4, int first, int last, hipStream_t stream) {
+    if (n == 0) return GSR_OK;
+    for (int p = first; p < last; ++p) {
+        const uint32_t* src_k = (p == 0) ? keys_in : ((p % 2 == 1) ? a_k : b_k);
+        const uint32_t* src_v = (p == 0) ? nullptr : ((p % 2 == 1) ? a_v : b_v);
         uint32_t* dst_k = (p % 2 == 0) ? a_k : b_k;
         uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
         DigitSpec spec;
@@ -541,8 +560,6 @@ int launch_sort_u32_iota(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uin
         sc.error_word = sc4[0].error_word;
         const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true);
         if (rc != GSR_OK) return rc;
-        src_k = dst_k;
-        src_v = dst_v;
     }
     return GSR_OK;
 }
