@@ -90,35 +90,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     int32_t out_radius = 0;
     uint32_t out_tiles = 0, out_rect = 0;
 
-    // The two matrices are wave-uniform: both are read here, before any store of this kernel, so that
-    // they come in through the scalar cache (a load placed after the cov3D store cannot be proven
-    // unaliased and would be a vector load — one more memory round trip in every wave's chain).
-    float view[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) view[i] = p.view[i];
+    // The two matrices are wave-uniform: they come in through the scalar cache.
     const float4 mean = p.means3D[idx];
     const float4 ph = mat4_vec4(p.proj, mean.x, mean.y, mean.z, mean.w);
     const float one_over_w = 1.0f / (0.001f + ph.w);
     const float prx = one_over_w * ph.x, pry = one_over_w * ph.y, prz = one_over_w * ph.z;
     const bool in_frustum = !(prz < 0.0f || prz > 1.0f || prx < -1.3f || prx > 1.3f || pry < -1.3f || pry > 1.3f);
     if (in_frustum) {
-        // Everything else this Gaussian needs from HBM is requested now, in one go: its latency then
-        // overlaps instead of adding up (mean -> scale / rotation -> colour / opacity used to be
-        // three dependent round trips). The empty asm keeps the late-used values from being sunk
-        // back down to their use.
-        // (with precomputed covariances / colours the unused loads read the means instead: no branch here)
-        const float4 sc = (p.cov3D_precomp ? p.means3D : p.scales)[idx];
-        const float4 rot = (p.cov3D_precomp ? p.means3D : p.rotations)[idx];
-        const float* sh_base = p.colors_precomp ? reinterpret_cast<const float*>(p.means3D) : p.shs;
-        const float* sh = sh_base + (p.colors_precomp ? (size_t)4 : (size_t)48) * (size_t)idx;
-        float sh0 = sh[0], sh1 = sh[1], sh2 = sh[2];
-        float opacity = p.opacities[idx];
-        asm volatile("" : "+v"(sh0), "+v"(sh1), "+v"(sh2), "+v"(opacity));
         float c3[6];
         if (p.cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) c3[i] = p.cov3D_precomp[6 * (size_t)idx + i];
         } else {
+            const float4 sc = p.scales[idx];
+            const float4 rot = p.rotations[idx];
             M3 s;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -151,7 +136,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
         }
 
         // EWA projection (computeCov2D)
-        float4 t = mat4_vec4(view, mean.x, mean.y, mean.z, 1.0f);
+        float4 t = mat4_vec4(p.view, mean.x, mean.y, mean.z, 1.0f);
         const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
         const float txtz = t.x / t.z, tytz = t.y / t.z;
         t.x = fminr(limx, fmaxr(-limx, txtz)) * t.z;
@@ -164,7 +149,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) wv.m[c][r] = view[4 * r + c];
+            for (int r = 0; r < 3; ++r) wv.m[c][r] = p.view[4 * r + c];
         const M3 tm = mul3(wv, j);
         M3 vrk;
         vrk.m[0][0] = c3[0]; vrk.m[0][1] = c3[1]; vrk.m[0][2] = c3[2];
@@ -199,14 +184,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
             const uint32_t full_area = (uint32_t)(x1 - x0) * (uint32_t)(fy1 - fy0);
             if (full_area != 0) {
                 if (!p.colors_precomp) {
+                    const float* sh = p.shs + 48 * (size_t)idx;
                     float* o = p.rgb + 3 * (size_t)idx;
-                    o[0] = 0.5f + 0.4f * sh0;
-                    o[1] = 0.5f + 0.4f * sh1;
-                    o[2] = 0.5f + 0.4f * sh2;
+                    o[0] = 0.5f + 0.4f * sh[0];
+                    o[1] = 0.5f + 0.4f * sh[1];
+                    o[2] = 0.5f + 0.4f * sh[2];
                 }
                 p.depths[idx] = prz;
                 p.means2D[idx] = make_float2(pix, piy);
-                p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacity);
+                p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[idx]);
                 out_radius = (int)my_radius;
                 out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
                 if (out_tiles)
