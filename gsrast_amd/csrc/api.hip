@@ -406,11 +406,9 @@ int gsr_forward(gsr_forward_args* a) {
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     GSR_BEGIN(GSR_STAGE_BLEND);
-#ifndef GSR_EXP_NOBLEND      // timing experiments that leave the lists unwritten must not blend them
     GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                           img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
                           t_cutoff, stream));                                                        // :804-810
-#endif
     GSR_END(GSR_STAGE_BLEND);
 
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 1, gs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

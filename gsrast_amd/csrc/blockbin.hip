@@ -380,9 +380,6 @@ __device__ __forceinline__ void store_run_sparse(const uint2* run_buf, uint32_t 
                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     for (uint32_t g = a + lane; g < b; g += kWave) {
-#ifdef GSR_EXP_NOSTORE      // timing experiment only: everything but the global stores
-        if (tile != 0xFFFFFFF0u) continue;
-#endif
         const uint2 q = run_buf[g & (kRun - 1)];
         keys[g] = ((uint64_t)tile << 32) | q.x;
         values[g] = q.y;
@@ -393,9 +390,6 @@ __device__ __forceinline__ void store_run_group(const uint2* run_buf, uint32_t a
                                                 uint32_t* __restrict__ values) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint4 q = *reinterpret_cast<const uint4*>(run_buf + ((a & (kRun - 1)) + 2u * lane));
-#ifdef GSR_EXP_NOSTORE
-    if (tile != 0xFFFFFFF0u) return;
-#endif
     // streaming (nt) stores: 12 R bytes go out once and at most 1 % of them is read back by the blend
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
