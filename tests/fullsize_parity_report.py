@@ -1,7 +1,7 @@
 """One-off full-size parity run (BASELINE config 2 stand-in, 5.83 M splats, 1920x1080): the HIP
 frame against the CPU oracle on the same inputs. Takes a few minutes of host time (the oracle's
 stable sort of R keys is single-threaded), so it is a script, not a pytest case.
-Usage (GPU box): python scripts/fullsize_parity.py > gpurun_out/fullsize_parity.txt"""
+Usage (GPU box): python tests/fullsize_parity_report.py > gpurun_out/fullsize_parity.txt"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
