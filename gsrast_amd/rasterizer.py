@@ -204,7 +204,8 @@ class SplatRasterizer:
                  tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0) -> dict:
         """Gradients of sum(dL_dout * out_color) of the LAST draw() (gscuda semantics) through gsr_backward.
         Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3] and, with
-        with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (DC triple only), dL_dmeans3D / dL_dscales / dL_drotations [N,4]."""
+        with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (DC triple only), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
+        The tensors are owned by this object and overwritten by the next call."""
         n, dev = self.num_gaussians, self.device
         g = dL_dout.to(device=dev, dtype=torch.float32).contiguous()
         assert g.shape == (3, self.height, self.width)
@@ -212,14 +213,20 @@ class SplatRasterizer:
         self.lib.gsr_geometry_from_chunk(self.geom.base(), n, C.byref(gst))
         self.lib.gsr_image_from_chunk(self.image.base(), self.width * self.height, C.byref(ist))
         self.lib.gsr_binning_from_chunk(self.binning.base(), self.last_num_rendered, C.byref(bst))
-        out = {"dL_dmean2D": torch.empty((n, 2), dtype=torch.float32, device=dev),
-               "dL_dconic_opacity": torch.empty((n, 4), dtype=torch.float32, device=dev),
-               "dL_dcolors": torch.empty((n, 3), dtype=torch.float32, device=dev)}
-        if with_cov3D:
-            out["dL_dcov3D"] = torch.empty((n, 6), dtype=torch.float32, device=dev)
-            out["dL_dshs"] = torch.zeros((n, 48), dtype=torch.float32, device=dev)
-            for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
-                out[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        # output buffers are allocated once per scene and reused (dL_dshs is 48 floats per Gaussian of which
+        # only the DC triple is ever written: it is zero-filled once, not per call)
+        cache = getattr(self, "_bw_out", None)
+        if cache is None or cache["dL_dmean2D"].shape[0] != n or ("dL_dcov3D" in cache) != with_cov3D:
+            cache = {"dL_dmean2D": torch.empty((n, 2), dtype=torch.float32, device=dev),
+                     "dL_dconic_opacity": torch.empty((n, 4), dtype=torch.float32, device=dev),
+                     "dL_dcolors": torch.empty((n, 3), dtype=torch.float32, device=dev)}
+            if with_cov3D:
+                cache["dL_dcov3D"] = torch.empty((n, 6), dtype=torch.float32, device=dev)
+                cache["dL_dshs"] = torch.zeros((n, 48), dtype=torch.float32, device=dev)
+                for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
+                    cache[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
+            self._bw_out = cache
+        out = cache
         a = _capi.BackwardArgs()
         a.struct_size = C.sizeof(_capi.BackwardArgs)
         a.flags = _capi.GSR_FLAG_PROFILE if profile else 0
