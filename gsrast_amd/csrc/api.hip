@@ -347,7 +347,7 @@ int gsr_forward(gsr_forward_args* a) {
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(n, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, R, spare_k, gs.block_scratch,
-                                      bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, bin.keys, bin.values, stream,
+                                      bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, bin.keys, bin.values, img.ranges, inria, stream,
                                       profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
                                       profile ? g_rb.ev[2 * GSR_STAGE_SORT_PASS1 + 1] : nullptr));
         if (profile) {
@@ -400,9 +400,12 @@ int gsr_forward(gsr_forward_args* a) {
                                    bin.sorting_space, stream));
         GSR_END(GSR_STAGE_SORT_PASS2);
     }
-    GSR_BEGIN(GSR_STAGE_RANGES);
-    GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, inria, stream));              // :800-801
-    GSR_END(GSR_STAGE_RANGES);
+    // :800-801 — under the block plan the ranges are the tile starts it has already computed
+    if (!use_blocks) {
+        GSR_BEGIN(GSR_STAGE_RANGES);
+        GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, inria, stream));
+        GSR_END(GSR_STAGE_RANGES);
+    }
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     GSR_BEGIN(GSR_STAGE_BLEND);

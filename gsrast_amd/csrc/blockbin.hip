@@ -332,9 +332,13 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(BlockMeta meta, int n
     if (wave == 0 && tx < (uint32_t)gx && ty < (uint32_t)gy) tile_count[ty * gx + tx] = total;
 }
 
-// Exclusive prefix over the tiles in tile order (one workgroup; T <= 65 025).
+// Exclusive prefix over the tiles in tile order (one workgroup; T <= 65 025) = where every tile's list
+// starts, which is also the tile's range: [start, start + count) as identifyTileRanges leaves it
+// (GSCuda.cu:504-538) — (0, 0) for tiles without a key, and for the lone tile of an R == 1 frame unless
+// `close_single` (the upstream behaviour) is asked for.
 __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __restrict__ tile_count, uint32_t tiles,
-                                                          uint32_t* __restrict__ tile_start) {
+                                                          uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
+                                                          uint32_t r_total, bool close_single) {
     __shared__ uint32_t s_ws[16];
     const uint32_t per = (tiles + 1023) / 1024;
     const uint32_t a = min(tiles, threadIdx.x * per), z = min(tiles, a + per);
@@ -351,9 +355,12 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
     __syncthreads();
     uint32_t running = incl - s;
     for (int w = 0; w < wave; ++w) running += s_ws[w];
+    const bool closed = r_total > 1u || close_single;
     for (uint32_t t = a; t < z; ++t) {
+        const uint32_t c = tile_count[t];
         tile_start[t] = running;
-        running += tile_count[t];
+        ranges[t] = (c != 0u && closed) ? make_uint2(running, running + c) : make_uint2(0u, 0u);
+        running += c;
     }
     if (threadIdx.x == 1023) tile_start[tiles] = running;
 }
@@ -525,8 +532,8 @@ size_t blockbin_bin_bytes(size_t r) { return blockbin_cnt_bytes(r) + align128((r
 // ev_*: optional events recorded between the three groups of kernels (stage timing).
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
                          int grid_x, int grid_y, uint32_t r_total, uint32_t* rect_packed, char* geo_scratch, uint64_t* ent_rd,
-                         uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream,
-                         hipEvent_t ev_coarse_end, hipEvent_t ev_prefix_end) {
+                         uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, uint32_t* ranges,
+                         bool close_single, hipStream_t stream, hipEvent_t ev_coarse_end, hipEvent_t ev_prefix_end) {
     const int nbx = (grid_x + kBW - 1) / kBW, nby = (grid_y + kBH - 1) / kBH, nb = nbx * nby;
     const int nbp = (nb + kWave - 1) / kWave * kWave;
     const uint32_t chunks = (uint32_t)((n + kCoarse - 1) / kCoarse);
@@ -567,7 +574,8 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     GSR_HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
     hipLaunchKernelGGL(block_prefix_kernel, dim3(nb), dim3(256), 0, stream, meta, nbx, grid_x, grid_y, cnt, tile_count);
     GSR_LAUNCH_CHECK("block_prefix_kernel");
-    hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tiles, tile_start);
+    hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tiles, tile_start,
+                       reinterpret_cast<uint2*>(ranges), r_total, close_single);
     GSR_LAUNCH_CHECK("tile_start_kernel");
     if (ev_prefix_end) GSR_HIP_TRY(hipEventRecord(ev_prefix_end, stream));
 
