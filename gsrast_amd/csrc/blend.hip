@@ -13,16 +13,10 @@
 // cut for every lane) is skipped after the power evaluation by one ballot.
 #include <stdlib.h>
 
-#include "gsr_common.hpp"
+#include "blend_core.hpp"
 
 namespace gsr {
 namespace {
-
-constexpr int kBatch = 256;
-
-// exp(power) >= 1/255 needs power >= -ln(255) = -5.5413; anything below -5.56 fails the
-// alpha >= 1/255 test for every opacity <= 1 with a 1.9 % margin, far outside rounding.
-constexpr float kPowerFloor = -5.56f;
 
 struct BlendParams {
     const uint2* ranges;
@@ -39,13 +33,6 @@ struct BlendParams {
     FrameDims dims;
     int num_tiles;                 // tiles in [row_begin,row_end)
 };
-
-// Blocks b and b+8 share an XCD (and its L2). Give every XCD one contiguous run of tiles so
-// the Gaussians neighbouring tiles share are gathered through one L2.
-__device__ __forceinline__ int xcd_tile_of_block(int b, int n) {
-    const int q = n / 8, r = n % 8, x = b % 8, k = b / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
 
 __global__ __launch_bounds__(256) void blend_kernel(const BlendParams p) {
     __shared__ float2 s_xy[kBatch];
@@ -129,8 +116,6 @@ __global__ __launch_bounds__(256) void blend_kernel(const BlendParams p) {
 // a time, one per lane, in wave-private LDS: no workgroup barrier anywhere. The batch size of the
 // reference (256) only survives as the granularity of the "whole tile done" test and of the
 // staged-record count R_f, which therefore stay identical to the reference's.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     __shared__ float2 s_xy[kWave];
     __shared__ float4 s_co[kWave];
@@ -140,30 +125,19 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
-    const int px = tx * kTile + (lane & 15), py0 = ty * kTile + (lane >> 4);
-    const float fx = (float)px;
-    bool inside[4], done[4];
-    float T[4], cr[4], cg[4], cb[4];
-    uint32_t last[4];
-    f32x2 fy01, fy23;
-    fy01.x = (float)py0; fy01.y = (float)(py0 + 4); fy23.x = (float)(py0 + 8); fy23.y = (float)(py0 + 12);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        inside[k] = px < p.dims.width && (py0 + 4 * k) < p.dims.height;
-        done[k] = !inside[k];
-        T[k] = 1.0f; cr[k] = cg[k] = cb[k] = 0.0f; last[k] = 0;
-    }
+    TileLanes s;
+    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height);
     const uint2 range = p.ranges[tile];
     const uint32_t total = range.y - range.x;          // unsigned wrap as in the reference
     const uint32_t rounds256 = (total + kBatch - 1) / kBatch;
     unsigned long long staged = 0;
-    bool all_done = __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull;
+    bool all_done = tile_lanes_all_done(s);
 
     for (uint32_t b = 0; b < rounds256 && !all_done; ++b) {
         const uint32_t batch_first = b * (uint32_t)kBatch;
         const uint32_t batch_cnt = min((uint32_t)kBatch, total - batch_first);
         staged += batch_cnt;                          // the reference stages the whole batch here
-        for (uint32_t c0 = 0; c0 < batch_cnt; c0 += kWave) {
+        for (uint32_t c0 = 0; c0 < batch_cnt && !all_done; c0 += kWave) {
             const uint32_t chunk = min((uint32_t)kWave, batch_cnt - c0);
             if ((uint32_t)lane < chunk) {
                 const uint32_t id = p.point_list[range.x + batch_first + c0 + (uint32_t)lane];
@@ -173,66 +147,10 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
                 s_rgb[lane] = make_float4(c[0], c[1], c[2], 0.0f);
             }
             // wave-private LDS: the writes above and the reads below are ordered inside the wave
-            for (uint32_t j = 0; j < chunk; ++j) {
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
-                const float dx = xy.x - fx;
-                const float adx = co.x * dx;
-                const float t1 = adx * dx;
-                const float bdx = co.y * dx;
-                f32x2 gy; gy.x = xy.y; gy.y = xy.y;
-                const f32x2 dy01 = gy - fy01, dy23 = gy - fy23;
-                const f32x2 pw01 = -0.5f * (t1 + (co.z * dy01) * dy01) - bdx * dy01;
-                const f32x2 pw23 = -0.5f * (t1 + (co.z * dy23) * dy23) - bdx * dy23;
-                const float power[4] = {pw01.x, pw01.y, pw23.x, pw23.y};
-                const bool wide = co.w > 1.0f;       // wave-uniform: the floor only holds for opacity <= 1
-                bool cand[4];
-                bool any_cand = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cand[k] = !done[k] && !(power[k] > 0.0f) && (power[k] >= kPowerFloor || wide);
-                    any_cand = any_cand || cand[k];
-                }
-                if (__ballot(any_cand) == 0ull) continue;
-                const float4 col = s_rgb[j];
-                const uint32_t contributor = batch_first + c0 + j + 1u;
-                bool newly_done = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (__ballot(cand[k]) == 0ull) continue;      // nobody in this strip sees the record
-                    const float alpha = fminf(0.99f, co.w * __expf(power[k]));
-                    const bool live = cand[k] && !(alpha < 1.0f / 255.0f);
-                    const float test = T[k] * (1.0f - alpha);
-                    const bool stop = live && test < p.t_cutoff;
-                    if (live && !stop) {
-                        cr[k] += col.x * alpha * T[k];
-                        cg[k] += col.y * alpha * T[k];
-                        cb[k] += col.z * alpha * T[k];
-                        T[k] = test;
-                        last[k] = contributor;
-                    }
-                    done[k] = done[k] || stop;
-                    newly_done = newly_done || stop;
-                }
-                if (__ballot(newly_done) != 0ull &&
-                    __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) { all_done = true; break; }
-            }
-            if (all_done) break;
+            all_done = composite_staged(s, s_xy, s_co, s_rgb, chunk, batch_first + c0 + 1u, p.t_cutoff);
         }
     }
-
-    const size_t plane = (size_t)p.dims.width * (size_t)p.dims.height;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (inside[k]) {
-            const size_t pid = (size_t)(py0 + 4 * k) * (size_t)p.dims.width + (size_t)px;
-            p.final_t[pid] = T[k];
-            p.n_contrib[pid] = last[k];
-            p.out_color[pid] = cr[k] + T[k] * p.background[0];
-            p.out_color[pid + plane] = cg[k] + T[k] * p.background[1];
-            p.out_color[pid + 2 * plane] = cb[k] + T[k] * p.background[2];
-        }
-    }
+    tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
 }
 
