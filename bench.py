@@ -47,6 +47,9 @@ def parse_args():
     p.add_argument("--no-rebalance", action="store_true")
     p.add_argument("--backward", action="store_true",
                    help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
+    p.add_argument("--overlap", action="store_true",
+                   help="GSR_FLAG_OVERLAP_EMIT: block plan's emission on a second stream beside the blend (shorter frames, "
+                        "but per-kernel times are then those of kernels sharing the chip)")
     p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
     return p.parse_args()
 
@@ -140,7 +143,8 @@ def main():
 
     def step(profile=False):
         rows = exch.my_tile_rows() if exch else None
-        frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not distributed, plan=args.plan)
+        frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not distributed, plan=args.plan,
+                          overlap_emit=args.overlap)
         if dl_dout is not None:
             rast.backward(dl_dout, profile=profile)
             if profile:

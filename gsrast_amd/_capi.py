@@ -26,6 +26,7 @@ GSR_FLAG_COUNT_STAGED = 0x2
 GSR_FLAG_SEMANTICS_INRIA = 0x4
 GSR_FLAG_PLAN_SORT = 0x8
 GSR_FLAG_PLAN_BLOCKS = 0x10
+GSR_FLAG_OVERLAP_EMIT = 0x20
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8
 STAGE_NAMES = ("preprocess", "scan", "depth_order", "duplicate", "sort_pass1", "sort_pass2", "ranges", "blend")

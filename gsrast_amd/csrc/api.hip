@@ -4,6 +4,7 @@
 // gsr_forward follows reference apps/gsrast/gscuda/GSCuda.cu:695-811 (gscuda::forward);
 // the chunk carving follows AuxBuffer.cu:13-21 (obtain) and :44-89 (fromChunk).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gsr_common.hpp"
@@ -99,6 +100,16 @@ struct Readback {
     int begin_of[GSR_NUM_STAGES] = {};        // event index a stage starts at (default 2s)
     void ev_alias_begin(int stage, int after_stage) { begin_of[stage] = 2 * after_stage + 1; }
     hipEvent_t ev_r = nullptr;                // "numRendered has landed in host memory"
+    hipStream_t side = nullptr;               // block plan: the emission runs here, beside the blend
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int ensure_side() {
+        if (!side) {
+            GSR_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            GSR_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            GSR_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        return GSR_OK;
+    }
     int ensure() {
         if (!host) {
             GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocDefault));
@@ -344,20 +355,40 @@ int gsr_forward(gsr_forward_args* a) {
     // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
     if (!use_blocks)
         GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
+    bool forked = false;
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(n, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, R, spare_k, gs.block_scratch,
-                                      bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, bin.keys, bin.values, img.ranges, inria, stream,
-                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
-                                      profile ? g_rb.ev[2 * GSR_STAGE_SORT_PASS1 + 1] : nullptr));
+                                      bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, img.ranges, inria, stream,
+                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr));
         if (profile) {
-            // depth order + block lists | unit counts + prefixes (recorded as "sort_pass1") | emission
+            // depth order + block lists | unit masks + prefixes + ranges (recorded as "sort_pass1") | emission
             g_rb.ev_alias_begin(GSR_STAGE_SORT_PASS1, GSR_STAGE_DEPTH_ORDER);
-            g_rb.ev_alias_begin(GSR_STAGE_DUPLICATE, GSR_STAGE_SORT_PASS1);
+            GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_SORT_PASS1 + 1], stream));
             g_rb.recorded[GSR_STAGE_DEPTH_ORDER] = g_rb.recorded[GSR_STAGE_SORT_PASS1] = true;
-            GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], stream));
+        }
+        // The blend of this plan reads the block lists, not the sorted lists, so it does not depend on the
+        // emission. With GSR_FLAG_OVERLAP_EMIT the emission (bound by the HBM write path) runs beside the
+        // blend (bound by vector ALU work) on a second stream, and the caller's stream waits for it before
+        // gsr_forward's work is complete: 5 % shorter frames, but each of the two kernels runs ~20 % longer
+        // while they share the chip, so per-kernel times are no longer those of the kernels alone.
+        const bool serial = !(a->flags & GSR_FLAG_OVERLAP_EMIT);
+        hipStream_t emit_stream = stream;
+        if (!serial) {
+            GSR_STEP(g_rb.ensure_side());
+            GSR_HIP_TRY(hipEventRecord(g_rb.ev_fork, stream));
+            GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_fork, 0));
+            emit_stream = g_rb.side;
+            forked = true;
+        }
+        if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
+        GSR_STEP(launch_block_emit(n, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
+                                   bin.sorting_space, bin.keys, bin.values, emit_stream));
+        if (profile) {
+            GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], emit_stream));
             g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
         }
+        if (forked) GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
         uint32_t* rect_packed = spare_k;
@@ -409,10 +440,16 @@ int gsr_forward(gsr_forward_args* a) {
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     GSR_BEGIN(GSR_STAGE_BLEND);
-    GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
-                          img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                          t_cutoff, stream));                                                        // :804-810
+    if (use_blocks)
+        GSR_STEP(launch_blend_blocks(n, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
+                                     colors, geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color,
+                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, stream));
+    else
+        GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
+                              img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
+                              t_cutoff, stream));                                                    // :804-810
     GSR_END(GSR_STAGE_BLEND);
+    if (forked) GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));      // the sorted lists are complete too
 
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 1, gs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (!use_blocks)

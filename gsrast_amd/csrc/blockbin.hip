@@ -20,7 +20,9 @@
 //       written front to back by one wave.
 // The result is bit-identical to the stable 64-bit sort (same lists, same order inside a tile).
 // R-sized traffic: 12 R bytes written once (the reference's emit + 6-pass sort moves > 150 R).
-#include "gsr_common.hpp"
+#include <stdlib.h>
+
+#include "blend_core.hpp"
 
 namespace gsr {
 namespace {
@@ -506,6 +508,87 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
     }
 }
 
+// ---- blend straight from the block lists -------------------------------------------------------------
+// The tile's records, in list order, are the entries of its block whose (column mask & row mask) bit is
+// set — the same filter the emission applies. Reading them from the block lists makes the blend
+// independent of the emission, which can then run beside it on a second stream: the blend is bound by
+// vector ALU work, the emission by the HBM write path. Per batch of 64 entries the covered ones are
+// staged compacted (v_mbcnt rank) in wave-private LDS and composited by the shared core; the 256-record
+// batches of the reference survive as the granularity of the staged-record count.
+struct BlockBlendParams {
+    BlockMeta meta;
+    int nbx;
+    const uint2* unit_masks;
+    const uint32_t* ent_idx;
+    const uint2* ranges;
+    const float2* means2D;
+    const float* colors;
+    const float4* conic_opacity;
+    float* final_t;
+    uint32_t* n_contrib;
+    const float* background;
+    float* out_color;
+    unsigned long long* staged_counter;
+    float t_cutoff;
+    FrameDims dims;
+    int num_tiles;
+};
+
+__global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendParams p) {
+    __shared__ float2 s_xy[kWave];
+    __shared__ float4 s_co[kWave];
+    __shared__ float4 s_rgb[kWave];
+    const int tile_local = xcd_tile_of_block(blockIdx.x, p.num_tiles);
+    const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
+    const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
+    const int lane = threadIdx.x;
+    TileLanes s;
+    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height);
+    const uint2 range = p.ranges[tile];
+    const uint32_t total = range.y - range.x;
+    unsigned long long staged = 0;
+    bool all_done = tile_lanes_all_done(s) || total == 0u;
+
+    const uint32_t b = (uint32_t)(ty / kBH) * (uint32_t)p.nbx + (uint32_t)(tx / kBW);
+    const uint32_t col = (uint32_t)(tx % kBW), row = 8u + (uint32_t)(ty % kBH);
+    const uint32_t u0 = p.meta.unit_start()[b], u1 = p.meta.unit_start()[b + 1];
+    const uint32_t list0 = p.meta.list_start()[b];
+    uint32_t pos = 0;                                   // records of this tile composited so far
+    for (uint32_t u = u0; u < u1 && !all_done; ++u) {
+        const uint2* um = p.unit_masks + (size_t)u * 16 * kBatches + (lane & (kBatches - 1));
+        const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
+        const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
+        const uint32_t e0 = list0 + (u - u0) * kUnit;
+        for (int w = 0; w < kBatches && !all_done; ++w) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
+            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+            if (m == 0ull) continue;
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                const uint32_t id = p.ent_idx[e0 + (uint32_t)w * kWave + (uint32_t)lane];
+                s_xy[slot] = p.means2D[id];
+                s_co[slot] = p.conic_opacity[id];
+                const float* c = p.colors + 3 * (size_t)id;
+                s_rgb[slot] = make_float4(c[0], c[1], c[2], 0.0f);
+            }
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            // composite, stopping at every 256-record boundary of the tile's list to count the batch the
+            // reference would stage there (it stages a whole batch whenever a pixel is still unfinished)
+            for (uint32_t j0 = 0; j0 < cnt && !all_done;) {
+                const uint32_t at = pos + j0;
+                if ((at & (kBatch - 1)) == 0u) staged += min((uint32_t)kBatch, total - at);
+                const uint32_t nrec = min(cnt - j0, (uint32_t)kBatch - (at & (kBatch - 1)));
+                all_done = composite_staged(s, s_xy + j0, s_co + j0, s_rgb + j0, nrec, at + 1u, p.t_cutoff);
+                j0 += nrec;
+            }
+            pos += cnt;
+        }
+    }
+    tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
+    if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
+}
+
 }  // namespace
 
 bool blockbin_supported(int grid_x, int grid_y) {
@@ -528,64 +611,117 @@ size_t blockbin_geo_bytes(size_t n) {
 static size_t blockbin_cnt_bytes(size_t r) { return align128((r / kUnit + kMaxBlocks + 1) * 64 * 4); }
 size_t blockbin_bin_bytes(size_t r) { return blockbin_cnt_bytes(r) + align128((r / kUnit + kMaxBlocks + 1) * 16 * kBatches * 8); }
 
-// rect_packed: out, u32[n] in depth order. ent_rd / ent_idx: R-sized scratch for the block lists.
-// ev_*: optional events recorded between the three groups of kernels (stage timing).
+namespace {
+// Where the plan's tables live inside the two scratch areas.
+struct PlanTables {
+    int nbx, nb, nbp;
+    uint32_t chunks, groups, tiles, max_units;
+    uint32_t *table, *partial, *tile_count, *tile_start, *cnt;
+    uint2* unit_masks;
+    BlockMeta meta;
+};
+PlanTables plan_tables(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, char* bin_scratch) {
+    PlanTables t;
+    t.nbx = (grid_x + kBW - 1) / kBW;
+    t.nb = t.nbx * ((grid_y + kBH - 1) / kBH);
+    t.nbp = (t.nb + kWave - 1) / kWave * kWave;
+    t.chunks = (uint32_t)((n + kCoarse - 1) / kCoarse);
+    t.groups = (t.chunks + kScanRows - 1) / kScanRows;
+    t.tiles = (uint32_t)(grid_x * grid_y);
+    t.max_units = r_total / kUnit + (uint32_t)t.nb + 1u;
+    char* p = geo_scratch;
+    t.table = reinterpret_cast<uint32_t*>(p); p += blockbin_table_bytes((size_t)n);
+    t.partial = reinterpret_cast<uint32_t*>(p); p += blockbin_partial_bytes((size_t)n);
+    t.meta.w = reinterpret_cast<uint32_t*>(p); t.meta.nbp = t.nbp; p += align128((2 * (kMaxBlocks + 1) + 2) * 4);
+    t.tile_count = reinterpret_cast<uint32_t*>(p); p += align128((65536 + 1) * 4);
+    t.tile_start = reinterpret_cast<uint32_t*>(p);
+    t.cnt = reinterpret_cast<uint32_t*>(bin_scratch);
+    t.unit_masks = reinterpret_cast<uint2*>(bin_scratch + blockbin_cnt_bytes(r_total));
+    return t;
+}
+}  // namespace
+
+// Everything of the block plan up to (not including) the emission: block lists, unit masks, prefixes and
+// the tile ranges. rect_packed: out, u32[n] in depth order. ent_rd / ent_idx: R-sized scratch for the
+// block lists. ev_coarse_end: optional event recorded after the block lists (stage timing).
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
                          int grid_x, int grid_y, uint32_t r_total, uint32_t* rect_packed, char* geo_scratch, uint64_t* ent_rd,
-                         uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, uint32_t* ranges,
-                         bool close_single, hipStream_t stream, hipEvent_t ev_coarse_end, hipEvent_t ev_prefix_end) {
-    const int nbx = (grid_x + kBW - 1) / kBW, nby = (grid_y + kBH - 1) / kBH, nb = nbx * nby;
-    const int nbp = (nb + kWave - 1) / kWave * kWave;
-    const uint32_t chunks = (uint32_t)((n + kCoarse - 1) / kCoarse);
-    const uint32_t groups = (chunks + kScanRows - 1) / kScanRows;
-    const uint32_t tiles = (uint32_t)(grid_x * grid_y);
-    char* p = geo_scratch;
-    uint32_t* table = reinterpret_cast<uint32_t*>(p); p += blockbin_table_bytes((size_t)n);
-    uint32_t* partial = reinterpret_cast<uint32_t*>(p); p += blockbin_partial_bytes((size_t)n);
-    BlockMeta meta; meta.w = reinterpret_cast<uint32_t*>(p); meta.nbp = nbp; p += align128((2 * (kMaxBlocks + 1) + 2) * 4);
-    uint32_t* tile_count = reinterpret_cast<uint32_t*>(p); p += align128((65536 + 1) * 4);
-    uint32_t* tile_start = reinterpret_cast<uint32_t*>(p);
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(bin_scratch);
-    uint2* unit_masks = reinterpret_cast<uint2*>(bin_scratch + blockbin_cnt_bytes(r_total));
-
-    hipLaunchKernelGGL(coarse_count_kernel, dim3(chunks), dim3(kCoarse), 0, stream, n, sorted_depth, sorted_idx, rect_by_index,
-                       nbx, nbp, rect_packed, table);
+                         uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
+                         hipEvent_t ev_coarse_end) {
+    const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
+    hipLaunchKernelGGL(coarse_count_kernel, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_depth, sorted_idx, rect_by_index,
+                       t.nbx, t.nbp, rect_packed, t.table);
     GSR_LAUNCH_CHECK("coarse_count_kernel");
-    hipLaunchKernelGGL(blockscan_reduce_kernel, dim3(groups), dim3(nbp), 0, stream, table, chunks, nbp, partial);
+    hipLaunchKernelGGL(blockscan_reduce_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial);
     GSR_LAUNCH_CHECK("blockscan_reduce_kernel");
-    hipLaunchKernelGGL(blockscan_partials_kernel, dim3(1), dim3(nbp), 0, stream, partial, groups, nb, meta);
+    hipLaunchKernelGGL(blockscan_partials_kernel, dim3(1), dim3(t.nbp), 0, stream, t.partial, t.groups, t.nb, t.meta);
     GSR_LAUNCH_CHECK("blockscan_partials_kernel");
-    hipLaunchKernelGGL(blockscan_apply_kernel, dim3(groups), dim3(nbp), 0, stream, table, chunks, nbp, partial, meta.list_start());
+    hipLaunchKernelGGL(blockscan_apply_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial,
+                       t.meta.list_start());
     GSR_LAUNCH_CHECK("blockscan_apply_kernel");
-    const size_t mask_bytes = (size_t)nb * 32 * 4 * 2;
+    const size_t mask_bytes = (size_t)t.nb * 32 * 4 * 2;
     if (mask_bytes > 48 * 1024)
         GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
-    hipLaunchKernelGGL(coarse_emit_kernel, dim3(chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
-                       sorted_idx, rect_packed, table, nbx, nb, nbp, ent_rd, ent_idx);
+    hipLaunchKernelGGL(coarse_emit_kernel, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
+                       sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
     GSR_LAUNCH_CHECK("coarse_emit_kernel");
     if (ev_coarse_end) GSR_HIP_TRY(hipEventRecord(ev_coarse_end, stream));
 
-    // persistent grids: enough waves to fill the chip, never more than there can be units
-    const uint32_t max_units = r_total / kUnit + (uint32_t)nb + 1u;
-    const uint32_t count_wgs = std::min<uint32_t>((max_units + 3) / 4, 256u * 8u);
-    hipLaunchKernelGGL(unit_masks_kernel, dim3(count_wgs), dim3(256), 0, stream, meta, nb, nbx, ent_rd, unit_masks, cnt);
+    // persistent grid: enough waves to fill the chip, never more than there can be units
+    const uint32_t count_wgs = std::min<uint32_t>((t.max_units + 3) / 4, 256u * 8u);
+    hipLaunchKernelGGL(unit_masks_kernel, dim3(count_wgs), dim3(256), 0, stream, t.meta, t.nb, t.nbx, ent_rd, t.unit_masks, t.cnt);
     GSR_LAUNCH_CHECK("unit_masks_kernel");
-    GSR_HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
-    hipLaunchKernelGGL(block_prefix_kernel, dim3(nb), dim3(256), 0, stream, meta, nbx, grid_x, grid_y, cnt, tile_count);
+    hipLaunchKernelGGL(block_prefix_kernel, dim3(t.nb), dim3(256), 0, stream, t.meta, t.nbx, grid_x, grid_y, t.cnt, t.tile_count);
     GSR_LAUNCH_CHECK("block_prefix_kernel");
-    hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(1024), 0, stream, tile_count, tiles, tile_start,
+    hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(1024), 0, stream, t.tile_count, t.tiles, t.tile_start,
                        reinterpret_cast<uint2*>(ranges), r_total, close_single);
     GSR_LAUNCH_CHECK("tile_start_kernel");
-    if (ev_prefix_end) GSR_HIP_TRY(hipEventRecord(ev_prefix_end, stream));
+    return GSR_OK;
+}
 
+// The emission: the sorted keys / values written from the tables launch_block_binning left.
+int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
+                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream) {
+    const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
 #ifndef GSR_EMIT_WGS_PER_CU
 #define GSR_EMIT_WGS_PER_CU 2
 #endif
-    const uint32_t emit_wgs = std::min<uint32_t>((max_units + kEmitWaves - 1) / kEmitWaves, 256u * GSR_EMIT_WGS_PER_CU);
-    hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, meta, nb, nbx, grid_x, grid_y, ent_rd, ent_idx,
-                       unit_masks, cnt, tile_start, keys, values, r_total);
+    const uint32_t emit_wgs = std::min<uint32_t>((t.max_units + kEmitWaves - 1) / kEmitWaves, 256u * GSR_EMIT_WGS_PER_CU);
+    hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, t.meta, t.nb, t.nbx, grid_x, grid_y,
+                       ent_rd, ent_idx, t.unit_masks, t.cnt, t.tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");
+    return GSR_OK;
+}
+
+// The blend, fed from the block lists (independent of launch_block_emit).
+int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
+                        const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
+                        float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
+                        unsigned long long* staged_counter, float t_cutoff, hipStream_t stream) {
+    const PlanTables t = plan_tables(n, d.grid_x, d.grid_y, r_total, geo_scratch, bin_scratch);
+    BlockBlendParams p;
+    p.meta = t.meta;
+    p.nbx = t.nbx;
+    p.unit_masks = t.unit_masks;
+    p.ent_idx = ent_idx;
+    p.ranges = reinterpret_cast<const uint2*>(ranges);
+    p.means2D = reinterpret_cast<const float2*>(means2D);
+    p.colors = colors;
+    p.conic_opacity = reinterpret_cast<const float4*>(conic_opacity);
+    p.final_t = final_t;
+    p.n_contrib = n_contrib;
+    p.background = background;
+    p.out_color = out_color;
+    p.staged_counter = staged_counter;
+    p.t_cutoff = t_cutoff;
+    p.dims = d;
+    p.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
+    if (p.num_tiles <= 0) return GSR_OK;
+    // tuning aid: GSR_BLEND_PAD=<bytes> of unused dynamic LDS lowers how many of these waves a CU holds
+    static const unsigned pad = [] { const char* e = getenv("GSR_BLEND_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    hipLaunchKernelGGL(blend_blocks_kernel, dim3((unsigned)p.num_tiles), dim3(kWave), pad, stream, p);
+    GSR_LAUNCH_CHECK("blend_blocks_kernel");
     return GSR_OK;
 }
 

@@ -79,8 +79,14 @@ size_t blockbin_geo_bytes(size_t n);
 size_t blockbin_bin_bytes(size_t r);
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
                          int grid_x, int grid_y, uint32_t r_total, uint32_t* rect_packed, char* geo_scratch, uint64_t* ent_rd,
-                         uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, uint32_t* ranges,
-                         bool close_single, hipStream_t stream, hipEvent_t ev_coarse_end, hipEvent_t ev_prefix_end);
+                         uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
+                         hipEvent_t ev_coarse_end);
+int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
+                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream);
+int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
+                        const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
+                        float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
+                        unsigned long long* staged_counter, float t_cutoff, hipStream_t stream);
 
 int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream);
 

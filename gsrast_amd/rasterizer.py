@@ -118,12 +118,14 @@ class SplatRasterizer:
     # -- one frame --------------------------------------------------------------------
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
-             sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto") -> torch.Tensor:
+             sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
+             overlap_emit: bool = False) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
         rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3].
-        plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan."""
+        plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan.
+        overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: emission on a second stream beside the blend)."""
         if cam is not None:
             self.set_camera(cam)
         a = _capi.ForwardArgs()
@@ -132,7 +134,8 @@ class SplatRasterizer:
         assert semantics in ("gscuda", "inria")
         a.flags = ((_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
                    | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0)
-                   | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan])
+                   | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan]
+                   | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else 0))
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
         a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()

@@ -112,6 +112,9 @@ enum {
  * keysUnsorted / valuesUnsorted then hold that plan's block lists (scratch, as sortingSpace is). */
 #define GSR_FLAG_PLAN_SORT 0x8u
 #define GSR_FLAG_PLAN_BLOCKS 0x10u
+/* Block plan only: run the emission of the sorted lists on a second stream beside the blend (which reads the
+ * block lists and does not need them). Same results; the call's work is complete, as always, when `stream` is. */
+#define GSR_FLAG_OVERLAP_EMIT 0x20u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */ };
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of

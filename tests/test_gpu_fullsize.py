@@ -196,3 +196,32 @@ def test_cpp_harness_through_the_reference_signature(tmp_path):
     assert f"numRendered={exp['num_rendered']}" in out, out
     img = np.fromfile(path_out, np.float32).reshape(3, cam.height, cam.width)
     assert np.abs(img - exp["out_color"]).max() <= 1e-4
+
+
+def test_overlapped_emission_gives_the_same_frame():
+    """GSR_FLAG_OVERLAP_EMIT: the emission runs on a second stream beside the blend (which reads the block lists).
+    Keys, values, ranges, pixels, nContrib and the staged-record count must not change."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    scene = scenes.garden_like_scene(400_000, seed=43)
+    scene["means3D"][:, 2] += 6.0
+    cam = camera.default_camera(1920, 1080, near=0.05, far=80.0)
+    r = SplatRasterizer(1920, 1080, background=(0.05, 0.1, 0.15))
+    r.configure_from_scene(scene)
+    img = r.draw(cam, plan="blocks", count_staged=True).clone()
+    staged = r.last_records_staged
+    b = r.map_binning_state()
+    keys, vals = b["keys"].clone(), b["values"].clone()
+    nc = r.map_image_state()["nContrib"].clone()
+    for cb in (r.binning,):
+        cb.tensor.zero_()
+    for _ in range(3):
+        img2 = r.draw(cam, plan="blocks", count_staged=True, overlap_emit=True)
+        assert r.last_plan == "blocks" and r.last_records_staged == staged
+        b = r.map_binning_state()
+        assert torch.equal(img2, img) and torch.equal(b["keys"], keys) and torch.equal(b["values"], vals)
+        assert torch.equal(r.map_image_state()["nContrib"], nc)
+    # and the old pairing (sort plan, blend from the sorted list) agrees with both
+    img3 = r.draw(cam, plan="sort", count_staged=True)
+    assert torch.equal(img3, img) and r.last_records_staged == staged
