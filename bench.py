@@ -227,7 +227,7 @@ def main():
             "duplicate": 12 * R if blocks else 8 * N + 20 * n_visible + 12 * R,
             "sort_pass1": 0 if blocks else 24 * R,   # one onesweep launch: 12 B read + 12 B written per pair
             "sort_pass2": 24 * R,
-            "ranges": 16 * T_loc * max(1, int(np.ceil(np.log2(max(R, 2))))) + 8 * T_loc,   # two binary searches per tile
+            "ranges": 0 if blocks else 16 * T_loc * max(1, int(np.ceil(np.log2(max(R, 2))))) + 8 * T_loc,   # two binary searches per tile
             "blend": 40 * r_f + 20 * P_loc + 8 * T_loc,
         }
         kernels = {}
@@ -239,7 +239,8 @@ def main():
         dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"),
                   key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
-                     "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)", "blend": "blend_wave_kernel",
+                     "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)",
+                     "blend": "blend_blocks_kernel" if blocks else "blend_wave_kernel",
                      "duplicate": "block_emit_kernel (sorted lists written directly)" if blocks else "emit_chunk_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
 
         # HBM bytes per launch measured with PMC counters in separate rocprofv3 passes of this same

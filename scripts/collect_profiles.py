@@ -23,7 +23,7 @@ for i in range(2):
             vals.setdefault(k, {})[n] = float(v)
 traffic = lambda k: int((2 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024)
 j = json.load(open("profiles/pmc_traffic_r01.json"))
-j["blocks"] = {"duplicate": traffic("block_emit_kernel"), "preprocess": traffic("preprocess_kernel"), "blend": traffic("blend_wave_kernel")}
+j["blocks"] = {"duplicate": traffic("block_emit_kernel"), "preprocess": traffic("preprocess_kernel"), "blend": traffic("blend_blocks_kernel")}
 json.dump(j, open("profiles/pmc_traffic_r01.json", "w"), indent=1)
 for name, out in (("bench_default", "r01_bench_default.json"), ("bench_backward", "r01_bench_backward.json"), ("bench_4k", "r01_bench_4k.json")):
     try:
