@@ -25,7 +25,7 @@ traffic = lambda k: int((2 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 10
 j = json.load(open("profiles/pmc_traffic_r01.json"))
 j["blocks"] = {"duplicate": traffic("block_emit_kernel"), "preprocess": traffic("preprocess_kernel"), "blend": traffic("blend_blocks_kernel")}
 json.dump(j, open("profiles/pmc_traffic_r01.json", "w"), indent=1)
-for name, out in (("bench_default", "r01_bench_default.json"), ("bench_backward", "r01_bench_backward.json"), ("bench_4k", "r01_bench_4k.json")):
+for name, out in (("bench_default", "r01_bench_default.json"), ("bench_backward", "r01_bench_backward.json"), ("bench_4k", "r01_bench_4k.json"), ("bench_overlap", "r01_bench_overlap.json")):
     try:
         d = json.loads([l for l in open(f"gpurun_out/{name}.log") if l.startswith('{"metric')][-1])
         open(f"profiles/{out}", "w").write(json.dumps(d, indent=1))
