@@ -13,11 +13,14 @@
 //       (entries x tile columns / rows, transposed with v_writelane) and, from their bit counts,
 //       the keys per (unit, tile)
 //   block_prefix / tile_start : prefix of those counts down the units of a block, then over the
-//       tiles in tile order = where every (unit, tile) run starts in the sorted list
+//       tiles in tile order = where every (unit, tile) run starts in the sorted list — and, per
+//       tile, its range [start, end) (identifyTileRanges, GSCuda.cu:504-538)
 //   block_emit   : one wavefront per unit: per tile, (column mask & row mask) says which entries of
 //       each batch of 64 cover it; they are compacted by v_mbcnt rank through a small LDS run
 //       buffer and stored as dense, line-aligned groups of 128 keys — every (unit, tile) run is
 //       written front to back by one wave.
+//   blend_blocks : the per-tile blend (GSCuda.cu:543-677) fed from the same block lists and masks,
+//       so it does not wait for — and can run beside — the emission.
 // The result is bit-identical to the stable 64-bit sort (same lists, same order inside a tile).
 // R-sized traffic: 12 R bytes written once (the reference's emit + 6-pass sort moves > 150 R).
 #include <stdlib.h>
