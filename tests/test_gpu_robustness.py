@@ -140,3 +140,33 @@ def test_precomputed_colors_and_cov3d_paths():
     # same geometry, so the same per-pixel weights: out = sum_i w_i colour_i with the weights of the DC render
     assert torch.equal(r2.map_image_state()["nContrib"], r.map_image_state()["nContrib"])
     assert torch.equal(r2.map_image_state()["finalT"], r.map_image_state()["finalT"])
+
+
+def test_overlapped_emission_on_a_non_default_stream_with_bands_and_upstream_semantics():
+    """GSR_FLAG_OVERLAP_EMIT forks to the library's own side stream and joins the caller's stream again: the
+    results must be those of the serial call whatever stream the caller uses, for band-limited calls and for
+    the upstream semantics profile (forced block plan on a small frame)."""
+    import torch
+    from gsrast_amd import camera, scenes
+    scene = scenes.garden_like_scene(20_000, seed=31)
+    scene["means3D"][:, :3] *= 0.25
+    cam = camera.default_camera(640, 360, near=0.05, far=50.0)
+    r = _rast(640, 360, background=(0.2, 0.1, 0.0))
+    r.configure_from_scene(scene)
+    ref = r.draw(cam, plan="blocks", count_staged=True).clone()
+    ref_keys = r.map_binning_state()["keys"].clone()
+    staged = r.last_records_staged
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            img = r.draw(cam, plan="blocks", overlap_emit=True, count_staged=True)
+            assert torch.equal(img, ref) and r.last_records_staged == staged
+            assert torch.equal(r.map_binning_state()["keys"], ref_keys)
+        r.out_color.fill_(-1.0)
+        for rows in ((0, 5), (5, 6), (6, 23)):
+            r.draw(cam, plan="blocks", overlap_emit=True, tile_rows=rows)
+        assert torch.equal(r.out_color, ref)
+        a = r.draw(cam, plan="blocks", semantics="inria", sh_degree=0).clone()
+        b = r.draw(cam, plan="blocks", semantics="inria", sh_degree=0, overlap_emit=True)
+        c = r.draw(cam, plan="sort", semantics="inria", sh_degree=0)
+        assert torch.equal(a, b) and torch.equal(a, c)
