@@ -43,7 +43,7 @@ def parse_args():
     p.add_argument("--splats", type=int, default=5_834_784)
     p.add_argument("--scene", default="garden_like", choices=["garden_like", "stress", "isotropic"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=4, help="CPU baseline renders every k-th splat")
+    p.add_argument("--cpu-sample", type=int, default=3, help="CPU baseline renders every k-th splat (about 10 s of host time)")
     p.add_argument("--no-rebalance", action="store_true")
     p.add_argument("--backward", action="store_true",
                    help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
