@@ -42,7 +42,9 @@ struct GeoScratch {
     char* scan_temp;          // partial sums of the two prefix scans
     uint32_t* depth_key;      // u32[N] depth bits or ~0 (written by preprocess)
     uint32_t* rect_idx;       // u32[N] packed band-clipped rectangle in index order (written by preprocess)
-    uint32_t* top_digits;     // one word: distinct top-byte digits (< 255) of the depth keys
+    uint32_t* sort_info;      // [0] distinct top-byte digits of the visible depth keys, [1] visible Gaussians V
+    uint32_t* vis_partial;    // per 4096-key chunk: visible keys before it (compaction)
+    uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     SweepScratch sweep;       // onesweep status words for the N-sized sort: pass 0 (+ error word, digit histograms)
@@ -57,7 +59,10 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.scan_temp = base + off; off += align128(scan_temp_bytes(n));
     g.depth_key = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.rect_idx = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
-    g.top_digits = reinterpret_cast<uint32_t*>(base + off); off += 128;
+    g.sort_info = reinterpret_cast<uint32_t*>(base + off); off += 128;
+    g.vis_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
+    g.c_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.c_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
@@ -306,19 +311,21 @@ int gsr_forward(gsr_forward_args* a) {
     // (the four scratch areas are adjacent in the chunk)
     GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, 4 * sweep_scratch_bytes((size_t)n), stream));
     const SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
-    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, four, gs.top_digits, stream));
-    // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits
-    // for the two copies only (an event); the first three depth passes — which do not depend on R — are
-    // queued first, so the device keeps working during the host round trip. The second word says
-    // whether the fourth pass is needed: depth keys are float bits, and when every visible Gaussian
-    // has the same top byte (NDC z in [0.5, 1), the usual case) that pass would move nothing.
+    // Only Gaussians with at least one tile in this call take part from here on (V of N: 52 % on the
+    // bench frame, a few per cent per rank when the frame is sharded): their (depth key, index) pairs
+    // are compacted in index order — the same kernels count the digits of the four sort passes.
+    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream));
+    // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
+    // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
+    // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
+    // move nothing.
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.top_digits, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.sort_info, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
-    GSR_STEP(sort_u32_passes(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     const bool four_passes = g_rb.host[3] > 1u;
-    if (four_passes) GSR_STEP(sort_u32_passes(gs.depth_key, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream));
+    const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
+    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, four_passes ? 4 : 3, stream));
     // depth-sorted keys / indices, and the other pair of buffers (free from here on)
     uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k;
     uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v;
@@ -358,7 +365,7 @@ int gsr_forward(gsr_forward_args* a) {
     bool forked = false;
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
-        GSR_STEP(launch_block_binning(n, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, R, spare_k, gs.block_scratch,
+        GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, R, spare_k, gs.block_scratch,
                                       bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, img.ranges, inria, stream,
                                       profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr));
         if (profile) {
@@ -382,7 +389,7 @@ int gsr_forward(gsr_forward_args* a) {
             forked = true;
         }
         if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
-        GSR_STEP(launch_block_emit(n, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
+        GSR_STEP(launch_block_emit(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
                                    bin.sorting_space, bin.keys, bin.values, emit_stream));
         if (profile) {
             GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], emit_stream));
@@ -397,7 +404,7 @@ int gsr_forward(gsr_forward_args* a) {
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
         uint32_t* emit_v = d.grid_y > 1 ? bin.values_unsorted : bin.values;
         // the depth-order stage ends and the emission stage starts at an event inside the launcher
-        GSR_STEP(launch_emit_columns(n, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, rect_packed, gs.emit_scratch, hist_y,
+        GSR_STEP(launch_emit_columns(nv, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, rect_packed, gs.emit_scratch, hist_y,
                                      emit_k, emit_v, stream, profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
                                      profile ? g_rb.ev[2 * GSR_STAGE_DUPLICATE] : nullptr));   // :787
         if (profile) {
@@ -418,11 +425,11 @@ int gsr_forward(gsr_forward_args* a) {
             GSR_HIP_TRY(hipMemcpyAsync(bin.values_unsorted, bin.values, 4 * (size_t)R, hipMemcpyDeviceToDevice, stream));
         }
     } else {
-        GSR_STEP(launch_gather_counts(n, sorted_k, sorted_v, geom.tiles_touched, spare_k, stream));
-        GSR_STEP(launch_inclusive_scan(spare_k, spare_k, (size_t)n, gs.scan_temp, stream));
+        GSR_STEP(launch_gather_counts(nv, sorted_k, sorted_v, geom.tiles_touched, spare_k, stream));
+        GSR_STEP(launch_inclusive_scan(spare_k, spare_k, (size_t)nv, gs.scan_temp, stream));
         GSR_END(GSR_STAGE_DEPTH_ORDER);
         GSR_BEGIN(GSR_STAGE_DUPLICATE);
-        GSR_STEP(launch_duplicate(n, sorted_k, sorted_v, spare_k, geom, radii, rects_in, d, bin.keys_unsorted,
+        GSR_STEP(launch_duplicate(nv, sorted_k, sorted_v, spare_k, geom, radii, rects_in, d, bin.keys_unsorted,
                                   bin.values_unsorted, nullptr, nullptr, stream));         // :787
         GSR_END(GSR_STAGE_DUPLICATE);
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
@@ -441,7 +448,7 @@ int gsr_forward(gsr_forward_args* a) {
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     GSR_BEGIN(GSR_STAGE_BLEND);
     if (use_blocks)
-        GSR_STEP(launch_blend_blocks(n, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
+        GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
                                      colors, geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color,
                                      count_staged ? g_rb.staged_dev : nullptr, t_cutoff, stream));
     else

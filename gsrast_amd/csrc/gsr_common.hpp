@@ -62,9 +62,11 @@ size_t sort_temp_bytes(size_t n);
 struct SweepScratch;
 // Depth order (radix_sort.hip). sc4: one scratch area per pass, already zeroed by the caller (look-back words,
 // tickets, error word, histograms); the error word and the digit histograms live in sc4[0].
-int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, const SweepScratch* sc4, uint32_t* top_digits, hipStream_t stream);
-int sort_u32_passes(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                    const SweepScratch* sc4, int first, int last, hipStream_t stream);
+size_t depth_compact_scratch_bytes(size_t n);
+int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
+                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream);
+int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
+                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream);
 
 // Column-major emission (emit.hip): count, column scan and emission. The two events (may be null)
 // are recorded between the N-sized preparation and the emission kernel, for stage timing.

@@ -528,30 +528,136 @@ __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __
     const int c = __syncthreads_count(threadIdx.x < 255 && hist_top[threadIdx.x] != 0u);
     if (threadIdx.x == 0) *out = (uint32_t)c;
 }
+
+// ---- visible keys first: stable compaction of the keys that are not the 0xFFFFFFFF sentinel --------
+constexpr int kCompactThreads = 256, kCompactRows = 16, kCompactChunk = kCompactThreads * kCompactRows;
+
+__global__ __launch_bounds__(kCompactThreads) void visible_count_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                        uint32_t* __restrict__ partial) {
+    const uint32_t base = blockIdx.x * kCompactChunk;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < kCompactRows; ++r) {
+        const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
+        c += (e < n && keys[e] != 0xFFFFFFFFu) ? 1u : 0u;
+    }
+    __shared__ uint32_t s_w[kCompactThreads / kWave];
+    uint32_t v = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive prefix of the per-chunk counts, in place; the total (visible keys) goes to *total_out
+__global__ __launch_bounds__(1024) void visible_scan_kernel(uint32_t* __restrict__ partial, uint32_t chunks,
+                                                            uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t s_ws[16];
+    const uint32_t per = (chunks + 1023) / 1024;
+    const uint32_t a = min(chunks, threadIdx.x * per), z = min(chunks, a + per);
+    uint32_t s = 0;
+    for (uint32_t i = a; i < z; ++i) s += partial[i];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) s_ws[wave] = incl;
+    __syncthreads();
+    uint32_t running = incl - s;
+    for (int w = 0; w < wave; ++w) running += s_ws[w];
+    for (uint32_t i = a; i < z; ++i) {
+        const uint32_t c = partial[i];
+        partial[i] = running;
+        running += c;
+    }
+    if (threadIdx.x == 1023) *total_out = running;
+}
+
+// writes the visible (key, index) pairs in index order and counts the four 8-bit digits of every
+// visible key (the histograms of the four sort passes) on the way
+__global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                          const uint32_t* __restrict__ partial,
+                                                                          uint32_t* __restrict__ out_k, uint32_t* __restrict__ out_v,
+                                                                          uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lds[4 * 256];
+    __shared__ uint32_t s_w[kCompactThreads / kWave];
+    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads) lds[i] = 0;
+    const uint32_t base = blockIdx.x * kCompactChunk;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t running = partial[blockIdx.x];
+    for (int r = 0; r < kCompactRows; ++r) {
+        const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
+        const uint32_t k = (e < n) ? keys[e] : 0xFFFFFFFFu;
+        const bool vis = k != 0xFFFFFFFFu;
+        const unsigned long long m = __ballot(vis);
+        __syncthreads();                                   // s_w of the previous row has been read
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, row_total = 0;
+#pragma unroll
+        for (int w = 0; w < kCompactThreads / kWave; ++w) {
+            if (w < wave) before += s_w[w];
+            row_total += s_w[w];
+        }
+        if (vis) {
+            const uint32_t pos = running + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            out_k[pos] = k;
+            out_v[pos] = e;
+            atomicAdd(&lds[k & 255u], 1u);
+            atomicAdd(&lds[256 + ((k >> 8) & 255u)], 1u);
+            atomicAdd(&lds[512 + ((k >> 16) & 255u)], 1u);
+        }
+        // The top byte of float bit patterns takes few distinct values: one LDS atomic per distinct value
+        // and wave instead of 64 colliding on the same counter.
+        const uint32_t d = k >> 24;
+        unsigned long long todo = m;
+        while (todo) {
+            const uint32_t v = (uint32_t)__shfl((int)d, __ffsll((long long)todo) - 1, kWave);
+            const unsigned long long same = __ballot(vis && d == v) & todo;
+            if (lane == __ffsll((long long)same) - 1) atomicAdd(&lds[768 + v], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+        running += row_total;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads)
+        if (lds[i]) atomicAdd(&hist[i], lds[i]);
+}
 }  // namespace
 
-// Digit counts of the four passes from one read of the keys, plus (top_digits, device word) the number
-// of distinct top-byte digits below 255: with at most one, and 0xFFFFFFFF the only key whose top byte
-// is 255 (the caller's sentinel), the fourth pass would move nothing — three passes already sort the keys.
-int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, const SweepScratch* sc4, uint32_t* top_digits, hipStream_t stream) {
+size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChunk - 1) / kCompactChunk) * sizeof(uint32_t), 128); }
+
+// Depth keys of the visible Gaussians first (stable: index order), their count, the digit histograms of
+// the four sort passes, and (top_digits) the number of distinct top-byte digits: with at most one the
+// fourth pass would move nothing. info[0] = top_digits, info[1] = visible count (device words).
+int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
+                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream) {
     if (n == 0) return GSR_OK;
-    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + kSortTile - 1) / kSortTile, 2048);
-    hipLaunchKernelGGL((histogram_bits_kernel<uint32_t>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, stream, keys_in, (size_t)n, 4,
-                       0, 32, sc4[0].hist);
-    GSR_LAUNCH_CHECK("histogram_bits_kernel");
-    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, top_digits);
+    const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
+    hipLaunchKernelGGL(visible_count_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial);
+    GSR_LAUNCH_CHECK("visible_count_kernel");
+    hipLaunchKernelGGL(visible_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, chunks, info + 1);
+    GSR_LAUNCH_CHECK("visible_scan_kernel");
+    hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, out_k, out_v,
+                       sc4[0].hist);
+    GSR_LAUNCH_CHECK("visible_compact_kernel");
+    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info);
     GSR_LAUNCH_CHECK("top_digit_count_kernel");
     return GSR_OK;
 }
 
-// Passes [first, last) of the stable sort of N u32 keys carrying their own index:
-// in -> a -> b -> a -> b. After P passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
-int sort_u32_passes(const uint32_t* keys_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k, uint32_t* b_v,
-                    const SweepScratch* sc4, int first, int last, hipStream_t stream) {
+// Passes [first, last) of the stable sort of n (key, value) u32 pairs: in -> a -> b -> a -> b. After P
+// passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
+int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
+                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream) {
     if (n == 0) return GSR_OK;
     for (int p = first; p < last; ++p) {
         const uint32_t* src_k = (p == 0) ? keys_in : ((p % 2 == 1) ? a_k : b_k);
-        const uint32_t* src_v = (p == 0) ? nullptr : ((p % 2 == 1) ? a_v : b_v);
+        const uint32_t* src_v = (p == 0) ? vals_in : ((p % 2 == 1) ? a_v : b_v);
         uint32_t* dst_k = (p % 2 == 0) ? a_k : b_k;
         uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
         DigitSpec spec;
