@@ -177,12 +177,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
             }
             int x0, y0, x1, y1;
             tile_rect(pix, piy, ex, ey, p.dims, x0, y0, x1, y1);
-            // Visibility follows the UNCLIPPED rectangle (reference :356); the count is of the
-            // tiles inside this call's row band, which is the same thing when not sharded.
-            int fy0 = clampi((int)((piy - (float)ey) / 16.0f), 0, p.dims.grid_y);
-            int fy1 = clampi((int)((((piy + (float)ey) + 16.0f) - 1.0f) / 16.0f), 0, p.dims.grid_y);
-            const uint32_t full_area = (uint32_t)(x1 - x0) * (uint32_t)(fy1 - fy0);
-            if (full_area != 0) {
+            // Visibility (reference :356: rectangle area != 0) is decided on the rectangle clipped to this
+            // call's tile-row band — the whole grid when the call is not sharded, which is then exactly
+            // the reference's test. In a sharded call a Gaussian without a tile in the band is treated as
+            // invisible (radius 0, nothing written): the rank that owns the band never looks at it.
+            const uint32_t band_area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+            if (band_area != 0) {
                 if (!p.colors_precomp) {
                     const float* sh = p.shs + 48 * (size_t)idx;
                     float* o = p.rgb + 3 * (size_t)idx;
@@ -194,9 +194,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
                 p.means2D[idx] = make_float2(pix, piy);
                 p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[idx]);
                 out_radius = (int)my_radius;
-                out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
-                if (out_tiles)
-                    out_rect = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - y0) << 24);
+                out_tiles = band_area;
+                out_rect = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - y0) << 24);
             }
         }
     }

@@ -151,7 +151,9 @@ typedef struct gsr_forward_args {
     /* ---- extensions ---- */
     void* stream;                  /* hipStream_t; NULL = the default stream */
     int32_t tile_row_begin;        /* multi-GPU: only tile rows [begin,end) are binned,   */
-    int32_t tile_row_end;          /*   sorted and blended; 0,0 = all rows                 */
+    int32_t tile_row_end;          /*   sorted and blended; 0,0 = all rows. In such a call  */
+                                   /*   a Gaussian without a tile in the band counts as     */
+                                   /*   invisible (radius 0, its geometry fields unwritten) */
     /* ---- outputs ---- */
     uint32_t num_rendered;         /* R = sum of tiles touched (for the rows processed)    */
     uint64_t records_staged;       /* R_f, only with GSR_FLAG_COUNT_STAGED                 */
