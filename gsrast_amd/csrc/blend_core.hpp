@@ -26,14 +26,17 @@ struct TileLanes {                 // per-lane state of the four pixels a lane o
     uint32_t last[4];
 };
 
-__device__ __forceinline__ void tile_lanes_init(TileLanes& s, int tx, int ty, int lane, int width, int height) {
+// only_strip >= 0: the wave composites just that 16 x 4 strip of the tile (the other three pixel slots start
+// out finished and are never written) — four waves per tile, used when there are few tiles to go round.
+__device__ __forceinline__ void tile_lanes_init(TileLanes& s, int tx, int ty, int lane, int width, int height,
+                                                int only_strip = -1) {
     s.px = tx * kTile + (lane & 15);
     s.py0 = ty * kTile + (lane >> 4);
     s.fx = (float)s.px;
     s.fy01.x = (float)s.py0; s.fy01.y = (float)(s.py0 + 4); s.fy23.x = (float)(s.py0 + 8); s.fy23.y = (float)(s.py0 + 12);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        s.inside[k] = s.px < width && (s.py0 + 4 * k) < height;
+        s.inside[k] = s.px < width && (s.py0 + 4 * k) < height && (only_strip < 0 || only_strip == k);
         s.done[k] = s.inside[k] ? 0u : 1u;
         s.T[k] = 1.0f; s.cr[k] = s.cg[k] = s.cb[k] = 0.0f; s.last[k] = 0;
     }

@@ -314,3 +314,21 @@ def test_random_small_frames_against_oracle(seed):
         pytest.skip("nothing visible for this seed")
     r, img = _run(scene, cam, bg)
     _compare_all(r, img, exp, n)
+
+
+def test_four_waves_per_tile_blend_matches_one_wave_per_tile():
+    """Calls with few tiles blend with four waves per tile (one 16 x 4 strip each) unless the staged records are
+    counted; both forms must give the same pixels, nContrib and finalT bit for bit."""
+    from gsrast_amd import camera, scenes
+    scene = scenes.garden_like_scene(5000, seed=77)
+    scene["means3D"][:, :3] *= 0.25
+    cam = camera.default_camera(333, 257, near=0.05, far=50.0)
+    torch, SplatRasterizer = _gpu()
+    r = SplatRasterizer(333, 257, background=(0.3, 0.2, 0.1))
+    r.configure_from_scene(scene)
+    one = r.draw(cam, plan=PLAN, count_staged=True).clone()
+    st1 = {k: v.clone() for k, v in r.map_image_state().items()}
+    four = r.draw(cam, plan=PLAN)
+    st4 = r.map_image_state()
+    assert torch.equal(one, four)
+    assert torch.equal(st1["nContrib"], st4["nContrib"]) and torch.equal(st1["finalT"], st4["finalT"])
