@@ -357,7 +357,7 @@ int gsr_forward(gsr_forward_args* a) {
     // one onesweep pass on the tile row. The block plan pays per (Gaussian, block) entry, so scenes
     // of tiny splats (few tiles per Gaussian) stay on the sort plan unless a flag forces one.
     bool use_blocks = xy_plan && blockbin_supported(d.grid_x, d.grid_y) && !(a->flags & GSR_FLAG_PLAN_SORT);
-    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 2ull * (uint64_t)n;   // measured: equal at R/N = 2.5, 1.9x faster at 46
+    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 4ull * (uint64_t)n;   // measured: 3.5 % slower at R/N = 2.5 (50 M tiny splats), 2x faster at 46
     a->plan_used = use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC);
     // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
     if (!use_blocks)
