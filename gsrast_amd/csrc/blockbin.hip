@@ -348,6 +348,7 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
     const uint32_t per = (tiles + 1023) / 1024;
     const uint32_t a = min(tiles, threadIdx.x * per), z = min(tiles, a + per);
     uint32_t s = 0;
+#pragma unroll 8
     for (uint32_t t = a; t < z; ++t) s += tile_count[t];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     uint32_t incl = s;
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
     uint32_t running = incl - s;
     for (int w = 0; w < wave; ++w) running += s_ws[w];
     const bool closed = r_total > 1u || close_single;
+#pragma unroll 8
     for (uint32_t t = a; t < z; ++t) {
         const uint32_t c = tile_count[t];
         tile_start[t] = running;
