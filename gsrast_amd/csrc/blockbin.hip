@@ -31,7 +31,8 @@ namespace gsr {
 namespace {
 
 constexpr int kBW = 8, kBH = 8;          // tiles per block: one lane per tile
-constexpr int kCoarse = 1024;            // Gaussians per workgroup of the coarse passes
+constexpr int kCoarse = 1024;            // Gaussians per workgroup of the coarse passes ...
+constexpr int kCoarseSmall = 512;        // ... with more than 256 blocks (4K): half the LDS mask table, two workgroups per CU
 #ifndef GSR_UNIT
 #define GSR_UNIT 2048
 #endif
@@ -53,7 +54,8 @@ struct BlockMeta {                       // u32 words in HBM
 inline size_t align128(size_t v) { return (v + 127) / 128 * 128; }
 
 // ---- coarse pass 1: entries per (chunk of 1024 depth-consecutive Gaussians, block) ------------
-__global__ __launch_bounds__(kCoarse) void coarse_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
+template <int CHUNK>
+__global__ __launch_bounds__(CHUNK) void coarse_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                                const uint32_t* __restrict__ sorted_idx,
                                                                const uint32_t* __restrict__ rect_by_index, int nbx, int nbp,
                                                                uint32_t* __restrict__ rect_packed,
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kCoarse) void coarse_count_kernel(int n, const uint
     __shared__ uint32_t s_cnt[kMaxBlocks];
     if ((int)threadIdx.x < nbp) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int r = blockIdx.x * kCoarse + threadIdx.x;
+    const int r = blockIdx.x * CHUNK + threadIdx.x;
     uint32_t packed = 0;
     if (r < n && sorted_depth[r] != 0xFFFFFFFFu) packed = rect_by_index[sorted_idx[r]];
     if (r < n) rect_packed[r] = packed;
@@ -150,34 +152,36 @@ __global__ __launch_bounds__(kMaxBlocks) void blockscan_apply_kernel(uint32_t* _
 // ---- coarse pass 2: write the block lists ------------------------------------------------------
 // Order inside a chunk: per block a 1024-bit mask of the chunk's Gaussians touching it; the rank of
 // Gaussian g in block b is the number of set bits below g.
-__global__ __launch_bounds__(kCoarse) void coarse_emit_kernel(int n, const uint32_t* __restrict__ sorted_depth,
+template <int CHUNK>
+__global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                               const uint32_t* __restrict__ sorted_idx,
                                                               const uint32_t* __restrict__ rect_packed,
                                                               const uint32_t* __restrict__ table, int nbx, int nb, int nbp,
                                                               uint64_t* __restrict__ ent_rd, uint32_t* __restrict__ ent_idx) {
     extern __shared__ uint32_t s_dyn[];
-    uint32_t* s_mask = s_dyn;                    // [nb][32]
-    uint32_t* s_pre = s_dyn + (size_t)nb * 32;   // [nb][32] set bits in the words below
-    const int r = blockIdx.x * kCoarse + threadIdx.x;
+    constexpr int W = CHUNK / 32;                // mask words per block
+    uint32_t* s_mask = s_dyn;                    // [nb][W]
+    uint32_t* s_pre = s_dyn + (size_t)nb * W;    // [nb][W] set bits in the words below
+    const int r = blockIdx.x * CHUNK + threadIdx.x;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
     if (__syncthreads_or(rect != 0u) == 0) return;          // culled tail of the depth order
-    for (int i = threadIdx.x; i < nb * 32; i += kCoarse) s_mask[i] = 0;
+    for (int i = threadIdx.x; i < nb * W; i += CHUNK) s_mask[i] = 0;
     __syncthreads();
     const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
     uint32_t bx0 = 0, bx1 = 0, by0 = 1, by1 = 0;
     if (rect) { bx0 = x0 / kBW; bx1 = (x0 + w - 1) / kBW; by0 = y0 / kBH; by1 = (y0 + h - 1) / kBH; }
     const uint32_t word = threadIdx.x >> 5, bit = 1u << (threadIdx.x & 31);
     for (uint32_t by = by0; by <= by1; ++by)
-        for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[(by * nbx + bx) * 32 + word], bit);
+        for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[(by * nbx + bx) * W + word], bit);
     __syncthreads();
-    // 32 consecutive lanes scan the 32 words of one block
-    for (int i = threadIdx.x; i < nb * 32; i += kCoarse) {
+    // W consecutive lanes scan the W words of one block
+    for (int i = threadIdx.x; i < nb * W; i += CHUNK) {
         const uint32_t c = (uint32_t)__popc(s_mask[i]);
         uint32_t incl = c;
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 32);
-            if ((int)(threadIdx.x & 31) >= off) incl += o;
+        for (int off = 1; off < W; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, W);
+            if ((int)(threadIdx.x & (W - 1)) >= off) incl += o;
         }
         s_pre[i] = incl - c;
     }
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(kCoarse) void coarse_emit_kernel(int n, const uint3
     for (uint32_t by = by0; by <= by1; ++by)
         for (uint32_t bx = bx0; bx <= bx1; ++bx) {
             const uint32_t b = by * nbx + bx;
-            const uint32_t pos = row[b] + s_pre[b * 32 + word] + (uint32_t)__popc(s_mask[b * 32 + word] & (bit - 1u));
+            const uint32_t pos = row[b] + s_pre[b * W + word] + (uint32_t)__popc(s_mask[b * W + word] & (bit - 1u));
             ent_rd[pos] = rd;
             ent_idx[pos] = idx;
         }
@@ -604,9 +608,9 @@ bool blockbin_supported(int grid_x, int grid_y) {
     return nb <= kMaxBlocks;
 }
 
-static size_t blockbin_table_bytes(size_t n) { return align128(((n + kCoarse - 1) / kCoarse) * (size_t)kMaxBlocks * 4); }
+static size_t blockbin_table_bytes(size_t n) { return align128(((n + kCoarseSmall - 1) / kCoarseSmall) * (size_t)kMaxBlocks * 4); }
 static size_t blockbin_partial_bytes(size_t n) {
-    const size_t chunks = (n + kCoarse - 1) / kCoarse;
+    const size_t chunks = (n + kCoarseSmall - 1) / kCoarseSmall;
     return align128(((chunks + kScanRows - 1) / kScanRows) * (size_t)kMaxBlocks * 4);
 }
 // per-Gaussian scratch (geometry chunk): chunk table, row-group partials, block meta, tile counts / starts
@@ -621,7 +625,7 @@ size_t blockbin_bin_bytes(size_t r) { return blockbin_cnt_bytes(r) + align128((r
 namespace {
 // Where the plan's tables live inside the two scratch areas.
 struct PlanTables {
-    int nbx, nb, nbp;
+    int nbx, nb, nbp, chunk;
     uint32_t chunks, groups, tiles, max_units;
     uint32_t *table, *partial, *tile_count, *tile_start, *cnt;
     uint2* unit_masks;
@@ -632,7 +636,8 @@ PlanTables plan_tables(int n, int grid_x, int grid_y, uint32_t r_total, char* ge
     t.nbx = (grid_x + kBW - 1) / kBW;
     t.nb = t.nbx * ((grid_y + kBH - 1) / kBH);
     t.nbp = (t.nb + kWave - 1) / kWave * kWave;
-    t.chunks = (uint32_t)((n + kCoarse - 1) / kCoarse);
+    t.chunk = t.nb > 256 ? kCoarseSmall : kCoarse;
+    t.chunks = (uint32_t)((n + t.chunk - 1) / t.chunk);
     t.groups = (t.chunks + kScanRows - 1) / kScanRows;
     t.tiles = (uint32_t)(grid_x * grid_y);
     t.max_units = r_total / kUnit + (uint32_t)t.nb + 1u;
@@ -656,8 +661,12 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
                          hipEvent_t ev_coarse_end) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
-    hipLaunchKernelGGL(coarse_count_kernel, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_depth, sorted_idx, rect_by_index,
-                       t.nbx, t.nbp, rect_packed, t.table);
+    if (t.chunk == kCoarse)
+        hipLaunchKernelGGL(coarse_count_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_depth, sorted_idx,
+                           rect_by_index, t.nbx, t.nbp, rect_packed, t.table);
+    else
+        hipLaunchKernelGGL(coarse_count_kernel<kCoarseSmall>, dim3(t.chunks), dim3(kCoarseSmall), 0, stream, n, sorted_depth,
+                           sorted_idx, rect_by_index, t.nbx, t.nbp, rect_packed, t.table);
     GSR_LAUNCH_CHECK("coarse_count_kernel");
     hipLaunchKernelGGL(blockscan_reduce_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial);
     GSR_LAUNCH_CHECK("blockscan_reduce_kernel");
@@ -666,12 +675,17 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     hipLaunchKernelGGL(blockscan_apply_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial,
                        t.meta.list_start());
     GSR_LAUNCH_CHECK("blockscan_apply_kernel");
-    const size_t mask_bytes = (size_t)t.nb * 32 * 4 * 2;
-    if (mask_bytes > 48 * 1024)
-        GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
-    hipLaunchKernelGGL(coarse_emit_kernel, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
-                       sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
+    const size_t mask_bytes = (size_t)t.nb * (t.chunk / 32) * 4 * 2;
+    if (t.chunk == kCoarse) {
+        hipLaunchKernelGGL(coarse_emit_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
+                           sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
+    } else {
+        if (mask_bytes > 48 * 1024)
+            GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel<kCoarseSmall>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
+        hipLaunchKernelGGL(coarse_emit_kernel<kCoarseSmall>, dim3(t.chunks), dim3(kCoarseSmall), mask_bytes, stream, n, sorted_depth,
+                           sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
+    }
     GSR_LAUNCH_CHECK("coarse_emit_kernel");
     if (ev_coarse_end) GSR_HIP_TRY(hipEventRecord(ev_coarse_end, stream));
 
