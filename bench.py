@@ -279,6 +279,10 @@ def main():
                        "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "binning_plan": plan_used,
                        "bands": exch.bounds if exch else None},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
+                                  "duplicate": "block_emit_kernel (the sorted keys / values)", "blend": "blend_blocks_kernel"} if blocks else
+                                 {"depth_order": "visible-key compaction + depth sort + column counts / scan", "duplicate": "emit_chunk_kernel",
+                                  "sort_pass2": "onesweep pass on the tile row", "blend": "blend_wave_kernel"}),
             "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {prof_steps} "
                                 f"frames of the same workload run right after the timed region; those frames took "
                                 f"{elapsed_profiled / prof_steps * 1e3:.4f} ms each with the events in place"),
