@@ -112,3 +112,117 @@ def stress_scene(n: int = 50_000_000, seed: int = 44, full_sh: bool = False) -> 
     dc = 0.3 * s.normal(n, 3)
     rest = 0.3 * s.normal(n, 45) if full_sh else None
     return _pack(pos, scale, quat, opacity, dc, rest)
+
+
+# ---- the same scenes generated on a torch device -----------------------------------------------------
+# 50 M splats x 48 SH floats are 9.6 GB: building them with numpy on the host and uploading takes minutes.
+# The arithmetic definition is the same (splitmix64 -> 24-bit uniforms -> float64 transforms -> float32);
+# the float64 exp / log / cos of the device may differ from numpy's in the last place, which survives the
+# rounding to float32 about once in 2^29 values, so a test that compares against the CPU oracle takes its
+# sample FROM the device scene (scene_rows) instead of regenerating it.
+def _to_i64(v: int) -> int:
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def splitmix64_torch(seed: int, start: int, count: int, device):
+    """Outputs start .. start+count-1 of the stream as int64 bit patterns (two's-complement wrap = uint64 arithmetic)."""
+    import torch
+
+    def lsr(z, s):      # logical shift right on int64
+        return (z >> s) & ((1 << (64 - s)) - 1)
+    k = torch.arange(start + 1, start + count + 1, dtype=torch.int64, device=device)
+    z = k * _to_i64(int(_GOLDEN)) + _to_i64(seed)
+    z = (z ^ lsr(z, 30)) * _to_i64(int(_M1))
+    z = (z ^ lsr(z, 27)) * _to_i64(int(_M2))
+    return z ^ lsr(z, 31)
+
+
+class DeviceStream:
+    """Stream with random access: uniform_at(offset, count) are outputs pos+offset .. of the numpy Stream."""
+
+    def __init__(self, seed: int, device):
+        self.seed, self.device, self.pos = seed, device, 0
+
+    def uniform_at(self, start: int, count: int):
+        import torch
+        z = splitmix64_torch(self.seed, start, count, self.device)
+        return ((z >> 40) & ((1 << 24) - 1)).to(torch.float64) * (2.0 ** -24)
+
+    def uniform(self, *shape: int):
+        n = int(np.prod(shape))
+        u = self.uniform_at(self.pos, n).reshape(shape)
+        self.pos += n
+        return u
+
+    def normal(self, *shape: int):
+        import torch
+        u1 = self.uniform(*shape)
+        u2 = self.uniform(*shape)
+        return torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)
+
+    def normal_rows(self, rows: int, cols: int, r0: int, r1: int):
+        """Rows [r0, r1) of what normal(rows, cols) returns, without advancing (call skip afterwards)."""
+        import torch
+        u1 = self.uniform_at(self.pos + r0 * cols, (r1 - r0) * cols)
+        u2 = self.uniform_at(self.pos + rows * cols + r0 * cols, (r1 - r0) * cols)
+        return (torch.sqrt(-2.0 * torch.log(1.0 - u1)) * torch.cos(2.0 * math.pi * u2)).reshape(r1 - r0, cols)
+
+    def skip(self, count: int):
+        self.pos += count
+
+
+def _pack_device(pos, scale, quat, opacity, dc, device) -> dict:
+    import torch
+    n = pos.shape[0]
+    means = torch.ones((n, 4), dtype=torch.float32, device=device)
+    means[:, :3] = pos.to(torch.float32)
+    scales = torch.full((n, 4), math.e, dtype=torch.float32, device=device)
+    scales[:, :3] = scale.to(torch.float32)
+    shs = torch.zeros((n, 48), dtype=torch.float32, device=device)
+    shs[:, :3] = dc.to(torch.float32)
+    return {"means3D": means, "scales": scales, "rotations": quat.to(torch.float32).contiguous(),
+            "opacities": opacity.to(torch.float32).contiguous(), "shs": shs}
+
+
+def stress_scene_device(n: int = 50_000_000, seed: int = 44, device="cuda:0", full_sh: bool = False,
+                        sh_rows_per_chunk: int = 4_000_000) -> dict:
+    """stress_scene (BASELINE config 4) as float32 device tensors."""
+    import torch
+    s = DeviceStream(seed, device)
+    pos = s.uniform(n, 3) * 20.0 - 10.0
+    scale = torch.exp(math.log(0.005) + s.uniform(n, 3) * (math.log(0.05) - math.log(0.005)))
+    q = s.normal(n, 4)
+    q = q / torch.linalg.norm(q, dim=1, keepdim=True)
+    opacity = 1.0 / (1.0 + torch.exp(-(-2.0 + s.uniform(n) * 6.0)))
+    dc = 0.3 * s.normal(n, 3)
+    out = _pack_device(pos, scale, q, opacity, dc, device)
+    del pos, scale, q, opacity, dc
+    if full_sh:
+        for r0 in range(0, n, sh_rows_per_chunk):
+            r1 = min(n, r0 + sh_rows_per_chunk)
+            out["shs"][r0:r1, 3:] = (0.3 * s.normal_rows(n, 45, r0, r1)).to(torch.float32)
+        s.skip(2 * n * 45)
+    return out
+
+
+def garden_like_scene_device(n: int = 5_834_784, seed: int = 43, device="cuda:0") -> dict:
+    """garden_like_scene as float32 device tensors."""
+    import torch
+    s = DeviceStream(seed, device)
+    pos = s.normal(n, 3) * torch.tensor([4.0, 1.5, 4.0], dtype=torch.float64, device=device)
+    scale = torch.exp(-4.5 + 1.2 * s.normal(n, 3))
+    q = s.normal(n, 4)
+    q = q / torch.linalg.norm(q, dim=1, keepdim=True)
+    opacity = 1.0 / (1.0 + torch.exp(-(3.0 * s.normal(n))))
+    dc = s.normal(n, 3)
+    return _pack_device(pos, scale, q, opacity, dc, device)
+
+
+def scene_rows(scene: dict, rows) -> dict:
+    """Host (numpy float32) copy of the selected rows of a scene held as numpy arrays or torch tensors."""
+    out = {}
+    for k, v in scene.items():
+        sub = v[rows]
+        out[k] = np.ascontiguousarray(sub.cpu().numpy() if hasattr(sub, "cpu") else sub, dtype=np.float32)
+    return out

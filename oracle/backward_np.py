@@ -112,6 +112,68 @@ def blend_backward(means2D, conic_opacity, colors, ranges, point_list, n_contrib
     return {"dL_dmean2D": d_mean, "dL_dconic": d_conic, "dL_dopacity": d_op, "dL_dcolor": d_col}
 
 
+def blend_tile_backward(xy, co, col, tx, ty, width, height, background, dL_dout_tile, t_cutoff=0.001):
+    """One 16 x 16 tile, vectorised [L records x 256 pixels], float64: the forward loop of `blend_forward` and the
+    gradients of `blend_backward` restricted to this tile's pixels. Used at frame sizes where the per-pixel
+    Python loops above would take hours; tests/test_backward_oracle.py checks it against them.
+
+    xy [L,2], co [L,4], col [L,3]: the records of the tile's list, front to back (a prefix that reaches the last
+    contributor of every pixel is enough). dL_dout_tile [3,16,16] (entries outside the image are ignored).
+    Returns dict: per-record sums d_mean [L,2], d_conic [L,3], d_op [L], d_col [L,3]; per pixel out [3,16,16],
+    final_t [16,16], n_contrib [16,16] (pixels outside the image: 0)."""
+    xy = np.asarray(xy, np.float64).reshape(-1, 2)
+    co = np.asarray(co, np.float64).reshape(-1, 4)
+    col = np.asarray(col, np.float64).reshape(-1, 3)
+    bg = np.asarray(background, np.float64)
+    L = xy.shape[0]
+    ys, xs = np.mgrid[0:TILE, 0:TILE]
+    px = (tx * TILE + xs).reshape(-1).astype(np.float64)
+    py = (ty * TILE + ys).reshape(-1).astype(np.float64)
+    inside = (px < width) & (py < height)
+    gp = np.asarray(dL_dout_tile, np.float64).reshape(3, -1) * inside[None, :]
+    if L == 0:
+        out = np.where(inside[None, :], bg[:, None], 0.0)
+        return {"d_mean": np.zeros((0, 2)), "d_conic": np.zeros((0, 3)), "d_op": np.zeros(0), "d_col": np.zeros((0, 3)),
+                "out": out.reshape(3, TILE, TILE), "final_t": inside.astype(np.float64).reshape(TILE, TILE),
+                "n_contrib": np.zeros((TILE, TILE), np.int64)}
+    dx = xy[:, 0:1] - px[None, :]
+    dy = xy[:, 1:2] - py[None, :]
+    A, B, Cc, op = co[:, 0:1], co[:, 1:2], co[:, 2:3], co[:, 3:4]
+    power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+    with np.errstate(over="ignore"):
+        G = np.exp(np.minimum(power, 0.0))
+    raw = op * G
+    alpha = np.minimum(0.99, raw)
+    valid = (power <= 0.0) & (alpha >= 1.0 / 255.0) & inside[None, :]
+    a_eff = np.where(valid, alpha, 0.0)
+    t_after = np.cumprod(1.0 - a_eff, axis=0)                       # transmittance behind record k (no termination yet)
+    t_before = np.vstack([np.ones((1, px.size)), t_after[:-1]])
+    stop = valid & (t_after < t_cutoff)                             # GSCuda.cu:653: this record ends the pixel
+    has_stop = stop.any(axis=0)
+    stop_idx = np.where(has_stop, stop.argmax(axis=0), L)
+    k = np.arange(L)[:, None]
+    contrib = valid & (k < stop_idx[None, :])
+    final_t = np.where(has_stop, t_before[np.minimum(stop_idx, L - 1), np.arange(px.size)], t_after[-1])
+    w = np.where(contrib, alpha * t_before, 0.0)                    # weight of record k in the pixel
+    out = (col.T[:, :, None] * w[None]).sum(axis=1) + final_t[None, :] * bg[:, None]
+    n_contrib = np.where(contrib.any(axis=0), L - np.argmax(contrib[::-1], axis=0), 0)
+    # back to front: S_k = (everything behind record k) . dL/dC of the pixel
+    cg = col @ gp                                                   # [L, 256]
+    wc = w * cg
+    behind = (final_t * (bg @ gp))[None, :] + (wc.sum(axis=0)[None, :] - np.cumsum(wc, axis=0))
+    dL_dalpha = np.where(contrib, t_before * cg - behind / (1.0 - np.where(contrib, alpha, 0.0)), 0.0)
+    d_col = np.einsum("lp,cp->lc", w, gp)
+    free = contrib & ~(raw > 0.99)                                  # clamped alpha does not move with the parameters
+    dLa = np.where(free, dL_dalpha, 0.0)
+    d_op = (G * dLa).sum(axis=1)
+    dLp = op * G * dLa
+    d_conic = np.stack([(-0.5 * dx * dx * dLp).sum(1), (-dx * dy * dLp).sum(1), (-0.5 * dy * dy * dLp).sum(1)], 1)
+    d_mean = np.stack([((-A * dx - B * dy) * dLp).sum(1), ((-Cc * dy - B * dx) * dLp).sum(1)], 1)
+    return {"d_mean": d_mean, "d_conic": d_conic, "d_op": d_op, "d_col": d_col,
+            "out": np.where(inside[None, :], out, 0.0).reshape(3, TILE, TILE),
+            "final_t": np.where(inside, final_t, 0.0).reshape(TILE, TILE), "n_contrib": n_contrib.reshape(TILE, TILE)}
+
+
 # ---- cov3D -> conic (computeCov2D + inverse), and its gradient ------------------------------------
 def _jw(mean3, view, focal, tan_fovx, tan_fovy):
     """The 2 x 3 matrix P with cov2D = P Sigma P^T (GSCuda.cu:201-225). view: 16 floats, column-major."""

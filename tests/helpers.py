@@ -46,3 +46,35 @@ def image_report(got, exp, tol=1e-4):
     per_pixel = d.max(axis=0) if d.ndim == 3 else d
     bad = per_pixel > tol
     return float(d.max()), int(bad.sum()), per_pixel
+
+
+def check_backward_chain(got, g, scene, cam, w, h, ids):
+    """gsr_backward's per-Gaussian chain (conic -> cov3D -> scales / rotations, pixel centre and Jacobian -> means3D)
+    for the Gaussians `ids`, against oracle/backward_np.py fed with the GPU's own upstream gradients. `got`: the
+    gradient arrays (numpy, full size or indexable by id), `g`: geometry state arrays (cov3D), `scene`: host inputs.
+    Returns the largest expected magnitude of (dL_dcov3D, dL_dmeans3D, dL_dscales, dL_drotations)."""
+    from oracle import backward_np as B
+    focal = h / (2.0 * cam.tan_fovy)
+    m = len(ids)
+    exp_cov, exp_mean, exp_scale, exp_rot = np.zeros((m, 6)), np.zeros((m, 3)), np.zeros((m, 3)), np.zeros((m, 4))
+    for j, i in enumerate(ids):
+        c3 = g["cov3D"][i].astype(np.float64)
+        m3 = scene["means3D"][i, :3].astype(np.float64)
+        dconic = got["dL_dconic_opacity"][i, :3].astype(np.float64)
+        exp_cov[j] = B.conic_backward(c3, m3, cam.view, focal, cam.tan_fovx, cam.tan_fovy, dconic)
+        exp_mean[j] = (B.project_mean2d_backward(m3, cam.proj, w, h, got["dL_dmean2D"][i].astype(np.float64)) +
+                       B.conic_backward_mean(c3, m3, cam.view, focal, cam.tan_fovx, cam.tan_fovy, dconic))
+        exp_scale[j], exp_rot[j] = B.cov3d_backward(scene["scales"][i, :3], scene["rotations"][i], 1.0,
+                                                    got["dL_dcov3D"][i].astype(np.float64))
+    ids = np.asarray(ids)
+    # float32 chain through a 2x2 inverse: compare per Gaussian relative to its own magnitude
+    for name, e, gotv, tol in (("dL_dcov3D", exp_cov, got["dL_dcov3D"][ids], 2e-3),
+                               ("dL_dmeans3D", exp_mean, got["dL_dmeans3D"][ids][:, :3], 3e-3),
+                               ("dL_dscales", exp_scale, got["dL_dscales"][ids][:, :3], 3e-3),
+                               ("dL_drotations", exp_rot, got["dL_drotations"][ids], 3e-3)):
+        if m == 0:
+            continue
+        err = np.abs(gotv - e).max(1)
+        mag = np.maximum(np.abs(e).max(1), 1e-3 * np.abs(e).max())
+        assert (err <= tol * np.maximum(mag, 1e-30)).all(), (name, float((err / np.maximum(mag, 1e-30)).max()))
+    return [float(np.abs(e).max()) if m else 0.0 for e in (exp_cov, exp_mean, exp_scale, exp_rot)]

@@ -100,3 +100,33 @@ def test_input_chain_gradients_match_finite_differences():
                                   mean3, 1e-6)
         anm = B.conic_backward_mean(c3, mean3, cam.view, focal, cam.tan_fovx, cam.tan_fovy, gk)
         assert np.abs(anm - fdm).max() <= 2e-5 * max(1.0, np.abs(fdm).max()), (trial, anm, fdm)
+
+
+def test_vectorised_tile_backward_matches_the_per_pixel_loops():
+    """blend_tile_backward (what the full-size GPU test of BASELINE config 5 uses) against blend_forward / blend_backward."""
+    for seed in (0, 3, 5):
+        means, co, col, ranges, plist, w, h, bg, g_out = _toy(seed=seed, n=40, w=40, h=30)
+        co = co.copy()
+        co[:6, :3] *= 0.3                                   # enough coverage that some pixels terminate
+        out, ft, nc = B.blend_forward(means, co, col, ranges, plist, w, h, bg)
+        g = B.blend_backward(means, co, col, ranges, plist, nc, ft, w, h, bg, g_out)
+        gx, gy = (w + 15) // 16, (h + 15) // 16
+        acc = {k: np.zeros_like(v) for k, v in g.items()}
+        for ty in range(gy):
+            for tx in range(gx):
+                a, b = ranges[ty * gx + tx]
+                ids = plist[a:b]
+                tile_g = np.zeros((3, 16, 16))
+                y1, x1 = min(h, ty * 16 + 16), min(w, tx * 16 + 16)
+                tile_g[:, : y1 - ty * 16, : x1 - tx * 16] = g_out[:, ty * 16:y1, tx * 16:x1]
+                r = B.blend_tile_backward(means[ids], co[ids], col[ids], tx, ty, w, h, bg, tile_g)
+                np.add.at(acc["dL_dmean2D"], ids, r["d_mean"])
+                np.add.at(acc["dL_dconic"], ids, r["d_conic"])
+                np.add.at(acc["dL_dopacity"], ids, r["d_op"])
+                np.add.at(acc["dL_dcolor"], ids, r["d_col"])
+                assert np.abs(r["out"][:, : y1 - ty * 16, : x1 - tx * 16] - out[:, ty * 16:y1, tx * 16:x1]).max() <= 1e-12
+                assert np.array_equal(r["n_contrib"][: y1 - ty * 16, : x1 - tx * 16], nc[ty * 16:y1, tx * 16:x1])
+                assert np.abs(r["final_t"][: y1 - ty * 16, : x1 - tx * 16] - ft[ty * 16:y1, tx * 16:x1]).max() <= 1e-12
+        assert (nc < 40).any() and (ft < 0.01).any()
+        for k in g:
+            assert np.abs(acc[k] - g[k]).max() <= 1e-9 * max(1.0, np.abs(g[k]).max()), k
