@@ -27,6 +27,9 @@ GSR_FLAG_SEMANTICS_INRIA = 0x4
 GSR_FLAG_PLAN_SORT = 0x8
 GSR_FLAG_PLAN_BLOCKS = 0x10
 GSR_FLAG_OVERLAP_EMIT = 0x20
+GSR_FLAG_NO_SORTED_LISTS = 0x40
+GSR_PLAN_LISTS_SKIPPED = 0x100
+GSR_SH_LAYOUT_FILE, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 0, 1
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8
 STAGE_NAMES = ("preprocess", "scan", "depth_order", "duplicate", "sort_pass1", "sort_pass2", "ranges", "blend")
@@ -120,6 +123,8 @@ SIGNATURES = {
     "gsr_ply_parse_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "gsr_ply_activate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "gsr_ply_activate_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p]),
 }
 
 _lib = None

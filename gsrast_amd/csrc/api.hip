@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+
 #include "gsr_common.hpp"
 #include "radix_sort.hpp"
 
@@ -42,7 +44,8 @@ struct GeoScratch {
     char* scan_temp;          // partial sums of the two prefix scans
     uint32_t* depth_key;      // u32[N] depth bits or ~0 (written by preprocess)
     uint32_t* rect_idx;       // u32[N] packed band-clipped rectangle in index order (written by preprocess)
-    uint32_t* sort_info;      // [0] distinct top-byte digits of the visible depth keys, [1] visible Gaussians V
+    uint32_t* sort_info;      // [0] distinct top-byte digits of the visible depth keys, [1] visible Gaussians V,
+                              // [2..3] u64: sum of tilesTouched without the u32 wrap-around
     uint32_t* vis_partial;    // per 4096-key chunk: visible keys before it (compaction)
     uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
     uint32_t *a_k, *a_v;      // depth-sort ping
@@ -94,9 +97,12 @@ BinScratch carve_bin_scratch(char* base, size_t r) {
     return b;
 }
 
-// Pinned 4-byte landing zone for the numRendered read-back, one per host thread.
+// Pinned landing zone for the numRendered read-back plus the events / side stream of a call: one per host
+// thread AND device (events and streams belong to the device that was current when they were created).
 struct Readback {
-    uint32_t* host = nullptr;          // [0] numRendered, [1] / [2] onesweep error words, [8..] staged count
+    uint32_t* host = nullptr;          // [0] numRendered, [1] / [2] onesweep error words, [3] top digits, [4] V,
+                                       // [5..6] u64 un-wrapped instance count, [8..9] staged count
+    const void* lists_skipped = nullptr;   // `values` of the last call made with GSR_FLAG_NO_SORTED_LISTS under the block plan
     unsigned long long* staged_dev = nullptr;
     unsigned long long* staged_host = nullptr;
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
@@ -135,9 +141,23 @@ struct Readback {
         return GSR_OK;
     }
 };
-static thread_local Readback g_rb;
+static thread_local std::map<int, Readback> g_rb_by_device;
+static thread_local Readback* g_rb_last = nullptr;      // the state of this thread's most recent gsr_forward call
+
+// The calling thread's state for the CURRENT device.
+int current_readback(Readback*& out) {
+    int dev = 0;
+    GSR_HIP_TRY(hipGetDevice(&dev));
+    out = &g_rb_by_device[dev];
+    return GSR_OK;
+}
 
 }  // namespace
+
+bool forward_skipped_sorted_lists(const void* point_list) {
+    return g_rb_last && g_rb_last->lists_skipped && g_rb_last->lists_skipped == point_list;
+}
+
 }  // namespace gsr
 
 using namespace gsr;
@@ -224,7 +244,7 @@ int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const ui
 }
 
 int gsr_poll_async_error(void) {
-    if (g_rb.host && (g_rb.host[1] || g_rb.host[2])) return fail(GSR_ERR_INTERNAL);
+    if (g_rb_last && g_rb_last->host && (g_rb_last->host[1] || g_rb_last->host[2])) return fail(GSR_ERR_INTERNAL);
     return GSR_OK;
 }
 
@@ -250,6 +270,11 @@ int gsr_forward(gsr_forward_args* a) {
     if (inria && !a->cam_pos && !a->colors_precomp) return fail(GSR_ERR_INVALID_ARG);
     const int32_t* rects_in = inria ? nullptr : a->rects;      // upstream rectangles are radius-based
     int rc;
+    Readback* rbp = nullptr;
+    if ((rc = current_readback(rbp)) != GSR_OK) return fail(rc);
+    Readback& g_rb = *rbp;
+    g_rb_last = rbp;
+    g_rb.lists_skipped = nullptr;
     if ((rc = g_rb.ensure()) != GSR_OK) return fail(rc);
     if (profile && (rc = g_rb.ensure_events()) != GSR_OK) return fail(rc);
     if (count_staged && (rc = g_rb.ensure_staged()) != GSR_OK) return fail(rc);
@@ -301,7 +326,7 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
-                                   gs.scan_temp, stream));
+                                   gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2)));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
@@ -320,9 +345,14 @@ int gsr_forward(gsr_forward_args* a) {
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
     // move nothing.
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.sort_info, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.sort_info, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
+    // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
+    // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
+    // R-sized is touched (launch_sort_pairs draws the same line at n >= 0xFFFFFFFF).
+    const unsigned long long true_total = (unsigned long long)g_rb.host[5] | ((unsigned long long)g_rb.host[6] << 32);
+    if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
     const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
     GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, four_passes ? 4 : 3, stream));
@@ -379,7 +409,7 @@ int gsr_forward(gsr_forward_args* a) {
         // blend (bound by vector ALU work) on a second stream, and the caller's stream waits for it before
         // gsr_forward's work is complete: 5 % shorter frames, but each of the two kernels runs ~20 % longer
         // while they share the chip, so per-kernel times are no longer those of the kernels alone.
-        const bool serial = !(a->flags & GSR_FLAG_OVERLAP_EMIT);
+        const bool serial = !(a->flags & GSR_FLAG_OVERLAP_EMIT) || (a->flags & GSR_FLAG_NO_SORTED_LISTS);
         hipStream_t emit_stream = stream;
         if (!serial) {
             GSR_STEP(g_rb.ensure_side());
@@ -388,12 +418,20 @@ int gsr_forward(gsr_forward_args* a) {
             emit_stream = g_rb.side;
             forked = true;
         }
-        if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
-        GSR_STEP(launch_block_emit(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
-                                   bin.sorting_space, bin.keys, bin.values, emit_stream));
-        if (profile) {
-            GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], emit_stream));
-            g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
+        // GSR_FLAG_NO_SORTED_LISTS: this plan's blend reads the block lists, and no caller of the reference reads
+        // BinningState (GSGaussians.cpp:214-219 maps GeometryState only): a forward-only caller may skip the 12 R
+        // bytes of sorted keys / values altogether. keys / values are then left unwritten.
+        if (a->flags & GSR_FLAG_NO_SORTED_LISTS) {
+            g_rb.lists_skipped = bin.values;
+            a->plan_used |= GSR_PLAN_LISTS_SKIPPED;
+        } else {
+            if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
+            GSR_STEP(launch_block_emit(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
+                                       bin.sorting_space, bin.keys, bin.values, emit_stream));
+            if (profile) {
+                GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], emit_stream));
+                g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
+            }
         }
         if (forked) GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
     } else if (xy_plan) {

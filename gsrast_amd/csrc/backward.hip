@@ -359,6 +359,7 @@ static int backward_impl(gsr_backward_args* a) {
     if (a->dL_dmeans3D && !a->proj_matrix) return GSR_ERR_INVALID_ARG;
     if ((a->dL_dscales || a->dL_drotations) && (!a->scales || !a->rotations || !a->dL_dscales)) return GSR_ERR_INVALID_ARG;
     if (a->flags & GSR_FLAG_SEMANTICS_INRIA) return GSR_ERR_INVALID_ARG;      // gscuda semantics only
+    if (forward_skipped_sorted_lists(a->point_list)) return GSR_ERR_INVALID_ARG;   // the forward call left the sorted lists unwritten
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
     if (profile && !g_bw_ev[0])

@@ -11,8 +11,8 @@
 //          multiset of pairs as the reference's, in depth order rather than index order.
 //      (2) A Gaussian covering more than kOwnLaneMax tiles is expanded by its whole wave, so
 //          a full-height rectangle becomes coalesced 512-byte key stores.
-//  tile_ranges_kernel — reference GSCuda.cu:504-538 (identifyTileRanges), including the
-//      placement of the "last element closes its tile" test inside the else branch.
+//  tile_ranges_search_kernel — reference GSCuda.cu:504-538 (identifyTileRanges), including the
+//      effect of the "last element closes its tile" test sitting inside the else branch.
 #include <stdlib.h>
 
 #include "gsr_common.hpp"
@@ -26,12 +26,8 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, ma
 
 __device__ __forceinline__ void emit(uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t pos,
                                      uint32_t tile, uint32_t depth_bits, uint32_t idx) {
-#ifndef GSR_EMIT_NO_KEYS
     keys[pos] = ((uint64_t)tile << 32) | (uint64_t)depth_bits;
-#endif
-#ifndef GSR_EMIT_NO_VALUES
     values[pos] = idx;
-#endif
 }
 
 // Tiles covered by each depth-ordered Gaussian (0 for culled ones, whose depth key is ~0).
@@ -125,26 +121,10 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int n, const uint32_t* _
     }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys, size_t n,
-                                                          uint2* __restrict__ ranges) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
-    if (idx == 0) {
-        ranges[cur].x = 0;
-    } else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
-        if (prev != cur) {
-            ranges[prev].y = (uint32_t)idx;
-            ranges[cur].x = (uint32_t)idx;
-        }
-        if (idx == n - 1) ranges[cur].y = (uint32_t)n;
-    }
-}
-
-// Same result as tile_ranges_kernel without streaming the R keys: thread t finds the first sorted
+// identifyTileRanges (GSCuda.cu:504-538) without streaming the R keys: thread t finds the first sorted
 // key of tile t and of tile t + 1 by two interleaved binary searches (2 x ~log2 R dependent loads).
-// Tiles that own no key keep (0, 0) and the R == 1 quirk (the lone tile is never closed) is kept.
+// Tiles that own no key get (0, 0) (the reference's memset) and the R == 1 quirk is kept: the lone tile is
+// never closed there, because the "last element closes its tile" test sits inside the else branch.
 __global__ __launch_bounds__(256) void tile_ranges_search_kernel(const uint64_t* __restrict__ keys, uint32_t n,
                                                                  uint2* __restrict__ ranges, uint32_t num_tiles,
                                                                  bool close_single) {
@@ -189,18 +169,10 @@ int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num
         GSR_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, stream));
         return GSR_OK;
     }
-    // One thread per tile beats one thread per key as soon as there are more keys than a few per tile.
-    if ((n >= (size_t)num_tiles * 8 || close_single) && n < 0xFFFFFFFFull) {
-        hipLaunchKernelGGL(tile_ranges_search_kernel, dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, stream, keys,
-                           (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles, close_single);
-        GSR_LAUNCH_CHECK("tile_ranges_search_kernel");
-        return GSR_OK;
-    }
-    GSR_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, stream));
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks), dim3(256), 0, stream, keys, n,
-                       reinterpret_cast<uint2*>(ranges));
-    GSR_LAUNCH_CHECK("tile_ranges_kernel");
+    if (n >= 0xFFFFFFFFull) return GSR_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(tile_ranges_search_kernel, dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, stream, keys,
+                       (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles, close_single);
+    GSR_LAUNCH_CHECK("tile_ranges_search_kernel");
     return GSR_OK;
 }
 

@@ -1,6 +1,7 @@
-// Per-tile front-to-back alpha blend. One 16x16 screen tile per 256-lane workgroup
-// (4 wave64, each wave a 16x4 pixel strip), Gaussian records pulled from HBM in batches
-// of 256 into LDS and composited with per-wave early-outs decided by wave64 __ballot.
+// Per-tile front-to-back alpha blend of the sort plan: one 16x16 screen tile per wavefront (four pixels per
+// lane), Gaussian records pulled from HBM 64 at a time into wave-private LDS and composited with early-outs
+// decided by wave64 __ballot. (The block plan's blend, fed from the block lists, is in blockbin.hip; both
+// share blend_core.hpp.)
 //
 // Semantics follow reference apps/gsrast/gscuda/GSCuda.cu:543-677 (renderCUDA):
 //   integer pixel centres (no +0.5), power = -0.5(A dx^2 + C dy^2) - B dx dy, skip power > 0,
@@ -8,10 +9,8 @@
 //   C += rgb * alpha * T, out = C + T * background, finalT, nContrib = index (1-based) of the
 //   last contributing record. The batch size (256) and the "whole tile done" test at the top
 //   of each batch are the reference's, so the number of records staged (R_f) is identical.
-// Differences that do not change any pixel: a wave whose 64 pixels are all done skips the
-// batch's arithmetic; a record no lane of the wave can see (power > 0 or below the 1/255
-// cut for every lane) is skipped after the power evaluation by one ballot.
-#include <stdlib.h>
+// Differences that do not change any pixel: a record no lane of the wave can see (power > 0 or below the
+// 1/255 cut for every lane) is skipped after the power evaluation by one ballot.
 
 #include "blend_core.hpp"
 
@@ -33,79 +32,6 @@ struct BlendParams {
     FrameDims dims;
     int num_tiles;                 // tiles in [row_begin,row_end)
 };
-
-__global__ __launch_bounds__(256) void blend_kernel(const BlendParams p) {
-    __shared__ float2 s_xy[kBatch];
-    __shared__ float4 s_co[kBatch];
-    __shared__ float4 s_rgb[kBatch];
-
-    const int tile_local = xcd_tile_of_block(blockIdx.x, p.num_tiles);
-    const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
-    const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
-    const int px = tx * kTile + (threadIdx.x & 15), py = ty * kTile + (threadIdx.x >> 4);
-    const bool inside = px < p.dims.width && py < p.dims.height;
-    const float fx = (float)px, fy = (float)py;
-
-    const uint2 range = p.ranges[tile];
-    const int rounds = (int)((range.y - range.x + kBatch - 1) / kBatch);
-    int work = (int)(range.y - range.x);
-
-    bool done = !inside;
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    uint32_t last = 0;
-    unsigned long long staged = 0;
-
-    for (int i = 0; i < rounds; ++i, work -= kBatch) {
-        if (__syncthreads_count(done) == kBatch) break;
-        const int cnt = min(kBatch, work);
-        if ((int)threadIdx.x < cnt) {
-            const uint32_t id = p.point_list[range.x + (uint32_t)(i * kBatch) + threadIdx.x];
-            s_xy[threadIdx.x] = p.means2D[id];
-            s_co[threadIdx.x] = p.conic_opacity[id];
-            const float* c = p.colors + 3 * (size_t)id;
-            s_rgb[threadIdx.x] = make_float4(c[0], c[1], c[2], 0.0f);
-        }
-        staged += (unsigned long long)cnt;
-        __syncthreads();
-        if (__ballot(!done) == 0ull) continue;          // this wave's strip is finished
-        const uint32_t first = (uint32_t)(i * kBatch);
-        for (int j = 0; j < cnt; ++j) {
-            const float2 xy = s_xy[j];
-            const float4 co = s_co[j];
-            const float dx = xy.x - fx, dy = xy.y - fy;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            // co.w (opacity) is wave-uniform; the floor only holds for opacity <= 1.
-            const bool candidate = !done && !(power > 0.0f) && (power >= kPowerFloor || co.w > 1.0f);
-            if (__ballot(candidate) == 0ull) continue;
-            const float alpha = fminf(0.99f, co.w * __expf(power));
-            const bool live = candidate && !(alpha < 1.0f / 255.0f);
-            const float test = T * (1.0f - alpha);
-            const bool stop = live && test < p.t_cutoff;
-            if (live && !stop) {
-                const float4 c = s_rgb[j];
-                cr += c.x * alpha * T;
-                cg += c.y * alpha * T;
-                cb += c.z * alpha * T;
-                T = test;
-                last = first + (uint32_t)j + 1u;
-            }
-            done = done || stop;
-            if (stop && __ballot(!done) == 0ull) break;
-        }
-    }
-
-    if (inside) {
-        const size_t plane = (size_t)p.dims.width * (size_t)p.dims.height;
-        const size_t pid = (size_t)py * (size_t)p.dims.width + (size_t)px;
-        p.final_t[pid] = T;
-        p.n_contrib[pid] = last;
-        p.out_color[pid] = cr + T * p.background[0];
-        p.out_color[pid + plane] = cg + T * p.background[1];
-        p.out_color[pid + 2 * plane] = cb + T * p.background[2];
-    }
-    if (p.staged_counter && threadIdx.x == 0) atomicAdd(p.staged_counter, staged);
-}
-
 
 // ---- one wave per tile, four pixels per lane ------------------------------------------------
 // Lane l owns pixels (x = l & 15, y = (l >> 4) + 4 k), k = 0..3, so slot k of the wave is the
@@ -175,13 +101,8 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     p.dims = d;
     p.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
     if (p.num_tiles <= 0) return GSR_OK;
-    // GSR_BLEND=quad selects the 256-lane kernel (one pixel per lane), kept for A/B measurements.
-    static const bool quad = [] { const char* e = getenv("GSR_BLEND"); return e && e[0] == 'q'; }();
-    if (quad)
-        hipLaunchKernelGGL(blend_kernel, dim3((unsigned)p.num_tiles), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)p.num_tiles), dim3(kWave), 0, stream, p);
-    GSR_LAUNCH_CHECK("blend kernel");
+    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)p.num_tiles), dim3(kWave), 0, stream, p);
+    GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;
 }
 

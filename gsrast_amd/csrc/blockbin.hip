@@ -33,10 +33,7 @@ namespace {
 constexpr int kBW = 8, kBH = 8;          // tiles per block: one lane per tile
 constexpr int kCoarse = 1024;            // Gaussians per workgroup of the coarse passes ...
 constexpr int kCoarseSmall = 512;        // ... with more than 256 blocks (4K): half the LDS mask table, two workgroups per CU
-#ifndef GSR_UNIT
-#define GSR_UNIT 2048
-#endif
-constexpr int kUnit = GSR_UNIT;          // block-list entries per emission unit
+constexpr int kUnit = 2048;              // block-list entries per emission unit
 constexpr int kScanRows = 64;            // table rows per workgroup of the block scan
 constexpr int kMaxBlocks = 512;          // 8 x 8-tile blocks per frame (4K: 30 x 17 = 510)
 
@@ -705,10 +702,8 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
                       const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
-#ifndef GSR_EMIT_WGS_PER_CU
-#define GSR_EMIT_WGS_PER_CU 2
-#endif
-    const uint32_t emit_wgs = std::min<uint32_t>((t.max_units + kEmitWaves - 1) / kEmitWaves, 256u * GSR_EMIT_WGS_PER_CU);
+    // two workgroups (8 waves) per CU: 12 or 16 waves per CU measured the same, the write path is the limit
+    const uint32_t emit_wgs = std::min<uint32_t>((t.max_units + kEmitWaves - 1) / kEmitWaves, 256u * 2u);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, t.meta, t.nb, t.nbx, grid_x, grid_y,
                        ent_rd, ent_idx, t.unit_masks, t.cnt, t.tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");

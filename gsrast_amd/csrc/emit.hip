@@ -26,10 +26,7 @@ namespace {
 
 constexpr int kChunk = 256;        // Gaussians per workgroup
 constexpr int kRowsPerBlock = 256; // table rows per workgroup of the column scan
-#ifndef GSR_EMIT_SMALL
-#define GSR_EMIT_SMALL 8
-#endif
-constexpr int kSmallRect = GSR_EMIT_SMALL;   // rectangles up to this many tiles are written by their own lane
+constexpr int kSmallRect = 8;   // rectangles up to this many tiles are written by their own lane
 
 // Two consecutive rows of one column run in one go: a 16-byte key store and an 8-byte value store.
 // The destination is only 8-byte (keys) / 4-byte (values) aligned; gfx950 under HSA runs with

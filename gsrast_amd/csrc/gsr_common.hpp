@@ -34,6 +34,10 @@ int record_error(int code);
         }                                                   \
     } while (0)
 
+// True if `point_list` is the `values` array of this thread's last gsr_forward call and that call skipped the
+// sorted lists (GSR_FLAG_NO_SORTED_LISTS): gsr_backward refuses such a state.
+bool forward_skipped_sorted_lists(const void* point_list);
+
 struct FrameDims {
     int width, height;
     int grid_x, grid_y;            // tile grid of the whole image
@@ -47,7 +51,8 @@ int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, in
 int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
                             uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
 
-int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream);
+int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
+                          unsigned long long* total64 = nullptr);
 size_t scan_temp_bytes(size_t n);
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,

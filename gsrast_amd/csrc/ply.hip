@@ -24,7 +24,7 @@ constexpr int kWaveFloats = kWave * kPlyFloats;  // 3968 floats = 992 float4 per
 
 __global__ __launch_bounds__(256) void ply_activate_kernel(const float* __restrict__ raw, int n, float4* __restrict__ means3D,
                                                            float4* __restrict__ scales, float4* __restrict__ rotations,
-                                                           float* __restrict__ opacities, float* __restrict__ shs) {
+                                                           float* __restrict__ opacities, float* __restrict__ shs, int sh_layout) {
     __shared__ float lds[4][kWaveFloats];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const long long first = ((long long)blockIdx.x * 4 + wave) * kWave;     // first record of this wave
@@ -60,7 +60,12 @@ __global__ __launch_bounds__(256) void ply_activate_kernel(const float* __restri
     float* sh_out = shs + first * 48;
     for (int f = lane; f < count * 48; f += kWave) {
         const int s = f / 48, c = f - s * 48;
-        sh_out[f] = w[s * kPlyFloats + 6 + c];
+        int from = c;                                   // GSR_SH_LAYOUT_FILE: f_dc_0..2, f_rest_0..44 as they lie in the file
+        if (sh_layout == GSR_SH_LAYOUT_COEFFICIENT_MAJOR && c >= 3) {
+            const int k = c / 3, ch = c - 3 * k;        // coefficient 1..15, channel: f_rest is channel-major in the file
+            from = 3 + ch * 15 + (k - 1);
+        }
+        sh_out[f] = w[s * kPlyFloats + 6 + from];
     }
 }
 
@@ -97,12 +102,18 @@ int gsr_ply_parse_header(const char* path, int* num_splats, long long* data_offs
 
 int gsr_ply_activate(const float* raw_device, int n, float* means3D, float* scales, float* rotations, float* opacities,
                      float* shs, void* stream) {
+    return gsr_ply_activate_layout(raw_device, n, means3D, scales, rotations, opacities, shs, GSR_SH_LAYOUT_FILE, stream);
+}
+
+int gsr_ply_activate_layout(const float* raw_device, int n, float* means3D, float* scales, float* rotations, float* opacities,
+                            float* shs, int sh_layout, void* stream) {
     if (n <= 0) return GSR_OK;
     if (!raw_device || !means3D || !scales || !rotations || !opacities || !shs) return GSR_ERR_INVALID_ARG;
+    if (sh_layout != GSR_SH_LAYOUT_FILE && sh_layout != GSR_SH_LAYOUT_COEFFICIENT_MAJOR) return GSR_ERR_INVALID_ARG;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(ply_activate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, raw_device, n,
                        reinterpret_cast<float4*>(means3D), reinterpret_cast<float4*>(scales),
-                       reinterpret_cast<float4*>(rotations), opacities, shs);
+                       reinterpret_cast<float4*>(rotations), opacities, shs, sh_layout);
     GSR_LAUNCH_CHECK("ply_activate_kernel");
     return GSR_OK;
 }

@@ -18,8 +18,6 @@
 // loads (data-is-the-flag granules, cdna_hip_programming.md Guideline 16 R2); no payload is
 // exchanged inside the launch, so no fences are needed. Tickets make predecessors resident
 // before their successors; every spin is bounded and raises an error word instead of hanging.
-#include <stdlib.h>
-
 #include "gsr_common.hpp"
 #include "radix_sort.hpp"
 
@@ -27,26 +25,14 @@ namespace gsr {
 int sweep_clear(const SweepScratch& sc, uint32_t n, uint32_t nbins, hipStream_t stream);
 namespace {
 
-#ifndef GSR_SWEEP_THREADS
-#define GSR_SWEEP_THREADS 512
-#endif
-#ifndef GSR_SWEEP_ITEMS
-#define GSR_SWEEP_ITEMS 16
-#endif
-#ifndef GSR_SWEEP_MIN_WAVES
-#define GSR_SWEEP_MIN_WAVES 1
-#endif
-constexpr int kThreads = GSR_SWEEP_THREADS;
+constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kItems = GSR_SWEEP_ITEMS;
+constexpr int kItems = 16;                              // keys per lane (measured: 8192-key tiles beat 4096 and 2048)
 constexpr int kSortTile = kThreads * kItems;            // keys per workgroup
 constexpr int kWaveSpan = kWave * kItems;
 // The ranked tile leaves through LDS in kStageRounds slices of kStageSlots slots: a smaller LDS
 // footprint per workgroup buys more resident workgroups per CU (the pass is latency-bound).
-#ifndef GSR_SWEEP_STAGE_ROUNDS
-#define GSR_SWEEP_STAGE_ROUNDS 2
-#endif
-constexpr int kStageRounds = GSR_SWEEP_STAGE_ROUNDS;
+constexpr int kStageRounds = 2;
 constexpr int kStageSlots = kSortTile / kStageRounds;
 static_assert(kItems % kStageRounds == 0, "items per lane must split evenly over the staging rounds");
 
@@ -54,13 +40,8 @@ constexpr unsigned long long kFlagAggregate = 1ull << 62;
 constexpr unsigned long long kFlagPrefix = 2ull << 62;
 constexpr unsigned long long kValueMask = (1ull << 62) - 1ull;
 constexpr uint32_t kSpinLimit = 1u << 22;
-#ifndef GSR_LOOK_WINDOW
-#define GSR_LOOK_WINDOW 4
-#endif
-constexpr int kLookWindow = GSR_LOOK_WINDOW;
-#ifndef GSR_LOOK_LANES
-#define GSR_LOOK_LANES 1
-#endif
+constexpr int kLookWindow = 4;                          // predecessors' status words read per look-back round
+constexpr int kLookLanes = 1;                           // lanes sharing one digit's look-back
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t digit_of(KeyT key, const DigitSpec& s) {
@@ -112,23 +93,6 @@ __global__ __launch_bounds__(kThreads) void histogram_bits_kernel(const KeyT* __
 }
 
 // ---- one digit pass ----------------------------------------------------------------------
-// Diagnostic build only (-DGSR_SWEEP_STAMPS): lane 0 of every workgroup keeps the shader-clock
-// cycles of each phase and stores them once, at exit, into its own 128-byte slot of a debug
-// buffer placed behind the status words (memory no other code reads). No stamp executes in the
-// product build.
-#ifdef GSR_SWEEP_STAMPS
-#define GSR_STAMP(i)                                                                               \
-    do {                                                                                           \
-        if (threadIdx.x == 0) {                                                                    \
-            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
-            dbg_[i] = now_ - stamp_;                                                               \
-            stamp_ = now_;                                                                         \
-        }                                                                                          \
-    } while (0)
-#else
-#define GSR_STAMP(i) do { } while (0)
-#endif
-
 // Look-back state of one digit group, resumable so that its round trips can be interleaved
 // with the ranking and staging work of the tile.
 template <int RADIX, int LPD>
@@ -193,14 +157,14 @@ struct LookBack {
 };
 
 template <typename KeyT, int BITS>
-__global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             uint32_t n, const DigitSpec spec,
                                                             const uint32_t* __restrict__ digit_hist,
                                                             unsigned long long* status, uint32_t* ticket,
                                                             uint32_t* error_word) {
     constexpr int RADIX = 1 << BITS;
-    constexpr int kLanesPerDigit = (kThreads / RADIX) < GSR_LOOK_LANES ? (kThreads / RADIX) : GSR_LOOK_LANES;
+    constexpr int kLanesPerDigit = (kThreads / RADIX) < kLookLanes ? (kThreads / RADIX) : kLookLanes;
     __shared__ uint32_t wave_hist[kWaves][RADIX];
     __shared__ uint32_t tile_hist[RADIX];        // digit counts of the tile (early, by LDS atomics)
     __shared__ uint32_t run_start[RADIX];        // first slot of digit d inside the ranked tile
@@ -210,18 +174,8 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     __shared__ uint32_t s_tile, s_fail;
     __shared__ KeyT stage_keys[kStageSlots];
     __shared__ uint32_t stage_vals[kStageSlots];
-#ifdef GSR_SWEEP_LDS_PAD
-    __shared__ uint32_t occupancy_pad[GSR_SWEEP_LDS_PAD / 4];   // tuning experiment: caps workgroups per CU
-    if (threadIdx.x == 0 && n == 0xFFFFFFFFu) occupancy_pad[0] = 1;
-#endif
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#ifdef GSR_SWEEP_STAMPS
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-    unsigned long long dbg_[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dbg_[i] = 0;
-#endif
     if (threadIdx.x == 0) {
         s_tile = atomicAdd(ticket, 1u);
         s_fail = 0;
@@ -236,7 +190,6 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     const uint32_t tile_base = tile * (uint32_t)kSortTile;
     if (tile_base >= n) return;                  // cannot happen with grid = ceil(n / tile)
     const uint32_t valid = min((uint32_t)kSortTile, n - tile_base);
-    GSR_STAMP(0);   // ticket
 
     // Issue every global load of the tile first (keys AND values): the HBM latency is paid once.
     KeyT key[kItems];
@@ -271,7 +224,6 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         if (threadIdx.x < RADIX) global_start[threadIdx.x] = wbase + incl - hist_c;
         __syncthreads();
     }
-    GSR_STAMP(1);   // loads issued + digit-base scan
 
     // Stable ranks: wave64 match groups + per-wave LDS counters. Per digit bit one ballot and, per
     // 32-lane half, one xor + or: a lane keeps the lanes whose bit equals its own. Every lane of a
@@ -295,7 +247,6 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         if (below == 0) wave_hist[wave][d] = prior + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
         rd[i] = (d << 16) | (prior + below);
     }
-    GSR_STAMP(2);   // key-load wait + ranking
     __syncthreads();
 
     // per digit: exclusive offsets across waves (-> the tile's count), publish it, start the
@@ -305,9 +256,6 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
     lb.sub = threadIdx.x % kLanesPerDigit;
     lb.t = tile;
     lb.active = tile != 0 && threadIdx.x < RADIX * kLanesPerDigit && (uint32_t)lb.d < spec.nbins;
-#ifdef GSR_SWEEP_NO_LOOKBACK
-    lb.active = false;       // timing experiment only: every tile scatters from the digit base (wrong output)
-#endif
     {
         uint32_t acc = 0;
         if (threadIdx.x < RADIX) {
@@ -341,21 +289,16 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
         if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - acc;
     }
     __syncthreads();
-    GSR_STAMP(3);   // totals + publish + scans
     // final slot of every key inside the ranked tile (kept in the low half of rd)
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t d = rd[i] >> 16;
         rd[i] = (rd[i] & 0xFFFF0000u) | ((rd[i] & 0xFFFFu) + run_start[d] + wave_hist[wave][d]);
     }
-    GSR_STAMP(4);   // scans + slots
 
     if (lb.active) {
         while (!lb.found) {
             const uint32_t used = lb.consume(lane);
-#ifdef GSR_SWEEP_STAMPS
-            if (threadIdx.x == 0) { dbg_[12] += 1; dbg_[13] += used; if (!used) dbg_[14] += 1; }
-#endif
             if (lb.found) break;
             if (used == 0) {
                 if (++lb.spins > kSpinLimit) { s_fail = 1; atomicExch(error_word, 1u); break; }
@@ -369,9 +312,7 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
             global_start[lb.d] += (uint32_t)lb.excl;
         }
     }
-    GSR_STAMP(5);   // rest of the look-back of digit 0
     __syncthreads();
-    GSR_STAMP(6);   // barrier: slowest digit's look-back
     if (s_fail) return;
     if (threadIdx.x < RADIX) run_delta[threadIdx.x] = global_start[threadIdx.x] - run_start[threadIdx.x];
     __syncthreads();
@@ -405,14 +346,6 @@ __global__ __launch_bounds__(kThreads, GSR_SWEEP_MIN_WAVES) void onesweep_kernel
             }
         }
     }
-    GSR_STAMP(7);   // write-out issued
-#ifdef GSR_SWEEP_STAMPS
-    if (threadIdx.x == 0) {
-        unsigned long long* slot = status + (size_t)gridDim.x * 256 + (size_t)tile * 16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) slot[i] += dbg_[i];
-    }
-#endif
 }
 
 inline int radix_bits_for(uint32_t nbins) {
@@ -432,11 +365,8 @@ int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, ui
         const int rc = sweep_clear(sc, n, spec.nbins, stream);
         if (rc != GSR_OK) return rc;
     }
-    // Tuning aid: GSR_SWEEP_DYN_LDS=<bytes> adds unused dynamic LDS to every workgroup, which lowers the
-    // number of workgroups a CU can hold without changing the code (occupancy sensitivity runs).
-    static const unsigned dyn_lds = [] { const char* e = getenv("GSR_SWEEP_DYN_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
 #define GSR_SWEEP(B)                                                                                              \
-    hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), dyn_lds, stream, keys_in, vals_in, \
+    hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, \
                        keys_out, vals_out, n, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
     switch (bits) {
         case 4: GSR_SWEEP(4); break;
@@ -454,15 +384,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
-#ifdef GSR_SWEEP_STAMPS
-constexpr size_t kDebugPerTile = 128;
-#else
-constexpr size_t kDebugPerTile = 0;
-#endif
-
 size_t sweep_scratch_bytes(size_t n) {
     const size_t tiles = (n + kSortTile - 1) / kSortTile;
-    return align_up(tiles * (256 * sizeof(unsigned long long) + kDebugPerTile), 128) + 128 /*ticket*/ + 128 /*error*/ +
+    return align_up(tiles * 256 * sizeof(unsigned long long), 128) + 128 /*ticket*/ + 128 /*error*/ +
            align_up(8 * 256 * sizeof(uint32_t), 128);
 }
 
@@ -472,7 +396,7 @@ SweepScratch carve_sweep_scratch(char* base, size_t n) {
     size_t off = 0;
     s.ticket = reinterpret_cast<uint32_t*>(base + off); off += 128;     // directly in front of the status
     s.status = reinterpret_cast<unsigned long long*>(base + off);      // words: one clear covers both
-    off += align_up(tiles * (256 * sizeof(unsigned long long) + kDebugPerTile), 128);
+    off += align_up(tiles * 256 * sizeof(unsigned long long), 128);
     s.error_word = reinterpret_cast<uint32_t*>(base + off); off += 128;
     s.hist = reinterpret_cast<uint32_t*>(base + off); off += align_up(8 * 256 * sizeof(uint32_t), 128);
     return s;
@@ -523,9 +447,11 @@ int histogram_bits_u64(const uint64_t* keys, size_t n, int begin_bit, int end_bi
 // ---- depth order: stable sort of N u32 keys carrying their own index ---------------------
 // in -> a -> b -> a -> b : the result (sorted keys, original indices) is in (b_k, b_v).
 namespace {
-// How many distinct digits, other than 255, the top byte of the keys takes (one thread per digit).
+// How many distinct digits the top byte of the visible keys takes (one thread per digit; culled Gaussians'
+// 0xFFFFFFFF sentinels are compacted away before the histogram, so digit 255 is a real depth — the top byte
+// of a negative NaN, which passes the reference's frustum test — and counts like any other).
 __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __restrict__ hist_top, uint32_t* __restrict__ out) {
-    const int c = __syncthreads_count(threadIdx.x < 255 && hist_top[threadIdx.x] != 0u);
+    const int c = __syncthreads_count(hist_top[threadIdx.x] != 0u);
     if (threadIdx.x == 0) *out = (uint32_t)c;
 }
 

@@ -7,7 +7,8 @@
 //   2. partial_scan: one workgroup turns partial[] into its exclusive prefix
 //   3. tile_scan   : tile t re-reads its elements, scans them in registers + wave shuffles,
 //                    adds partial[t] and stores
-// Integer wrap-around is that of u32 addition, as in the reference.
+// Integer wrap-around is that of u32 addition, as in the reference; the un-wrapped 64-bit total is available
+// on request (gsr_forward refuses frames whose instance count does not fit the u32 offsets).
 #include "gsr_common.hpp"
 
 namespace gsr {
@@ -83,16 +84,35 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
     }
 }
 
-__global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict__ partial, size_t tiles) {
+// total64 (may be null): the sum of all elements WITHOUT the u32 wrap-around, so that the caller can tell
+// whether the scan's last element is the true total (a tile's own sum cannot wrap: 4096 elements of at most
+// 2^20 tiles each).
+__global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict__ partial, size_t tiles,
+                                                            unsigned long long* __restrict__ total64) {
     __shared__ uint32_t wave_sums[1024 / kWave];
+    __shared__ unsigned long long wide_sums[1024 / kWave];
     uint32_t carry = 0;
+    unsigned long long wide = 0;
     for (size_t base = 0; base < tiles; base += 1024) {
         const size_t i = base + threadIdx.x;
         const uint32_t v = (i < tiles) ? partial[i] : 0u;
+        wide += v;
         uint32_t total;
         const uint32_t excl = block_exclusive_scan<1024>(v, wave_sums, total);
         if (i < tiles) partial[i] = carry + excl;
         carry += total;
+    }
+    if (total64) {
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) wide += __shfl_down(wide, off, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) wide_sums[threadIdx.x / kWave] = wide;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+#pragma unroll
+            for (int w = 0; w < 1024 / kWave; ++w) t += wide_sums[w];
+            *total64 = t;
+        }
     }
 }
 
@@ -136,13 +156,14 @@ size_t scan_temp_bytes(size_t n) {
     return ((tiles + 1) * sizeof(uint32_t) + 127) / 128 * 128;
 }
 
-int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream) {
+int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
+                          unsigned long long* total64) {
     if (n == 0) return GSR_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
     hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial);
     GSR_LAUNCH_CHECK("tile_reduce_kernel");
-    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles);
+    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64);
     GSR_LAUNCH_CHECK("partial_scan_kernel");
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, partial);
     GSR_LAUNCH_CHECK("tile_scan_kernel");

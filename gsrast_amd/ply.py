@@ -27,9 +27,14 @@ def parse_header(path: str) -> tuple[int, int]:
     return int(n.value), int(off.value)
 
 
-def load_ply(path: str, device="cuda:0") -> dict:
+def load_ply(path: str, device="cuda:0", sh_layout: str = "file") -> dict:
     """Loads a scene to the device in the layout `SplatRasterizer.configure_from_scene` takes.
-    Also returns the bounding box and centre the reference computes (SplatData.cpp:55-62)."""
+    Also returns the bounding box and centre the reference computes (SplatData.cpp:55-62).
+
+    sh_layout: "file" keeps the 48 SH floats as they lie in the file (f_dc, then f_rest channel-major) — what the
+    reference does, and all its DC-only colour needs; "coefficient_major" transposes f_rest to [16][3], the layout
+    `draw(semantics="inria", sh_degree >= 1)` reads (GSR_SH_LAYOUT_*, include/gsrast_amd.h)."""
+    layout = {"file": _capi.GSR_SH_LAYOUT_FILE, "coefficient_major": _capi.GSR_SH_LAYOUT_COEFFICIENT_MAJOR}[sh_layout]
     n, off = parse_header(path)
     raw = np.fromfile(path, dtype="<f4", offset=off, count=n * RECORD_FLOATS)
     if raw.size < n * RECORD_FLOATS:                  # the reference rejects a short file (:147-152)
@@ -44,10 +49,11 @@ def load_ply(path: str, device="cuda:0") -> dict:
         "shs": torch.empty((n, 48), dtype=torch.float32, device=dev),
     }
     with torch.cuda.device(dev):
-        rc = _capi.lib().gsr_ply_activate(raw_dev.data_ptr(), n, out["means3D"].data_ptr(), out["scales"].data_ptr(),
-                                          out["rotations"].data_ptr(), out["opacities"].data_ptr(), out["shs"].data_ptr(),
-                                          torch.cuda.current_stream(dev).cuda_stream)
-    _capi.check(rc, "gsr_ply_activate")
+        rc = _capi.lib().gsr_ply_activate_layout(raw_dev.data_ptr(), n, out["means3D"].data_ptr(), out["scales"].data_ptr(),
+                                                 out["rotations"].data_ptr(), out["opacities"].data_ptr(),
+                                                 out["shs"].data_ptr(), layout, torch.cuda.current_stream(dev).cuda_stream)
+    _capi.check(rc, "gsr_ply_activate_layout")
+    out["sh_layout"] = sh_layout
     torch.cuda.current_stream(dev).synchronize()
     pos = out["means3D"][:, :3]
     out["bbox_min"], out["bbox_max"] = pos.min(0).values, pos.max(0).values

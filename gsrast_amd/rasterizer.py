@@ -119,13 +119,15 @@ class SplatRasterizer:
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
              sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
-             overlap_emit: bool = False) -> torch.Tensor:
+             overlap_emit: bool = False, sorted_lists: bool = True) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
         rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3].
         plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan.
-        overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: emission on a second stream beside the blend)."""
+        overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: emission on a second stream beside the blend).
+        sorted_lists=False: GSR_FLAG_NO_SORTED_LISTS (forward-only callers; last_lists_written tells whether the
+        binning chunk holds the sorted keys / values of this call)."""
         if cam is not None:
             self.set_camera(cam)
         a = _capi.ForwardArgs()
@@ -135,7 +137,8 @@ class SplatRasterizer:
         a.flags = ((_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
                    | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0)
                    | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan]
-                   | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else 0))
+                   | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else 0)
+                   | (0 if sorted_lists else _capi.GSR_FLAG_NO_SORTED_LISTS))
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
         a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()
@@ -161,7 +164,8 @@ class SplatRasterizer:
         _capi.check(rc, "gsr_forward")
         self.last_num_rendered = int(a.num_rendered)
         self.last_records_staged = int(a.records_staged)
-        self.last_plan = _capi.PLAN_NAMES[int(a.plan_used)]
+        self.last_plan = _capi.PLAN_NAMES[int(a.plan_used) & 0xFF]
+        self.last_lists_written = not (int(a.plan_used) & _capi.GSR_PLAN_LISTS_SKIPPED)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()

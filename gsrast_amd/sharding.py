@@ -7,8 +7,9 @@ over xGMI on the GPU box, "gloo" in the CPU tests).
   * Frame: rank g bins / sorts / blends only tile rows [rows[g], rows[g+1]) — the library clips
     every Gaussian's rectangle to the band (gsr_forward_args.tile_row_begin/end), so per-tile
     lists, and therefore pixels, are identical to the single-GPU frame.
-  * Exchange: the planar row bands are all-gathered (padded to the tallest band) and copied
-    into place; one collective per frame, no other data-path communication.
+  * Exchange: every rank sends its planar row band to every peer and receives theirs straight into
+    its frame (one group of exact-size point-to-point transfers per frame; no staging, no padding);
+    no other data-path communication.
   * Balance: bands are re-cut between frames from the per-tile-row instance counts of the last
     frame (each rank knows its own rows; one small all-gather of grid_y integers).
 """
@@ -79,7 +80,13 @@ def broadcast_scene(scene: dict | None, device, src: int = 0) -> dict:
 
 
 class RowBandExchange:
-    """All-gathers planar (3,H,W) row bands into a full frame on every rank."""
+    """Exchanges planar (3,H,W) row bands so that every rank ends up with the full frame.
+
+    A band of a planar CHW frame is three contiguous pieces (rows [y0, y1) of each colour plane), so the
+    exchange is one group of point-to-point transfers of exact sizes — this rank's three pieces to every
+    peer, every peer's three pieces received straight into their place in the frame: no staging buffer,
+    no padding to the tallest band, no copy back. On RCCL the group is one ncclGroupStart/End; each of the
+    seven xGMI links of a fully connected node carries one peer's band."""
 
     def __init__(self, width: int, height: int, device):
         self.width, self.height = width, height
@@ -88,36 +95,36 @@ class RowBandExchange:
         self.rank = dist.get_rank()
         self.device = device
         self.bounds = uniform_bands(self.grid_y, self.world)
-        self._alloc()
-
-    def _alloc(self):
-        self.max_rows = max(band_pixel_rows(self.bounds, g, self.height)[1] - band_pixel_rows(self.bounds, g, self.height)[0]
-                            for g in range(self.world))
-        self.max_rows = max(self.max_rows, 1)
-        self.send = torch.zeros((3, self.max_rows, self.width), dtype=torch.float32, device=self.device)
-        self.recv = torch.zeros((self.world, 3, self.max_rows, self.width), dtype=torch.float32, device=self.device)
 
     def set_bounds(self, bounds: list[int]) -> None:
         assert len(bounds) == self.world + 1 and bounds[0] == 0 and bounds[-1] == self.grid_y
         assert all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
         self.bounds = list(bounds)
-        self._alloc()
 
     def my_tile_rows(self) -> tuple[int, int]:
         return self.bounds[self.rank], self.bounds[self.rank + 1]
 
-    def gather(self, local_frame: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """local_frame: this rank's (3,H,W) buffer whose band rows are rendered. Returns the
-        assembled frame (written into `out` if given, else in place into local_frame)."""
+    def gather(self, frame: torch.Tensor) -> torch.Tensor:
+        """frame: this rank's contiguous (3,H,W) buffer whose own band rows are rendered. On return the other
+        ranks' bands have been received in place. (The transfers are enqueued on the current stream for RCCL;
+        the call returns once they are enqueued.)"""
+        assert frame.is_contiguous() and tuple(frame.shape) == (3, self.height, self.width)
+        if self.world == 1:
+            return frame
         y0, y1 = band_pixel_rows(self.bounds, self.rank, self.height)
-        if y1 > y0:
-            self.send[:, : y1 - y0, :].copy_(local_frame[:, y0:y1, :])
-        dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
-        frame = local_frame if out is None else out
-        for g in range(self.world):
-            a, b = band_pixel_rows(self.bounds, g, self.height)
-            if b > a and (g != self.rank or out is not None):
-                frame[:, a:b, :].copy_(self.recv[g, :, : b - a, :])
+        ops = []
+        for step in range(1, self.world):
+            # staggered peers: in round `step` rank r sends to r + step and receives from r - step
+            dst, src = (self.rank + step) % self.world, (self.rank - step) % self.world
+            a, b = band_pixel_rows(self.bounds, src, self.height)
+            for c in range(3):
+                if y1 > y0:
+                    ops.append(dist.P2POp(dist.isend, frame[c, y0:y1, :], dst))
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, frame[c, a:b, :], src))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         return frame
 
     def rebalance(self, my_row_cost: np.ndarray, floor_cost: float = 0.0) -> list[int]:

@@ -32,7 +32,8 @@ enum {
     GSR_ERR_ALLOC = 2,         /* an allocator callback returned NULL                      */
     GSR_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed               */
     GSR_ERR_NO_DEVICE = 4,     /* no gfx950 device visible                                 */
-    GSR_ERR_TOO_LARGE = 5,     /* numRendered does not fit the reference's u32 offsets     */
+    GSR_ERR_TOO_LARGE = 5,     /* sum of tiles touched >= 2^32 - 1: does not fit the reference's u32 offsets (checked
+                                  on the un-wrapped 64-bit total before the binning chunk is requested) */
     GSR_ERR_INTERNAL = 6       /* a bounded device-side wait expired (see gsr_poll_async_error) */
 };
 
@@ -115,7 +116,15 @@ enum {
 /* Block plan only: run the emission of the sorted lists on a second stream beside the blend (which reads the
  * block lists and does not need them). Same results; the call's work is complete, as always, when `stream` is. */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
-enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */ };
+/* Forward-only callers: under the block plan the blend is fed from the block lists and never reads the sorted
+ * keys / values, and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
+ * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
+ * UNWRITTEN, plan_used carries GSR_PLAN_LISTS_SKIPPED, and gsr_backward refuses that state (it walks `values`).
+ * Pixels, ranges, finalT, nContrib and numRendered are unchanged. Ignored under the other plans, whose blend
+ * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
+#define GSR_FLAG_NO_SORTED_LISTS 0x40u
+enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
+       GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */ };
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
  * gscuda::forward (GSCuda.cuh:103-126); the rest are extensions with neutral defaults (0). */
@@ -158,7 +167,7 @@ typedef struct gsr_forward_args {
     uint32_t num_rendered;         /* R = sum of tiles touched (for the rows processed)    */
     uint64_t records_staged;       /* R_f, only with GSR_FLAG_COUNT_STAGED                 */
     float stage_ms[GSR_NUM_STAGES];/* only with GSR_FLAG_PROFILE                           */
-    uint32_t plan_used;            /* GSR_PLAN_* of this call (0 if R == 0)                */
+    uint32_t plan_used;            /* GSR_PLAN_* of this call (0 if R == 0), | GSR_PLAN_LISTS_SKIPPED */
 } gsr_forward_args;
 
 /* The forward pass. Calls geometry_alloc(required_geometry(N)), then
@@ -275,6 +284,14 @@ int gsr_ply_parse_header(const char* path, int* num_splats, long long* data_offs
  * (means3D/scales/rotations vec4[n], opacities f32[n], shs f32[48 n]). Asynchronous on stream. */
 int gsr_ply_activate(const float* raw_device, int n, float* means3D, float* scales, float* rotations,
                      float* opacities, float* shs, void* stream);
+/* The 48 SH floats of a record are f_dc_0..2 followed by f_rest_0..44, and a 3DGS .ply stores f_rest CHANNEL-major
+ * (R1..R15, G1..G15, B1..B15). The reference copies them as they lie (SplatData.cpp:146) and reads only the DC
+ * triple (GSCuda.cu:362-366): GSR_SH_LAYOUT_FILE, what gsr_ply_activate does. GSR_FLAG_SEMANTICS_INRIA reads shs as
+ * [N][16][3], coefficient-major (upstream's layout, SURVEY.md divergence D2): a scene that is to be drawn with that
+ * flag and sh_dims >= 1 must be loaded with GSR_SH_LAYOUT_COEFFICIENT_MAJOR, which transposes f_rest on the way. */
+enum { GSR_SH_LAYOUT_FILE = 0, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 1 };
+int gsr_ply_activate_layout(const float* raw_device, int n, float* means3D, float* scales, float* rotations,
+                            float* opacities, float* shs, int sh_layout, void* stream);
 
 #ifdef __cplusplus
 }

@@ -170,3 +170,83 @@ def test_overlapped_emission_on_a_non_default_stream_with_bands_and_upstream_sem
         b = r.draw(cam, plan="blocks", semantics="inria", sh_degree=0, overlap_emit=True)
         c = r.draw(cam, plan="sort", semantics="inria", sh_degree=0)
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_more_than_u32_instances_is_refused_before_the_binning_chunk():
+    """The reference's offsets are u32 (AuxBuffer.cuh:51). 140 000 splats that each cover all 32 400 tiles of a 4K
+    frame sum to 4.5 G instances: the u32 scan wraps to a small number, the un-wrapped 64-bit total says so, and the
+    call must stop with GSR_ERR_TOO_LARGE without asking for a binning chunk sized by the wrapped count."""
+    from gsrast_amd import _capi, camera
+    n = 140_000
+    scene = single_gaussian_scene(pos=(0.0, 0.0, 0.0), scale=30.0, opacity=0.01, n=n)
+    cam = camera.default_camera(3840, 2160)
+    r = _rast(3840, 2160)
+    r.configure_from_scene(scene)
+    with pytest.raises(_capi.GsrError) as e:
+        r.draw(cam)
+    assert e.value.code == _capi.GSR_ERR_TOO_LARGE
+    assert r.binning.calls == []                                  # never asked for
+    tt = r.map_geometry_state()["tilesTouched"].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert int(tt.sum()) == n * 240 * 135 > 2 ** 32
+    # one splat fewer than the limit's worth is still a legal frame for the scan (not rendered here: 51 GB of lists)
+    small = single_gaussian_scene(pos=(0.0, 0.0, 0.0), scale=30.0, opacity=0.01, n=100)
+    r2 = _rast(3840, 2160)
+    r2.configure_from_scene(small)
+    r2.draw(cam)
+    assert r2.last_num_rendered == 100 * 240 * 135
+
+
+def test_forward_only_calls_may_skip_the_sorted_lists():
+    """GSR_FLAG_NO_SORTED_LISTS under the block plan: same pixels, ranges, finalT, nContrib, R and R_f; keys / values
+    are left unwritten; gsr_backward refuses that state; the flag does nothing under the sort plan."""
+    import torch
+    from gsrast_amd import _capi, camera, scenes
+    scene = scenes.garden_like_scene(300_000, seed=43)
+    scene["means3D"][:, 2] += 6.0
+    cam = camera.default_camera(1920, 1080, near=0.05, far=80.0)
+    r = _rast(1920, 1080, background=(0.05, 0.1, 0.15))
+    r.configure_from_scene(scene)
+    img = r.draw(cam, plan="blocks", count_staged=True).clone()
+    staged, R = r.last_records_staged, r.last_num_rendered
+    assert r.last_lists_written
+    st = {k: v.clone() for k, v in r.map_image_state().items()}
+    b = r.map_binning_state()
+    b["keys"].fill_(-1); b["values"].fill_(-1)
+    img2 = r.draw(cam, plan="blocks", count_staged=True, sorted_lists=False)
+    assert r.last_plan == "blocks" and not r.last_lists_written
+    assert torch.equal(img2, img) and r.last_records_staged == staged and r.last_num_rendered == R
+    for k, v in r.map_image_state().items():
+        assert torch.equal(v, st[k]), k
+    b = r.map_binning_state()
+    assert bool((b["keys"] == -1).all()) and bool((b["values"] == -1).all())      # nothing wrote them
+    with pytest.raises(_capi.GsrError) as e:
+        r.backward(torch.ones((3, 1080, 1920)))
+    assert e.value.code == _capi.GSR_ERR_INVALID_ARG
+    # under the sort plan the blend reads the sorted list: the flag is ignored
+    img3 = r.draw(cam, plan="sort", sorted_lists=False)
+    assert r.last_plan == "sort" and r.last_lists_written and torch.equal(img3, img)
+    r.backward(torch.ones((3, 1080, 1920)))                                        # and backward works again
+
+
+def test_nan_positions_of_either_sign_match_the_oracle():
+    """A NaN position passes the reference's frustum test (every comparison is false, GSCuda.cu:306-309) and dies
+    at the rectangle (an int conversion of NaN gives an empty one): nothing of it may reach the lists. (A visible key
+    whose depth is a NaN can only come from overflow, 0 * inf, whose NaN sign is the platform's: no parity to test;
+    the depth sort counts all 256 top-byte digits so that such a key is still ordered by all four passes.)"""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.isotropic_scene(600, seed=21)
+    cam = camera.default_camera(96, 96)
+    r = _rast(96, 96)
+    for sign in (1.0, -1.0):
+        sc = {k: v.copy() for k, v in scene.items()}
+        sc["means3D"][7, 2] = np.float32(np.nan) * np.float32(sign)
+        exp = cpu_oracle.forward(sc, cam)
+        r.configure_from_scene(sc)
+        img = r.draw(cam).cpu().numpy()
+        assert r.last_num_rendered == exp["num_rendered"]
+        b = r.map_binning_state()
+        assert np.array_equal(b["keys"].cpu().numpy().view(np.uint64), exp["keys"])
+        assert np.array_equal(b["values"].cpu().numpy().view(np.uint32), exp["values"])
+        assert not (b["values"].cpu().numpy() == 7).any()
+        assert np.abs(img - exp["out_color"]).max() <= 1e-4

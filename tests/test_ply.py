@@ -30,6 +30,12 @@ def test_header_is_read_the_way_the_reference_reads_it(tmp_path):
     with pytest.raises(ValueError):
         ply.parse_header(q)
     o = ply_oracle.load(p)
+    # f_rest is channel-major in the file; "coefficient_major" regroups it as [15][3] behind the DC triple
+    oc = ply_oracle.load(p, sh_layout="coefficient_major")
+    assert np.array_equal(oc["shs"][:, :3], o["shs"][:, :3])
+    for k in range(1, 16):
+        for ch in range(3):
+            assert np.array_equal(oc["shs"][:, 3 * k + ch], o["shs"][:, 3 + 15 * ch + (k - 1)])
     assert o["means3D"].shape == (37, 4) and (o["means3D"][:, 3] == 1).all()
     assert np.allclose(np.linalg.norm(o["rotations"], axis=1), 1.0, atol=1e-6)
 
@@ -70,3 +76,37 @@ def test_scene_loaded_from_ply_renders_like_the_in_memory_scene(tmp_path):
     ia, ib = a.draw(cam).cpu().numpy(), b.draw(cam).cpu().numpy()
     assert np.abs(ia - ib).max() <= 2e-3        # log/exp round trip of scales and opacities moves a few thresholds
     assert abs(a.last_num_rendered - b.last_num_rendered) <= a.last_num_rendered // 200
+
+
+@pytest.mark.gpu
+def test_ply_with_higher_order_sh_renders_under_the_inria_profile(tmp_path):
+    """A .ply with random f_rest, loaded with sh_layout="coefficient_major", drawn with the upstream semantics
+    (degree 3) against oracle/inria_np.py fed by the CPU loader: the f_rest transposition must be the right one
+    (loaded in file order the colours come out visibly wrong)."""
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    from oracle import inria_np
+    sc = scenes.garden_like_scene(3000, seed=5)
+    sc["means3D"][:, :3] *= 0.25
+    rng = np.random.default_rng(5)
+    file_sh = rng.normal(0, 0.3, (3000, 48)).astype(np.float32)          # as stored: f_dc, then f_rest channel-major
+    p = str(tmp_path / "sh.ply")
+    opac = np.clip(sc["opacities"].astype(np.float64), 1e-6, 1 - 1e-6)
+    ply.write_ply(p, sc["means3D"][:, :3], file_sh, np.log(opac / (1 - opac)), np.log(sc["scales"][:, :3]), sc["rotations"])
+    want_scene = ply_oracle.load(p, sh_layout="coefficient_major")
+    got = ply.load_ply(p, sh_layout="coefficient_major")
+    assert np.array_equal(got["shs"].cpu().numpy(), want_scene["shs"])
+    assert np.array_equal(ply.load_ply(p)["shs"].cpu().numpy(), file_sh)
+    cam = camera.default_camera(200, 120, near=0.05, far=50.0)
+    bg = (0.1, 0.2, 0.3)
+    # the oracle renders the scene the GPU loader produced (its expf differs from numpy's by an ulp in scales / opacities)
+    host = {k: got[k].cpu().numpy() for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    exp = inria_np.forward(host, cam, bg, deg=3)
+    r = SplatRasterizer(200, 120, background=bg)
+    r.configure_from_scene({k: got[k] for k in host})
+    img = r.draw(cam, semantics="inria", sh_degree=3).cpu().numpy()
+    assert r.last_num_rendered == exp["num_rendered"]
+    assert np.abs(img - exp["out_color"]).max() <= 1e-4
+    wrong = ply.load_ply(p)                                               # file order fed to the [16][3] reader
+    r.configure_from_scene({k: wrong[k] for k in host})
+    assert np.abs(r.draw(cam, semantics="inria", sh_degree=3).cpu().numpy() - exp["out_color"]).max() > 1e-2
