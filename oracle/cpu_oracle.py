@@ -14,26 +14,29 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libgsr_oracle.so")
-_lib = None
+# the same source built with -ffp-contract=fast -mfma: contraction sensitivity study only (oracle/Makefile)
+_LIB_PATH_CONTRACT = os.path.join(_HERE, "_build", "libgsr_oracle_contract.so")
+_libs = {}
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "gsr_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+    stale = any(not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src) for p in (_LIB_PATH, _LIB_PATH_CONTRACT))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
 
 
-def lib() -> ctypes.CDLL:
-    global _lib
-    if _lib is None:
+def lib(contract: bool = False) -> ctypes.CDLL:
+    if contract not in _libs:
         build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.gsro_preprocess.restype = ctypes.c_uint64
-        _lib.gsro_blend.restype = ctypes.c_uint64
-        _lib.gsro_higher_msb.restype = ctypes.c_uint32
-        _lib.gsro_hardware_concurrency.restype = ctypes.c_uint
-    return _lib
+        L = ctypes.CDLL(_LIB_PATH_CONTRACT if contract else _LIB_PATH)
+        L.gsro_preprocess.restype = ctypes.c_uint64
+        L.gsro_blend.restype = ctypes.c_uint64
+        L.gsro_higher_msb.restype = ctypes.c_uint32
+        L.gsro_hardware_concurrency.restype = ctypes.c_uint
+        _libs[contract] = L
+    return _libs[contract]
 
 
 def _p(a):
@@ -49,12 +52,14 @@ def hardware_concurrency() -> int:
 
 
 def forward(scene: dict, cam, background=(0.0, 0.0, 0.0), use_rects: bool = True, scale_modifier: float = 1.0,
-            threads: int = 1, out_init: np.ndarray | None = None, timings: dict | None = None) -> dict:
+            threads: int = 1, out_init: np.ndarray | None = None, timings: dict | None = None,
+            contract: bool = False) -> dict:
     """Runs the whole reference pipeline (GSCuda.cu:695-811) on the CPU and returns every
     intermediate: GeometryState arrays, rects, keys/values (unsorted and sorted), tile
     ranges, the planar image, finalT, nContrib, R (num_rendered) and R_f (records staged).
-    Arrays the reference leaves unwritten keep their zero initialisation."""
-    L = lib()
+    Arrays the reference leaves unwritten keep their zero initialisation.
+    contract=True runs the build with fused multiply-adds allowed (contraction sensitivity study only)."""
+    L = lib(contract)
     n = int(scene["means3D"].shape[0])
     W, H = cam.width, cam.height
     P = W * H
