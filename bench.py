@@ -2,17 +2,23 @@
 """Benchmark of the forward splat rasterizer (BASELINE.json metric: forward Msplats/s + fps at
 1920x1080; blend-kernel HBM GB/s vs peak).
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
+      N = 1: runs in this process. N > 1 without a launcher around it: starts
+      `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD process (before
+      anything here touches the GPU) and relays its JSON line; fails loudly if fewer than N devices are visible.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+      what the driver runs: one rank per GPU over RCCL (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).
 
-A step is one `forward` call on one frame: allocator callbacks, preprocess, scan, the
-numRendered read-back, key emission, radix sort, tile ranges, blend and the trailing device
-synchronise the reference's caller performs (apps/gsrast/CudaBuffer.hpp:8-12). The scene is
-resident in HBM before the timed region. With N > 1 the frame's tile rows are sharded over the
-ranks and the row bands are all-gathered inside the step (strong scaling: same frame, N GPUs).
+A step is one `forward` call on one frame: allocator callbacks, preprocess, scan, the numRendered read-back, binning,
+blend and the trailing device synchronise the reference's caller performs (apps/gsrast/CudaBuffer.hpp:8-12). The
+scene is resident in HBM before the timed region. With N > 1 the frame's tile rows are sharded over the ranks and the
+row bands are exchanged inside the step (strong scaling: same frame, N GPUs); BASELINE config 3 (the same scene at
+3840 x 2160) is then timed as well and reported under "config3_4k".
 
-Workload at N=1: BASELINE config 2 — the Mip-NeRF360 garden .ply is not available offline, so
-the "garden-like" synthetic scene of SURVEY.md §8d stands in (same splat count, labelled so).
+Workload at N=1: BASELINE config 2 — the Mip-NeRF360 garden .ply is not available offline, so the "garden-like"
+synthetic scene of SURVEY.md §8d stands in (same splat count, labelled so), at the reference's default pose. Extra keys
+at N=1 (measured after, and outside, the timed region of the headline): the same scene from a pose outside the cloud,
+a blend-bound variant (opacities x 0.1) and the forward-only mode without the sorted lists.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -20,6 +26,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +39,8 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured-achievable
+N_SIMD = 1024              # 256 CUs x 4 SIMDs
+DEFAULT_SPLATS = 5_834_784
 
 
 def parse_args():
@@ -40,44 +50,139 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--splats", type=int, default=5_834_784)
+    p.add_argument("--splats", type=int, default=DEFAULT_SPLATS)
     p.add_argument("--scene", default="garden_like", choices=["garden_like", "stress", "isotropic"])
+    p.add_argument("--pose", default=None, help="camera position x,y,z (default: the reference's (0,0,-5); (0,0,-25) for --scene stress)")
+    p.add_argument("--opacity-scale", type=float, default=1.0, help="multiplies every opacity (0.1: blend-bound variant, R_f ~ R)")
+    p.add_argument("--semantics", default="gscuda", choices=["gscuda", "inria"],
+                   help="inria: the upstream rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA), SH evaluated up to --sh-degree")
+    p.add_argument("--sh-degree", type=int, default=3)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=3, help="CPU baseline renders every k-th splat (about 10 s of host time)")
     p.add_argument("--no-rebalance", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the extra frames (second pose, blend-bound, no sorted lists, config 3 at N > 1)")
     p.add_argument("--backward", action="store_true",
                    help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
     p.add_argument("--overlap", action="store_true",
                    help="GSR_FLAG_OVERLAP_EMIT: block plan's emission on a second stream beside the blend (shorter frames, "
                         "but per-kernel times are then those of kernels sharing the chip)")
+    p.add_argument("--no-sorted-lists", action="store_true", help="GSR_FLAG_NO_SORTED_LISTS for the headline frame (forward-only callers)")
     p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
+    p.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: a free one)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="launcher / rendezvous / band-exchange plumbing check on CPU over gloo: renders nothing, measures "
+                        "nothing, prints a line with value null")
     return p.parse_args()
 
 
-def make_scene(name: str, n: int):
-    from gsrast_amd import camera, scenes
+# ---- launching N ranks ------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    """--gpus N > 1 and no launcher around us: run the ranks as a child `torch.distributed.run` and relay the JSON
+    line. Nothing in this process touches the GPU (device_count does not initialise it on this image), and the
+    current process is never replaced."""
+    if not args.dry_run:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for, but {ndev} HIP device(s) visible: refusing to report a "
+                  f"{args.gpus}-GPU number from fewer GPUs", file=sys.stderr)
+            return 2
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = child.stdout.splitlines()
+    json_lines = [ln for ln in lines if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in lines:
+        if not json_lines or ln is not json_lines[-1]:
+            print(ln, file=sys.stderr)
+    if child.returncode != 0 or not json_lines:
+        print(f"bench.py: the {args.gpus}-rank child exited with code {child.returncode}"
+              + ("" if json_lines else " without a JSON line"), file=sys.stderr)
+        return child.returncode or 3
+    print(json_lines[-1], flush=True)
+    return 0
+
+
+def dry_run(args) -> int:
+    """CPU / gloo: every rank fills its band of a synthetic frame, the bands are exchanged, every rank checks the
+    assembled frame, the bands are re-cut once and exchanged again. No rasterizer, no number."""
+    import torch.distributed as dist
+    from gsrast_amd import sharding
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H = args.width, args.height
+    dev = torch.device("cpu")
+    ex = sharding.RowBandExchange(W, H, dev)
+    ys = torch.arange(H, dtype=torch.float32)[None, :, None]
+    want = (torch.arange(3, dtype=torch.float32)[:, None, None] * 1000.0 + ys).expand(3, H, W).contiguous()
+    ok = True
+    bands = []
+    for trial in range(2):
+        b0, b1 = ex.my_tile_rows()
+        y0, y1 = min(b0 * 16, H), min(b1 * 16, H)
+        frame = torch.full((3, H, W), -1.0)
+        frame[:, y0:y1, :] = want[:, y0:y1, :]
+        ex.gather(frame)
+        ok = ok and bool(torch.equal(frame, want))
+        bands.append(list(ex.bounds))
+        cost = np.zeros(ex.grid_y)
+        cost[b0:b1] = np.arange(b0, b1) + 1.0
+        ex.rebalance(cost)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    n = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "forward_msplats_per_s", "value": None, "unit": "Msplats/s", "n_gpus": n, "dry_run": True,
+                          "exchange_ok": bool(flag.item() == 1.0), "bands": bands,
+                          "note": "CPU / gloo plumbing check of the launcher and the band exchange: nothing rendered or measured"}),
+              flush=True)
+    return 0 if flag.item() == 1.0 else 4
+
+
+# ---- workload ---------------------------------------------------------------------------------------------------------
+def make_scene(name: str, n: int, device, full_sh: bool = False):
+    """Returns (scene dict, near, far, default position, label). The 50 M stress scene is generated on the device (same
+    splitmix64 definition, gsrast_amd/scenes.py); the others on the host as in round 1."""
+    from gsrast_amd import scenes
     if name == "garden_like":
         sc = scenes.garden_like_scene(n, seed=43)
         span = float(np.max(sc["means3D"][:, :3].max(0) - sc["means3D"][:, :3].min(0)))
         near, far = 0.001 * span, span                 # GSRastWindow.cpp:30-36
         label = f"garden-like synthetic stand-in for the garden .ply (seed 43), N={n}"
+        pos = (0.0, 0.0, -5.0)
     elif name == "stress":
-        sc = scenes.stress_scene(n, seed=44)
+        sc = scenes.stress_scene_device(n, seed=44, device=device, full_sh=full_sh)
         near, far = 0.1, 100.0
-        label = f"50M-style anisotropic stress scene (seed 44), N={n}"
+        label = f"50M-style anisotropic stress scene (seed 44{', 48 SH floats' if full_sh else ''}), N={n}"
+        pos = (0.0, 0.0, -25.0)
     else:
         sc = scenes.isotropic_scene(n, seed=42)
         near, far = 0.01, 100.0
         label = f"isotropic plumbing scene (seed 42), N={n}"
-    pos = (0.0, 0.0, -25.0) if name == "stress" else (0.0, 0.0, -5.0)
+        pos = (0.0, 0.0, -5.0)
+    if full_sh and name != "stress":
+        rng = np.random.default_rng(45)
+        sc["shs"][:, 3:] = rng.normal(0.0, 0.3, (n, 45)).astype(np.float32)
     return sc, near, far, pos, label
 
 
 def cpu_baseline(scene, cam, every: int):
     """Times the scalar C++ oracle (oracle/gsr_oracle.cpp, the CPU restatement of the same tile
     loop) on a bounded sample of the workload: every k-th splat, same camera and resolution."""
+    from gsrast_amd import scenes
     from oracle import cpu_oracle
-    sub = {k: np.ascontiguousarray(v[::every]) for k, v in scene.items()}
+    sub = scenes.scene_rows(scene, slice(None, None, every))
     n = int(sub["means3D"].shape[0])
     cores = cpu_oracle.hardware_concurrency() or 1
     t = {}
@@ -91,14 +196,178 @@ def cpu_baseline(scene, cam, every: int):
     }
 
 
-def main():
+class Runner:
+    """One rasterizer + (when sharded) its band exchange; `measure` times K steps of it."""
+
+    def __init__(self, dev_scene, W, H, device, distributed, args):
+        from gsrast_amd import _capi, sharding
+        from gsrast_amd.rasterizer import SplatRasterizer
+        self.capi = _capi
+        self.W, self.H, self.device, self.distributed, self.args = W, H, device, distributed, args
+        self.rast = SplatRasterizer(W, H, device=device)
+        self.rast.configure_from_scene(dev_scene)
+        self.exch = sharding.RowBandExchange(W, H, device) if distributed else None
+        self.grid_x, self.grid_y = (W + 15) // 16, (H + 15) // 16
+        self.dl_dout = None
+        self.bw_ms = [0.0, 0.0]
+
+    def step(self, cam, profile=False, **kw):
+        rast, exch = self.rast, self.exch
+        rows = exch.my_tile_rows() if exch else None
+        frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not self.distributed, **kw)
+        if self.dl_dout is not None:
+            rast.backward(self.dl_dout, profile=profile)
+            if profile:
+                self.bw_ms[0] += rast.last_backward_ms[0]
+                self.bw_ms[1] += rast.last_backward_ms[1]
+        if exch:
+            exch.gather(frame)
+            torch.cuda.current_stream(self.device).synchronize()
+            self.capi.check(rast.lib.gsr_poll_async_error(), "gsr_forward (device side)")
+        return frame
+
+    def sync_all(self):
+        torch.cuda.synchronize(self.device)
+        if self.distributed:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(self.device)
+
+    def measure(self, cam, steps, warmup, **kw):
+        rast, exch = self.rast, self.exch
+        for w in range(warmup):                     # warm-up (also converges the row-band balance when sharded)
+            self.step(cam, **kw)
+            if exch and not self.args.no_rebalance and w < warmup - 1:
+                r = rast.map_image_state()["ranges"].to(torch.int64)
+                per_tile = (r[:, 1] - r[:, 0]).clamp(min=0).view(self.grid_y, self.grid_x).sum(1).cpu().numpy().astype(np.float64)
+                b0, b1 = exch.my_tile_rows()
+                mine = np.zeros(self.grid_y)
+                mine[b0:b1] = per_tile[b0:b1]
+                exch.rebalance(mine, floor_cost=0.02 * float(per_tile[b0:b1].mean() if b1 > b0 else 0.0) + 1.0)
+        rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None, **kw)
+        out = {"plan": rast.last_plan, "lists_written": rast.last_lists_written, "records_staged": rast.last_records_staged,
+               "num_rendered": rast.last_num_rendered}
+        geo = rast.map_geometry_state()
+        out["visible_band"] = int((geo["tilesTouched"] != 0).sum().item())
+        out["visible"] = int((geo["radii"] > 0).sum().item())
+        self.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(cam, **kw)
+        self.sync_all()
+        out["elapsed"] = time.perf_counter() - t0
+        # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
+        # every stage cost a few tens of microseconds per frame, which the timed frames do not pay).
+        prof_steps = max(5, min(steps, 20))
+        stage_sum = {}
+        self.bw_ms = [0.0, 0.0]
+        t1 = time.perf_counter()
+        for _ in range(prof_steps):
+            self.step(cam, profile=True, **kw)
+            for k, v in rast.last_stage_ms.items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+        self.sync_all()
+        out["profiled_ms_per_step"] = (time.perf_counter() - t1) / prof_steps * 1e3
+        out["stage_ms"] = {k: v / prof_steps for k, v in stage_sum.items()}
+        out["prof_steps"] = prof_steps
+        out["backward_ms"] = [v / prof_steps for v in self.bw_ms]
+        out["tile_rows"] = list(exch.my_tile_rows()) if exch else [0, self.grid_y]
+        out["bands"] = list(exch.bounds) if exch else None
+        if self.distributed:
+            import torch.distributed as dist
+            t = torch.tensor([out["elapsed"]], dtype=torch.float64, device=self.device)
+            mine = torch.tensor([out["elapsed"], float(out["records_staged"]), float(out["num_rendered"]),
+                                 float(out["tile_rows"][0]), float(out["tile_rows"][1])], dtype=torch.float64, device=self.device)
+            allr = torch.zeros((dist.get_world_size(), 5), dtype=torch.float64, device=self.device)
+            dist.all_gather_into_tensor(allr.view(-1), mine)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out["elapsed"] = float(t.item())                       # MAX over ranks
+            allr = allr.cpu().numpy()
+            out["per_rank"] = [{"rank": g, "tile_rows": [int(allr[g, 3]), int(allr[g, 4])], "num_rendered": int(allr[g, 2]),
+                                "records_staged": int(allr[g, 1]), "ms_per_step": round(allr[g, 0] / steps * 1e3, 4)}
+                               for g in range(allr.shape[0])]
+            out["records_staged_total"], out["num_rendered_total"] = int(allr[:, 1].sum()), int(allr[:, 2].sum())
+        else:
+            out["per_rank"] = None
+            out["records_staged_total"], out["num_rendered_total"] = out["records_staged"], out["num_rendered"]
+        out["ms_per_step"] = out["elapsed"] / steps * 1e3
+        return out
+
+
+def alg_bytes(m, N, W, H, grid_x, sh_floats_read):
+    """ALGORITHMIC bytes per launch on THIS rank (SURVEY.md §8d / BASELINE.md §2). N splats, V visible, R instances,
+    R_f records staged by the blend, P pixels, T tiles of this rank's band."""
+    rows = m["tile_rows"]
+    px_rows = min(rows[1] * 16, H) - min(rows[0] * 16, H)
+    P_loc, T_loc = px_rows * W, (rows[1] - rows[0]) * grid_x
+    V, R, r_f = m["visible_band"], m["num_rendered"], m["records_staged"]
+    blocks = m["plan"] == "blocks"
+    return {
+        "preprocess": N * (52 + 4 * sh_floats_read + 8) + V * 72,
+        "scan": 8 * N,
+        # sort plan: the emission kernel of SURVEY.md §8d. block plan: block_emit_kernel writes the
+        # SORTED pairs once (12 B each); its block-list reads (12 B per entry, E <= R) are not counted.
+        "duplicate": (12 * R if m["lists_written"] else 0) if blocks else 8 * N + 20 * V + 12 * R,
+        "sort_pass1": 0 if blocks else 24 * R,   # one onesweep launch: 12 B read + 12 B written per pair
+        "sort_pass2": 24 * R,
+        "ranges": 0 if blocks else 16 * T_loc * max(1, int(np.ceil(np.log2(max(R, 2))))) + 8 * T_loc,   # two binary searches per tile
+        "blend": 40 * r_f + 20 * P_loc + 8 * T_loc,
+    }
+
+
+def kernel_table(m, alg):
+    kernels = {}
+    for k, b in alg.items():
+        t = m["stage_ms"].get(k, 0.0)
+        if t > 0:
+            gbs = b / (t * 1e-3) / 1e9
+            kernels[k] = {"ms": round(t, 4), "alg_bytes": int(b), "gbs": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+    return kernels
+
+
+def load_profile_json(*names):
+    for nm in names:
+        path = os.path.join(ROOT, "profiles", nm)
+        if os.path.exists(path):
+            return json.load(open(path)), "profiles/" + nm
+    return {}, None
+
+
+def blend_issue_fractions(pmc, blend_ms):
+    """VALU issue fraction of the blend kernel from a committed PMC pass (profiles/): SQ_INSTS_VALU wave-instructions
+    x 4 cycles (what one wave's stream holds its SIMD for per vector instruction, MI355X_MICROARCH.md) over the
+    1024 SIMDs x clock x the live launch time. The counters are per launch of the same kernel on the same frame."""
+    if not pmc or blend_ms <= 0:
+        return {}
+    clock_hz = float(pmc.get("clock_ghz", 2.4)) * 1e9
+    valu, salu = float(pmc["SQ_INSTS_VALU"]), float(pmc["SQ_INSTS_SALU"])
+    avail = N_SIMD * clock_hz * blend_ms * 1e-3
+    return {"valu_frac": round(valu * 4.0 / avail, 4), "scalar_share": round(salu / max(valu + salu, 1.0), 4),
+            "valu_insts": int(valu), "salu_insts": int(salu), "clock_ghz": float(pmc.get("clock_ghz", 2.4)),
+            "valu_frac_formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x launch time); counters from the committed PMC pass, time live"}
+
+
+def main() -> int:
     args = parse_args()
+    forced = os.environ.get("GSR_FORCE_DIST") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not forced:
+        return self_launch(args)
+    if args.dry_run:
+        return dry_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # GSR_FORCE_DIST=1 runs the sharded code path (RCCL broadcast, band all-gather, re-cut) even with one
+    if world != args.gpus and not forced:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop the launcher and let "
+              f"--gpus start the ranks)", file=sys.stderr)
+        return 2
+    # GSR_FORCE_DIST=1 runs the sharded code path (RCCL broadcast, band exchange, re-cut) even with one
     # rank: the only way to exercise it on a single-GPU box.
-    distributed = world > 1 or os.environ.get("GSR_FORCE_DIST") == "1"
+    distributed = world > 1 or forced
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs HIP device {local_rank}; {torch.cuda.device_count()} visible "
+              f"(the rasterizer has no CPU path)", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -108,14 +377,21 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
+        world = dist.get_world_size()
 
-    from gsrast_amd import _capi, camera
-    from gsrast_amd.rasterizer import SplatRasterizer
+    from gsrast_amd import camera
 
     W, H = args.width, args.height
+    inria = args.semantics == "inria"
+    full_sh = inria and args.sh_degree > 0
     scene = None
     if rank == 0 or not distributed:
-        scene, near, far, pos, label = make_scene(args.scene, args.splats)
+        scene, near, far, pos, label = make_scene(args.scene, args.splats, device, full_sh)
+        if args.pose:
+            pos = tuple(float(v) for v in args.pose.split(","))
+        if args.opacity_scale != 1.0:
+            scene["opacities"] = scene["opacities"] * np.float32(args.opacity_scale)
+            label += f", opacities x {args.opacity_scale}"
         meta = [near, far, *pos]
     else:
         meta, label = [0.0] * 5, ""
@@ -126,141 +402,90 @@ def main():
         near, far, pos = float(m[0]), float(m[1]), tuple(float(v) for v in m[2:5])
         dev_scene = sharding.broadcast_scene(scene, device, 0)          # RCCL broadcast of the SoA
     else:
-        dev_scene = scene
+        dev_scene = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)).to(device))
+                     for k, v in scene.items()}
     cam = camera.default_camera(W, H, near=near, far=far, position=pos)
 
-    rast = SplatRasterizer(W, H, device=device)
-    rast.configure_from_scene(dev_scene)
-    n_splats = rast.num_gaussians
-    grid_x, grid_y = (W + 15) // 16, (H + 15) // 16
-    exch = sharding.RowBandExchange(W, H, device) if distributed else None
-
-    dl_dout = None
+    run = Runner(dev_scene, W, H, device, distributed, args)
+    n_splats = run.rast.num_gaussians
     if args.backward:
         assert not distributed, "--backward is a single-GPU configuration"
-        dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
-    bw_ms = [0.0, 0.0]
+        run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
+    draw_kw = dict(plan=args.plan, overlap_emit=args.overlap, semantics=args.semantics, sh_degree=args.sh_degree,
+                   sorted_lists=not args.no_sorted_lists)
+    m = run.measure(cam, args.steps, args.warmup, **draw_kw)
 
-    def step(profile=False):
-        rows = exch.my_tile_rows() if exch else None
-        frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not distributed, plan=args.plan,
-                          overlap_emit=args.overlap)
-        if dl_dout is not None:
-            rast.backward(dl_dout, profile=profile)
-            if profile:
-                bw_ms[0] += rast.last_backward_ms[0]
-                bw_ms[1] += rast.last_backward_ms[1]
-        if exch:
-            exch.gather(frame)
-            torch.cuda.current_stream(device).synchronize()
-            _capi.check(rast.lib.gsr_poll_async_error(), "gsr_forward (device side)")
-        return frame
-
-    def sync_all():
-        torch.cuda.synchronize(device)
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-    # warm-up (also converges the row-band balance when sharded)
-    for w in range(args.warmup):
-        step()
-        if exch and not args.no_rebalance and w < args.warmup - 1:
-            r = rast.map_image_state()["ranges"].to(torch.int64)
-            per_tile = (r[:, 1] - r[:, 0]).clamp(min=0).view(grid_y, grid_x).sum(1).cpu().numpy().astype(np.float64)
-            b0, b1 = exch.my_tile_rows()
-            mine = np.zeros(grid_y)
-            mine[b0:b1] = per_tile[b0:b1]
-            exch.rebalance(mine, floor_cost=0.02 * float(per_tile[b0:b1].mean() if b1 > b0 else 0.0) + 1.0)
-
-    stage_sum = {}
-    staged_frame = rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None, plan=args.plan)
-    plan_used = rast.last_plan
-    r_f = rast.last_records_staged
-    num_rendered = rast.last_num_rendered
-    geo = rast.map_geometry_state()
-    n_visible = int((geo["tilesTouched"] != 0).sum().item())        # V of this rank's band
-    n_visible_total = int((geo["radii"] > 0).sum().item())
-
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
-    # every stage cost a few tens of microseconds per frame, which the timed frames do not pay).
-    prof_steps = max(5, min(args.steps, 20))
-    bw_ms[0] = bw_ms[1] = 0.0
-    t1 = time.perf_counter()
-    for _ in range(prof_steps):
-        step(profile=True)
-        for k, v in rast.last_stage_ms.items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-    sync_all()
-    elapsed_profiled = time.perf_counter() - t1
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([float(r_f), float(num_rendered)], dtype=torch.float64, device=device)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        r_f_total, r_total = int(cnt[0].item()), int(cnt[1].item())
-    else:
-        r_f_total, r_total = r_f, num_rendered
+    default_frame = (args.scene == "garden_like" and args.splats == DEFAULT_SPLATS and (W, H) == (1920, 1080) and not args.pose
+                     and args.opacity_scale == 1.0 and not inria and not args.backward and args.plan == "auto"
+                     and not args.overlap and not args.no_sorted_lists)
+    extras = {}
+    if not args.no_extras and default_frame:
+        short = dict(steps=max(5, min(args.steps, 15)), warmup=3)
+        if not distributed:
+            # (a) the same scene from outside the cloud (">= 1 in-scene pose" besides the default one)
+            cam_out = camera.default_camera(W, H, near=near, far=far, position=(0.0, 0.0, -14.0))
+            e = run.measure(cam_out, **short, **draw_kw)
+            extras["pose_outside"] = brief(e, n_splats, "eye (0,0,-14): the whole cloud in front of the camera, small splats, deep lists")
+            # (b) forward-only callers: GSR_FLAG_NO_SORTED_LISTS on the headline frame
+            e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
+            extras["no_sorted_lists"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_SORTED_LISTS (block plan: the 12 R bytes of sorted keys / values are not written)")
+            # (c) blend-bound variant: opacities x 0.1, so pixels saturate late and the blend stages most of R
+            saved = run.rast.opacities
+            run.rast.opacities = (saved * 0.1).contiguous()
+            e = run.measure(cam, **short, **draw_kw)
+            b = brief(e, n_splats, "headline frame with opacities x 0.1 (R_f ~ R: the blend walks deep lists)")
+            b["blend_ms_per_million_staged_records"] = round(e["stage_ms"].get("blend", 0.0) / max(e["records_staged"], 1) * 1e6, 5)
+            extras["blend_bound"] = b
+            e = run.measure(cam_out, **short, **draw_kw)
+            b = brief(e, n_splats, "eye (0,0,-14) with opacities x 0.1")
+            b["blend_ms_per_million_staged_records"] = round(e["stage_ms"].get("blend", 0.0) / max(e["records_staged"], 1) * 1e6, 5)
+            extras["blend_bound_pose_outside"] = b
+            run.rast.opacities = saved
+        else:
+            # BASELINE config 3: the same scene at 3840 x 2160, tile rows sharded over the ranks
+            run4k = Runner(dev_scene, 3840, 2160, device, distributed, args)
+            cam4k = camera.default_camera(3840, 2160, near=near, far=far, position=pos)
+            e = run4k.measure(cam4k, **short, **draw_kw)
+            c3 = brief(e, n_splats, "BASELINE config 3: same scene and pose at 3840x2160, tile rows sharded over the ranks")
+            c3["per_rank"], c3["bands"] = e["per_rank"], e["bands"]
+            extras["config3_4k"] = c3
+            del run4k
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        stage_ms = {k: v / prof_steps for k, v in stage_sum.items()}
-        # ALGORITHMIC bytes per launch on THIS rank (SURVEY.md §8d / BASELINE.md §2). N splats,
-        # V visible, R instances, R_f records staged by the blend, P pixels, T tiles of this rank.
-        rows = exch.my_tile_rows() if exch else (0, grid_y)
-        px_rows = min(rows[1] * 16, H) - min(rows[0] * 16, H)
-        P_loc, T_loc = px_rows * W, (rows[1] - rows[0]) * grid_x
-        N, R = n_splats, num_rendered
-        blocks = plan_used == "blocks"
-        alg = {
-            "preprocess": N * (52 + 12 + 8) + n_visible * 72,
-            "scan": 8 * N,
-            # sort plan: the emission kernel of SURVEY.md §8d. block plan: block_emit_kernel writes the
-            # SORTED pairs once (12 B each); its block-list reads (12 B per entry, E <= R) are not counted.
-            "duplicate": 12 * R if blocks else 8 * N + 20 * n_visible + 12 * R,
-            "sort_pass1": 0 if blocks else 24 * R,   # one onesweep launch: 12 B read + 12 B written per pair
-            "sort_pass2": 24 * R,
-            "ranges": 0 if blocks else 16 * T_loc * max(1, int(np.ceil(np.log2(max(R, 2))))) + 8 * T_loc,   # two binary searches per tile
-            "blend": 40 * r_f + 20 * P_loc + 8 * T_loc,
-        }
-        kernels = {}
-        for k, b in alg.items():
-            t = stage_ms.get(k, 0.0)
-            if t > 0:
-                gbs = b / (t * 1e-3) / 1e9
-                kernels[k] = {"ms": round(t, 4), "alg_bytes": int(b), "gbs": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"),
-                  key=lambda k: stage_ms.get(k, 0.0))
+        grid_x = run.grid_x
+        ms_per_step = m["ms_per_step"]
+        stage_ms = dict(m["stage_ms"])
+        blocks = m["plan"] == "blocks"
+        alg = alg_bytes(m, n_splats, W, H, grid_x, 48 if full_sh else 3)
+        kernels = kernel_table(m, alg)
+        dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"), key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
                      "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)",
                      "blend": "blend_blocks_kernel" if blocks else "blend_wave_kernel",
-                     "duplicate": "block_emit_kernel (sorted lists written directly)" if blocks else "emit_chunk_kernel", "preprocess": "preprocess_kernel", "ranges": "tile_ranges_kernel"}
+                     "duplicate": "block_emit_kernel (sorted lists written directly)" if blocks else "emit_chunk_kernel",
+                     "preprocess": "preprocess_inria_kernel" if inria else "preprocess_kernel", "ranges": "tile_ranges_search_kernel"}
 
-        # HBM bytes per launch measured with PMC counters in separate rocprofv3 passes of this same
-        # command (profiles/): valid only for the default single-GPU workload they were taken on.
-        traffic = {}
-        default_frame = (not distributed and args.scene == "garden_like" and args.splats == 5_834_784 and (W, H) == (1920, 1080))
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")
-        if default_frame and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("blocks" if blocks else "sort", {})
+        # HBM bytes and instruction counts per launch measured with PMC counters in separate rocprofv3 passes of this
+        # same command (profiles/): valid only for the default single-GPU workload they were taken on.
+        traffic, traffic_src, blend_pmc = {}, None, {}
+        if default_frame and not distributed:
+            tj, traffic_src = load_profile_json("pmc_traffic_r02.json", "pmc_traffic_r01.json")
+            traffic = tj.get("blocks" if blocks else "sort", {})
+            blend_pmc = tj.get("blend_insts", {})
 
         def roof(k, note):
             e = kernels.get(k, {"gbs": 0.0, "ms": 0.0, "alg_bytes": 0})
             return {"bound": "hbm", "kernel": dom_names[k], "achieved": e["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(e["gbs"] / HBM_PEAK_GBS, 5), "traffic": traffic.get(k),
-                    "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc, separate passes)" if k in traffic else None,
+                    "traffic_source": f"{traffic_src} (rocprofv3 --pmc, separate passes)" if k in traffic else None,
                     "algorithmic_bytes_per_launch": e["alg_bytes"], "avg_launch_ms": e["ms"], "note": note}
 
         if args.backward:
-            stage_ms["render_backward"] = bw_ms[0] / prof_steps
-            stage_ms["chain_backward"] = bw_ms[1] / prof_steps
+            stage_ms["render_backward"], stage_ms["chain_backward"] = m["backward_ms"]
+        rb = roof("blend", "the kernel BASELINE.json names; bound by vector-instruction issue, not HBM (~100 flop/B): the HBM "
+                           "fraction is reported as measured, the issue fraction beside it")
+        rb.update(blend_issue_fractions(blend_pmc, stage_ms.get("blend", 0.0)))
+        rb["ms_per_million_staged_records"] = round(stage_ms.get("blend", 0.0) / max(m["records_staged"], 1) * 1e6, 5)
         out = {
             "metric": "forward_backward_msplats_per_s" if args.backward else "forward_msplats_per_s",
             "value": round(n_splats / (ms_per_step * 1e-3) / 1e6, 3),
@@ -273,23 +498,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{label}, {W}x{H} forward, fixed reference default camera",
-                       "width": W, "height": H, "splats": n_splats, "visible": n_visible_total, "num_rendered": r_total,
-                       "records_staged": r_f_total, "minstances_per_s": round(r_total / (ms_per_step * 1e-3) / 1e6, 2),
-                       "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "binning_plan": plan_used,
-                       "bands": exch.bounds if exch else None},
+            "config": {"workload": f"{label}, {W}x{H} forward, camera at {tuple(round(v, 3) for v in pos)}"
+                                   + (" (the reference's default pose)" if not args.pose and args.scene != "stress" else ""),
+                       "width": W, "height": H, "splats": n_splats, "visible": m["visible"], "num_rendered": m["num_rendered_total"],
+                       "records_staged": m["records_staged_total"],
+                       "minstances_per_s": round(m["num_rendered_total"] / (ms_per_step * 1e-3) / 1e6, 2),
+                       "semantics": args.semantics + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)"),
+                       "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "rccl_ranks": world if distributed else 0,
+                       "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"],
+                       "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
                                   "duplicate": "block_emit_kernel (the sorted keys / values)", "blend": "blend_blocks_kernel"} if blocks else
                                  {"depth_order": "visible-key compaction + depth sort + column counts / scan", "duplicate": "emit_chunk_kernel",
                                   "sort_pass2": "onesweep pass on the tile row", "blend": "blend_wave_kernel"}),
-            "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {prof_steps} "
+            "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {m['prof_steps']} "
                                 f"frames of the same workload run right after the timed region; those frames took "
-                                f"{elapsed_profiled / prof_steps * 1e3:.4f} ms each with the events in place"),
+                                f"{m['profiled_ms_per_step']:.4f} ms each with the events in place"),
             "roofline": roof(dom, "dominant kernel of this frame; HIP-event time of the launch on its own stream"),
-            "roofline_blend": roof("blend", "the kernel BASELINE.json names; VALU-bound (~100 flop/B), fraction as measured"),
+            "roofline_blend": rb,
             "kernels": kernels,
         }
+        out.update(extras)
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)
     if distributed:
@@ -298,7 +528,16 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(out), flush=True)          # the ONE JSON line, last thing on stdout
+    return 0
+
+
+def brief(e, n_splats, what):
+    """Compact record of an extra (untimed-for-the-headline) measurement."""
+    return {"what": what, "ms_per_step": round(e["ms_per_step"], 4), "fps": round(1e3 / e["ms_per_step"], 2),
+            "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
+            "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],
+            "sorted_lists_written": e["lists_written"], "stage_ms": {k: round(v, 4) for k, v in e["stage_ms"].items() if v > 0}}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
