@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
 
-    const int tile_local = xcd_tile_of_block(blockIdx.x, p.num_tiles);
+    const int tile_local = tile_of_workgroup((int)blockIdx.x);
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
@@ -55,26 +55,18 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height);
     const uint2 range = p.ranges[tile];
     const uint32_t total = range.y - range.x;          // unsigned wrap as in the reference
-    const uint32_t rounds256 = (total + kBatch - 1) / kBatch;
     unsigned long long staged = 0;
     bool all_done = tile_lanes_all_done(s);
 
-    for (uint32_t b = 0; b < rounds256 && !all_done; ++b) {
-        const uint32_t batch_first = b * (uint32_t)kBatch;
-        const uint32_t batch_cnt = min((uint32_t)kBatch, total - batch_first);
-        staged += batch_cnt;                          // the reference stages the whole batch here
-        for (uint32_t c0 = 0; c0 < batch_cnt && !all_done; c0 += kWave) {
-            const uint32_t chunk = min((uint32_t)kWave, batch_cnt - c0);
-            if ((uint32_t)lane < chunk) {
-                const uint32_t id = p.point_list[range.x + batch_first + c0 + (uint32_t)lane];
-                s_xy[lane] = p.means2D[id];
-                s_co[lane] = p.conic_opacity[id];
-                const float* c = p.colors + 3 * (size_t)id;
-                s_rgb[lane] = make_float4(c[0], c[1], c[2], 0.0f);
-            }
-            // wave-private LDS: the writes above and the reads below are ordered inside the wave
-            all_done = composite_staged(s, s_xy, s_co, s_rgb, chunk, batch_first + c0 + 1u, p.t_cutoff);
-        }
+    TileFeed feed;
+    feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
+    feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
+    feed.total = total; feed.t_cutoff = p.t_cutoff;
+    for (uint32_t pos = 0; pos < total && !all_done; pos += kWave) {
+        const uint32_t cnt = min((uint32_t)kWave, total - pos);
+        const bool present = (uint32_t)lane < cnt;
+        const uint32_t id = present ? p.point_list[range.x + pos + (uint32_t)lane] : 0u;
+        all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, present, id, (uint32_t)lane, pos, cnt, staged);
     }
     tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);

@@ -10,6 +10,52 @@ namespace gsr {
 
 constexpr int kBatch = 256;
 
+// ---- records that cannot touch the tile ----------------------------------------------------------------------
+// A tile's list holds every Gaussian whose RECTANGLE covers the tile (GSCuda.cu:449-474), and the rectangle is
+// generous: its y extent is ceil(3 * cov.z) pixels (no square root, GSCuda.cu:352). On the frames measured here
+// 73-93 % of the records staged by a tile light none of its pixels: every pixel fails `alpha < 1/255`
+// (GSCuda.cu:646). Such a record changes nothing but the numbering of the records behind it, so it is dropped
+// when the batch is staged (one lane per record), not walked by the compositing loop (one wave per record):
+//   power(d) = -0.5 (A dx^2 + C dy^2) - B dx dy is concave for a positive definite conic, so its maximum over
+//   the tile's pixel rectangle is 0 if the centre lies inside and otherwise sits on one of the four edges, where
+//   it is a 1-D parabola with a closed-form clamped maximiser. A pixel can pass the alpha test only if
+//   opacity * exp(power) >= 1/255, i.e. power >= -ln(255 * opacity).
+// The bound is evaluated over the real rectangle (a superset of the integer pixel centres) with a margin for
+// rounding (relative to the magnitude of the terms that cancel), so a dropped record provably contributes to no
+// pixel; anything odd (conic not positive definite, NaN, opacity <= 0 or NaN) keeps the record.
+struct TileBox { float x_lo, x_hi, y_lo, y_hi; };      // pixel-centre rectangle of the tile, clipped to the image
+
+__device__ __forceinline__ TileBox tile_box(int tx, int ty, int width, int height) {
+    TileBox b;
+    b.x_lo = (float)(tx * kTile); b.x_hi = (float)min(tx * kTile + kTile - 1, width - 1);
+    b.y_lo = (float)(ty * kTile); b.y_hi = (float)min(ty * kTile + kTile - 1, height - 1);
+    return b;
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// upper bound of power on the segment {dx = e, dy in [lo, hi]} (A: coefficient of the fixed coordinate, C: of the free one)
+__device__ __forceinline__ float edge_power_bound(float A, float B, float C, float inv_c, float e, float lo, float hi) {
+    const float d = clampf(-(B * e) * inv_c, lo, hi);
+    const float t0 = 0.5f * A * e * e, t1 = 0.5f * C * d * d, t2 = B * e * d;
+    return -(t0 + t1) - t2 + 1e-5f * (t0 + t1 + fabsf(t2));      // + rounding of the three terms that cancel
+}
+
+__device__ __forceinline__ bool record_misses_tile(const float2 xy, const float4 co, const TileBox& box) {
+    const float A = co.x, B = co.y, C = co.z;
+    const bool pd = A > 0.0f && C > 0.0f && A * C - B * B > 0.0f && fabsf(xy.x) < 1e30f && fabsf(xy.y) < 1e30f;
+    // d = centre - pixel (GSCuda.cu:626): d ranges over [centre - hi, centre - lo]
+    const float dx_lo = xy.x - box.x_hi, dx_hi = xy.x - box.x_lo, dy_lo = xy.y - box.y_hi, dy_hi = xy.y - box.y_lo;
+    const bool inside = dx_lo <= 0.0f && dx_hi >= 0.0f && dy_lo <= 0.0f && dy_hi >= 0.0f;
+    const float inv_a = 1.0f / A, inv_c = 1.0f / C;
+    float best = edge_power_bound(A, B, C, inv_c, dx_lo, dy_lo, dy_hi);
+    best = fmaxf(best, edge_power_bound(A, B, C, inv_c, dx_hi, dy_lo, dy_hi));
+    best = fmaxf(best, edge_power_bound(C, B, A, inv_a, dy_lo, dx_lo, dx_hi));
+    best = fmaxf(best, edge_power_bound(C, B, A, inv_a, dy_hi, dx_lo, dx_hi));
+    const float threshold = -__logf(255.0f * co.w);             // NaN for opacity <= 0 or NaN: the comparison below is then false
+    return pd && !inside && (best + 2e-3f < threshold);
+}
+
 // exp(power) >= 1/255 needs power >= -ln(255) = -5.5413; anything below -5.56 fails the
 // alpha >= 1/255 test for every opacity <= 1 with a 1.9 % margin, far outside rounding.
 constexpr float kPowerFloor = -5.56f;
@@ -46,13 +92,14 @@ __device__ __forceinline__ bool tile_lanes_all_done(const TileLanes& s) {
     return __ballot((s.done[0] & s.done[1] & s.done[2] & s.done[3]) == 0u) == 0ull;
 }
 
-// Composites the `chunk` records staged in wave-private LDS (record j is the tile's contributor number
-// first_contributor + j, 1-based). dx and the terms that only depend on it are computed once per record
+// Composites the `chunk` records staged in wave-private LDS (s_rgb[j].w carries, as bits, the record's 1-based
+// position in the tile's list: the contributor number of GSCuda.cu:624 — records dropped at staging leave gaps).
+// dx and the terms that only depend on it are computed once per record
 // and lane; the per-row terms run as packed f32 pairs (v_pk_mul_f32 / v_pk_add_f32: two IEEE single
 // operations per issue, same rounding as the scalar form, no fused multiply-add). Returns true as soon as
 // every pixel of the tile is finished.
 __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
-                                                 uint32_t chunk, uint32_t first_contributor, float t_cutoff) {
+                                                 uint32_t chunk, float t_cutoff) {
     for (uint32_t j = 0; j < chunk; ++j) {
         const float2 xy = s_xy[j];
         const float4 co = s_co[j];
@@ -75,7 +122,7 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
         }
         if (__ballot(any_cand) == 0ull) continue;
         const float4 col = s_rgb[j];
-        const uint32_t contributor = first_contributor + j;
+        const uint32_t contributor = __float_as_uint(col.w);
         bool newly_done = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -99,6 +146,52 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
     return false;
 }
 
+// Stages the records of one batch of up to 64 list entries and composites them. Lane l holds entry l of the batch
+// (`present`: the lane has an entry; `id`: its Gaussian; `number`: its 1-based position in the tile's list).
+// `first_number`..: the batch covers list positions [first_number - 1, first_number - 1 + count). The staged-record
+// count keeps the reference's granularity: a batch of 256 list positions is "staged" when its first position is
+// reached with some pixel unfinished (GSCuda.cu:595-609), whether or not its records survive the footprint test.
+struct TileFeed {
+    const float2* means2D;
+    const float* colors;
+    const float4* conic_opacity;
+    TileBox box;
+    uint32_t total;                 // records in the tile's list
+    float t_cutoff;
+};
+
+__device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, float2* s_xy, float4* s_co, float4* s_rgb,
+                                                    bool present, uint32_t id, uint32_t rank, uint32_t pos, uint32_t count,
+                                                    unsigned long long& staged) {
+    float2 xy = make_float2(0.0f, 0.0f);
+    float4 co = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (present) { xy = f.means2D[id]; co = f.conic_opacity[id]; }
+    const bool keep = present && !record_misses_tile(xy, co, f.box);
+    const unsigned long long m2 = __ballot(keep);
+    const uint32_t kept = (uint32_t)__popcll(m2);
+    if (keep) {
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+        const float* c = f.colors + 3 * (size_t)id;
+        s_xy[slot] = xy;
+        s_co[slot] = co;
+        s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
+    }
+    // wave-private LDS: the writes above and the reads of composite_staged are ordered inside the wave
+    bool all_done = false;
+    uint32_t first = 0;
+    const uint32_t boundary = (pos + (uint32_t)kBatch - 1u) & ~((uint32_t)kBatch - 1u);   // first multiple of 256 >= pos
+    if (boundary < pos + count) {
+        // records in front of the boundary first; then the reference would test "whole tile done" and stage the next 256
+        const uint32_t before = (uint32_t)__popcll(__ballot(keep && rank < boundary - pos));
+        if (before) all_done = composite_staged(s, s_xy, s_co, s_rgb, before, f.t_cutoff);
+        if (all_done) return true;
+        staged += min((uint32_t)kBatch, f.total - boundary);
+        first = before;
+    }
+    if (kept > first) all_done = composite_staged(s, s_xy + first, s_co + first, s_rgb + first, kept - first, f.t_cutoff);
+    return all_done;
+}
+
 __device__ __forceinline__ void tile_lanes_write(const TileLanes& s, int width, int height, const float* __restrict__ background,
                                                  float* __restrict__ final_t, uint32_t* __restrict__ n_contrib,
                                                  float* __restrict__ out_color) {
@@ -116,11 +209,10 @@ __device__ __forceinline__ void tile_lanes_write(const TileLanes& s, int width, 
     }
 }
 
-// Blocks b and b+8 share an XCD (and its L2). Give every XCD one contiguous run of tiles so
-// the Gaussians neighbouring tiles share are gathered through one L2.
-__device__ __forceinline__ int xcd_tile_of_block(int b, int n) {
-    const int q = n / 8, r = n % 8, x = b % 8, k = b / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
+// Tile of a workgroup: tiles are dealt to workgroups in tile order, so the eight XCDs (workgroups b and b + 8 share
+// one) each get every eighth tile. Giving every XCD one contiguous run of tiles instead (so that neighbouring
+// tiles gather their Gaussians through one L2) measured 6-23 % SLOWER: the image's busy rows then land on two or
+// three XCDs while the others idle (headline frame 0.31 vs 0.29 ms, pose outside the cloud 6.3 vs 5.4 ms).
+__device__ __forceinline__ int tile_of_workgroup(int b) { return b; }
 
 }  // namespace gsr

@@ -517,10 +517,11 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
 // ---- blend straight from the block lists -------------------------------------------------------------
 // The tile's records, in list order, are the entries of its block whose (column mask & row mask) bit is
 // set — the same filter the emission applies. Reading them from the block lists makes the blend
-// independent of the emission, which can then run beside it on a second stream: the blend is bound by
-// vector ALU work, the emission by the HBM write path. Per batch of 64 entries the covered ones are
-// staged compacted (v_mbcnt rank) in wave-private LDS and composited by the shared core; the 256-record
-// batches of the reference survive as the granularity of the staged-record count.
+// independent of the emission (which may run beside it on a second stream, or not at all:
+// GSR_FLAG_NO_SORTED_LISTS). Per batch of 64 entries the covered ones fetch their record, the ones whose
+// footprint can reach the tile are staged compacted (v_mbcnt rank) in wave-private LDS and composited by the
+// shared core (blend_core.hpp); the 256-record batches of the reference survive as the granularity of the
+// staged-record count.
 struct BlockBlendParams {
     BlockMeta meta;
     int nbx;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
     const int wpt = p.waves_per_tile;
-    const int tile_local = xcd_tile_of_block((int)blockIdx.x / wpt, p.num_tiles);
+    const int tile_local = tile_of_workgroup((int)blockIdx.x / wpt);
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
@@ -561,7 +562,11 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
     const uint32_t col = (uint32_t)(tx % kBW), row = 8u + (uint32_t)(ty % kBH);
     const uint32_t u0 = p.meta.unit_start()[b], u1 = p.meta.unit_start()[b + 1];
     const uint32_t list0 = p.meta.list_start()[b];
-    uint32_t pos = 0;                                   // records of this tile composited so far
+    TileFeed feed;
+    feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
+    feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
+    feed.total = total; feed.t_cutoff = p.t_cutoff;
+    uint32_t pos = 0;                                   // list positions of this tile walked so far
     for (uint32_t u = u0; u < u1 && !all_done; ++u) {
         const uint2* um = p.unit_masks + (size_t)u * 16 * kBatches + (lane & (kBatches - 1));
         const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
@@ -572,24 +577,11 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
             const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
             const unsigned long long m = ((unsigned long long)hi << 32) | lo;
             if (m == 0ull) continue;
-            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                const uint32_t slot = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                const uint32_t id = p.ent_idx[e0 + (uint32_t)w * kWave + (uint32_t)lane];
-                s_xy[slot] = p.means2D[id];
-                s_co[slot] = p.conic_opacity[id];
-                const float* c = p.colors + 3 * (size_t)id;
-                s_rgb[slot] = make_float4(c[0], c[1], c[2], 0.0f);
-            }
+            const bool present = __builtin_amdgcn_inverse_ballot_w64(m);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            const uint32_t id = present ? p.ent_idx[e0 + (uint32_t)w * kWave + (uint32_t)lane] : 0u;
             const uint32_t cnt = (uint32_t)__popcll(m);
-            // composite, stopping at every 256-record boundary of the tile's list to count the batch the
-            // reference would stage there (it stages a whole batch whenever a pixel is still unfinished)
-            for (uint32_t j0 = 0; j0 < cnt && !all_done;) {
-                const uint32_t at = pos + j0;
-                if ((at & (kBatch - 1)) == 0u) staged += min((uint32_t)kBatch, total - at);
-                const uint32_t nrec = min(cnt - j0, (uint32_t)kBatch - (at & (kBatch - 1)));
-                all_done = composite_staged(s, s_xy + j0, s_co + j0, s_rgb + j0, nrec, at + 1u, p.t_cutoff);
-                j0 += nrec;
-            }
+            all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, present, id, rank, pos, cnt, staged);
             pos += cnt;
         }
     }
