@@ -17,7 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
-#include "gsr_common.hpp"
+#include "blend_core.hpp"
 
 namespace gsr {
 namespace {
@@ -88,21 +88,35 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     for (int off = 32; off > 0; off >>= 1) hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, kWave));
     if (hi == 0) return;
     const uint2 range = p.ranges[tile];
+    const TileBox box = tile_box(tx, ty, p.dims.width, p.dims.height);
 
     for (int c = (int)((hi - 1) / kWave); c >= 0; --c) {
         const uint32_t first = (uint32_t)c * kWave;
         const uint32_t cnt = min((uint32_t)kWave, hi - first);
-        if ((uint32_t)lane < cnt) {
-            const uint32_t id = p.point_list[range.x + first + (uint32_t)lane];
-            s_id[lane] = id;
-            s_xy[lane] = p.means2D[id];
-            s_co[lane] = p.conic_opacity[id];
+        // As in the forward blend (blend_core.hpp): most records of a tile's list cannot light any of its pixels;
+        // they are dropped here, one lane per record, instead of being walked by the whole wave.
+        uint32_t id = 0;
+        float2 xy_l = make_float2(0.0f, 0.0f);
+        float4 co_l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const bool present = (uint32_t)lane < cnt;
+        if (present) {
+            id = p.point_list[range.x + first + (uint32_t)lane];
+            xy_l = p.means2D[id];
+            co_l = p.conic_opacity[id];
+        }
+        const bool keep = present && !record_misses_tile(xy_l, co_l, box);
+        const unsigned long long kept_mask = __ballot(keep);
+        if (keep) {
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(kept_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept_mask, 0u));
+            s_id[slot] = id;
+            s_xy[slot] = xy_l;
+            s_co[slot] = co_l;
             const float* col = p.colors + 3 * (size_t)id;
-            s_rgb[lane] = make_float4(col[0], col[1], col[2], 0.0f);
+            s_rgb[slot] = make_float4(col[0], col[1], col[2], __uint_as_float(first + (uint32_t)lane));
         }
         // wave-private LDS: the writes above and the reads below are ordered inside the wave
-        for (int j = (int)cnt - 1; j >= 0; --j) {
-            const uint32_t idx0 = first + (uint32_t)j;          // 0-based position in the tile's list
+        for (int j = (int)__popcll(kept_mask) - 1; j >= 0; --j) {
+            const uint32_t idx0 = __float_as_uint(s_rgb[j].w);   // 0-based position in the tile's list
             const float2 xy = s_xy[j];
             const float4 co = s_co[j];
             const float dx = xy.x - fx;

@@ -170,10 +170,7 @@ def _tile_rects(means2D, ext, gx, gy):
     return x0, y0, x1, y1
 
 
-MAX_DEPTH = 6000        # the oracle holds [records x 256] float64 arrays per tile: deeper tiles are passed over
-
-
-def _oracle_gradients(r, dL, bg, tiles, targets):
+def _oracle_gradients(r, dL, bg, tiles, targets, max_depth):
     """Float64 gradients (oracle/backward_np.blend_tile_backward) of the Gaussians `targets`, summed over `tiles`
     (which must contain every tile those Gaussians touch). Returns (dict of [len(targets), d] arrays, pixels whose
     last contributor differs from the GPU's)."""
@@ -196,7 +193,7 @@ def _oracle_gradients(r, dL, bg, tiles, targets):
         nc_tile = ncontrib[ya:yb, xa:xb]
         depth = int(nc_tile.max())                       # the list prefix that reaches every pixel's last contributor
         a = int(ranges[t, 0])
-        assert depth <= int(ranges[t, 1]) - a and depth <= MAX_DEPTH
+        assert depth <= int(ranges[t, 1]) - a and depth <= max_depth
         ids = plist[a:a + depth].to(torch.int64)
         tile_g = np.zeros((3, 16, 16))
         tile_g[:, : yb - ya, : xb - xa] = dL[:, ya:yb, xa:xb].cpu().numpy()
@@ -204,8 +201,8 @@ def _oracle_gradients(r, dL, bg, tiles, targets):
                                     geo["rgb"][ids].cpu().numpy(), tx, ty, W, H, bg, tile_g)
         bad = int((res["n_contrib"][: yb - ya, : xb - xa] != nc_tile.cpu().numpy()).sum())
         mismatch += bad
-        if bad == 0:
-            assert np.abs(res["out"][:, : yb - ya, : xb - xa] - r.out_color[:, ya:yb, xa:xb].cpu().numpy()).max() <= 1e-4
+        if bad == 0:       # float32 chain of up to 10 000 records against float64: sanity only (parity is the C++ oracle's job)
+            assert np.abs(res["out"][:, : yb - ya, : xb - xa] - r.out_color[:, ya:yb, xa:xb].cpu().numpy()).max() <= 1e-3
         rows = row_of[ids.cpu().numpy()]
         hit = rows >= 0
         np.add.at(sums["dL_dmean2D"], rows[hit], res["d_mean"][hit])
@@ -233,7 +230,9 @@ def _compare_gradients(got_dev, targets, exp, allowed_outliers, what):
             assert (got[k][zero] == 0).all(), (what, k, "a Gaussian no pixel composites must get exactly zero")
 
 
-def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_tiles_each=64, max_union=700, max_pick=120):
+def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_tiles_each=64, max_union=700, max_pick=120,
+                max_depth=6000):
+    # max_depth: the oracle holds [records x 256] float64 arrays per tile; tiles whose deepest pixel walks more are passed over
     """forward + backward at one camera; returns the number of Gaussians that received colour gradient."""
     import torch
     from gsrast_amd import scenes
@@ -254,7 +253,7 @@ def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_ti
     assert bool((((x1 - x0) * (y1 - y0)).to(torch.int64)[vis] == tt[vis]).all())
     nc = r.map_image_state()["nContrib"].to(torch.int32)
     tile_depth = torch.nn.functional.pad(nc, (0, gx * 16 - W, 0, gy * 16 - H)).view(gy, 16, gx, 16).amax(dim=(1, 3))
-    deep = (tile_depth > MAX_DEPTH).cpu().numpy()
+    deep = (tile_depth > max_depth).cpu().numpy()
 
     # (1) Gaussians chosen at random among those whose tiles all lie inside one of 40 random 2 x 2-tile windows: their
     # gradients come from those tiles only, so the oracle evaluated on the windows gives them completely.
@@ -270,11 +269,15 @@ def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_ti
     inside = torch.zeros_like(vis)
     for wx, wy in wins:
         inside |= vis & (x0 >= wx) & (x1 <= wx + 2) & (y0 >= wy) & (y1 <= wy + 2)
-    cand = torch.nonzero(inside).flatten().cpu().numpy()
-    cand = np.sort(np.random.default_rng(seed + 1).permutation(cand)[:2000])
-    assert cand.size >= 500, cand.size
+    # up to 1 000 of those that received gradient and up to 1 000 of those that did not (on a frame whose tiles saturate
+    # early, a uniform draw among the visible Gaussians would hold almost none of the former)
+    pool_a = torch.nonzero(inside & with_grad).flatten().cpu().numpy()
+    pool_b = torch.nonzero(inside & ~with_grad).flatten().cpu().numpy()
+    pick = np.random.default_rng(seed + 1)
+    cand = np.sort(np.concatenate([pick.permutation(pool_a)[:1000], pick.permutation(pool_b)[:1000]]))
+    assert cand.size >= 500, (pool_a.size, pool_b.size)
     tiles = sorted({(wx + i, wy + j) for wx, wy in wins for i in (0, 1) for j in (0, 1)})
-    exp, mismatch = _oracle_gradients(r, dL, bg, tiles, cand)
+    exp, mismatch = _oracle_gradients(r, dL, bg, tiles, cand, max_depth)
     assert mismatch <= 8, mismatch              # exp implementations may flip a threshold on a handful of pixels
     _compare_gradients(got_dev, cand, exp, mismatch, "random Gaussians inside windows")
     n_grad = int((np.abs(exp["dL_dcolors"]).sum(1) > 0).sum())
@@ -295,7 +298,7 @@ def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_ti
             break
     keep = np.asarray(sorted(keep))
     if keep.size:
-        exp2, mismatch2 = _oracle_gradients(r, dL, bg, sorted(tiles), keep)
+        exp2, mismatch2 = _oracle_gradients(r, dL, bg, sorted(tiles), keep, max_depth)
         assert mismatch2 <= 8, mismatch2
         _compare_gradients(got_dev, keep, exp2, mismatch2, "Gaussians with gradient")
         assert (np.abs(exp2["dL_dcolors"]).sum(1) > 0).all()
@@ -327,5 +330,5 @@ def test_config5_garden_1080p_forward_backward_fullsize():
     assert r.last_num_rendered > 200_000_000 and n_grad > 500 and n_checked >= 5, (n_grad, n_checked)
     # a pose outside the cloud: small splats, deep lists, most visible Gaussians receive gradient
     cam2 = camera.default_camera(W, H, near=0.001 * span, far=span, position=(0.0, 0.0, -14.0))
-    n_grad2, n_checked2 = _check_pose(r, scene, cam2, bg, seed=9, min_with_gradient=100)
+    n_grad2, n_checked2 = _check_pose(r, scene, cam2, bg, seed=9, min_with_gradient=100, n_windows=24, max_depth=10000)
     assert n_grad2 > 100_000 and n_checked2 >= 20, (n_grad2, n_checked2)
