@@ -62,11 +62,27 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
     feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
     feed.total = total; feed.t_cutoff = p.t_cutoff;
-    for (uint32_t pos = 0; pos < total && !all_done; pos += kWave) {
-        const uint32_t cnt = min((uint32_t)kWave, total - pos);
-        const bool present = (uint32_t)lane < cnt;
-        const uint32_t id = present ? p.point_list[range.x + pos + (uint32_t)lane] : 0u;
-        all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, present, id, (uint32_t)lane, pos, cnt, staged);
+    // batch k = list positions [64 k, 64 k + 64); ids are fetched two batches ahead, records one batch ahead
+    auto next_batch = [&](uint32_t pos) {
+        RecordBatch nb;
+        nb.valid = pos < total;
+        if (nb.valid) {
+            const uint32_t cnt = min((uint32_t)kWave, total - pos);
+            nb.mask = cnt == kWave ? ~0ull : ((1ull << cnt) - 1ull);
+            nb.pos = pos;
+            if ((uint32_t)lane < cnt) nb.id = p.point_list[range.x + pos + (uint32_t)lane];
+        }
+        return nb;
+    };
+    RecordBatch b0 = next_batch(0);
+    fetch_records(b0, feed);
+    RecordBatch b1 = next_batch(kWave);
+    for (uint32_t pos = 2 * kWave; b0.valid && !all_done; pos += kWave) {
+        fetch_records(b1, feed);
+        RecordBatch b2 = next_batch(pos);
+        all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, b0, staged);
+        b0 = b1;
+        b1 = b2;
     }
     tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);

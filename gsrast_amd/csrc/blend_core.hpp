@@ -160,20 +160,41 @@ struct TileFeed {
     float t_cutoff;
 };
 
+// One batch of up to 64 list entries on its way through the wave: lane l holds entry l. The loads of a batch are
+// issued ahead of its use (ids two batches ahead, records one batch ahead: see the kernels), so the three dependent
+// round trips id -> record -> colour are paid while earlier batches are being composited, not once per batch.
+struct RecordBatch {
+    unsigned long long mask = 0;   // lanes that hold an entry (wave-uniform)
+    uint32_t pos = 0;              // list position of the batch's first entry (wave-uniform)
+    bool valid = false;            // wave-uniform: false = the list is exhausted
+    uint32_t id = 0;               // per lane: Gaussian index
+    float2 xy;                     // per lane: its record
+    float4 co;
+    __device__ __forceinline__ uint32_t count() const { return (uint32_t)__popcll(mask); }
+    __device__ __forceinline__ bool present() const { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+    __device__ __forceinline__ uint32_t rank() const {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    }
+};
+
+__device__ __forceinline__ void fetch_records(RecordBatch& b, const TileFeed& f) {
+    b.xy = make_float2(0.0f, 0.0f);
+    b.co = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (b.valid && b.present()) { b.xy = f.means2D[b.id]; b.co = f.conic_opacity[b.id]; }
+}
+
 __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, float2* s_xy, float4* s_co, float4* s_rgb,
-                                                    bool present, uint32_t id, uint32_t rank, uint32_t pos, uint32_t count,
-                                                    unsigned long long& staged) {
-    float2 xy = make_float2(0.0f, 0.0f);
-    float4 co = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (present) { xy = f.means2D[id]; co = f.conic_opacity[id]; }
-    const bool keep = present && !record_misses_tile(xy, co, f.box);
+                                                    const RecordBatch& b, unsigned long long& staged) {
+    const bool present = b.present();
+    const uint32_t rank = b.rank(), pos = b.pos, count = b.count();
+    const bool keep = present && !record_misses_tile(b.xy, b.co, f.box);
     const unsigned long long m2 = __ballot(keep);
     const uint32_t kept = (uint32_t)__popcll(m2);
     if (keep) {
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-        const float* c = f.colors + 3 * (size_t)id;
-        s_xy[slot] = xy;
-        s_co[slot] = co;
+        const float* c = f.colors + 3 * (size_t)b.id;
+        s_xy[slot] = b.xy;
+        s_co[slot] = b.co;
         s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
     }
     // wave-private LDS: the writes above and the reads of composite_staged are ordered inside the wave

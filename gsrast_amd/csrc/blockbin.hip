@@ -566,24 +566,51 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
     feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
     feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
     feed.total = total; feed.t_cutoff = p.t_cutoff;
-    uint32_t pos = 0;                                   // list positions of this tile walked so far
-    for (uint32_t u = u0; u < u1 && !all_done; ++u) {
-        const uint2* um = p.unit_masks + (size_t)u * 16 * kBatches + (lane & (kBatches - 1));
-        const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
-        const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
-        const uint32_t e0 = list0 + (u - u0) * kUnit;
-        for (int w = 0; w < kBatches && !all_done; ++w) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
-            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-            if (m == 0ull) continue;
-            const bool present = __builtin_amdgcn_inverse_ballot_w64(m);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-            const uint32_t id = present ? p.ent_idx[e0 + (uint32_t)w * kWave + (uint32_t)lane] : 0u;
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, present, id, rank, pos, cnt, staged);
-            pos += cnt;
+    // The tile's batches, in list order: batch w of unit u, for every (u, w) whose mask is not empty. An iterator walks
+    // them; ids are fetched two batches ahead and records one batch ahead of the batch being composited.
+    uint32_t it_u = u0, it_nz = 0, it_pos = 0;          // unit, its batches still to come (bit w), list positions handed out
+    uint32_t tm_lo = 0, tm_hi = 0;                      // lane w < 32: the tile's mask of batch w of unit it_u
+    bool it_loaded = false;
+    auto next_batch = [&]() {
+        RecordBatch nb;
+        for (;;) {
+            if (!it_loaded) {
+                if (it_u >= u1) return nb;               // (valid = false)
+                const uint2* um = p.unit_masks + (size_t)it_u * 16 * kBatches + (lane & (kBatches - 1));
+                const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
+                tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u;
+                tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
+                it_nz = (uint32_t)__ballot((tm_lo | tm_hi) != 0u);
+                it_loaded = true;
+            }
+            if (it_nz != 0u) break;
+            ++it_u;
+            it_loaded = false;
         }
+        const int w = __builtin_amdgcn_readfirstlane(__ffs((int)it_nz) - 1);
+        it_nz &= it_nz - 1u;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
+        nb.mask = ((unsigned long long)hi << 32) | lo;
+        nb.pos = it_pos;
+        nb.valid = true;
+        it_pos += nb.count();
+        if (nb.present()) nb.id = p.ent_idx[list0 + (it_u - u0) * kUnit + (uint32_t)w * kWave + (uint32_t)lane];
+        if (it_nz == 0u) { ++it_u; it_loaded = false; }
+        return nb;
+    };
+    RecordBatch b0, b1;
+    if (!all_done) {
+        b0 = next_batch();
+        fetch_records(b0, feed);
+        b1 = next_batch();
+    }
+    while (b0.valid && !all_done) {
+        fetch_records(b1, feed);
+        RecordBatch b2 = next_batch();
+        all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, b0, staged);
+        b0 = b1;
+        b1 = b2;
     }
     tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
