@@ -75,25 +75,43 @@ struct InriaParams {
     FrameDims dims;
 };
 
+// Memory schedule of a wave, as in preprocess.hip: means; scale / rotation of the lanes in front of the camera; then,
+// if any lane of the wave has a tile, the wave's 64 x 48 SH floats in ONE coalesced sweep (12 KB: twelve 1-KB loads)
+// through wave-private LDS, each lane reading its own record from there; then every store. The first version read
+// a lane's 48 coefficients with 48 scalar loads at a 192-byte stride, three of them at a time behind a byte store
+// (`clamped`) the compiler had to assume they alias: 6.8 ms for 50 M Gaussians at degree 3.
+constexpr int kShFloats = 48;
+constexpr int kShStride = 49;            // LDS floats per record: odd, so the 64 lanes' reads of coefficient k hit 32 banks twice
+
 __global__ __launch_bounds__(256) void preprocess_inria_kernel(const InriaParams p) {
+    __shared__ float s_sh[4][kWave * kShStride];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.n) return;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const bool valid = idx < p.n;
     int32_t out_radius = 0;
     uint32_t out_tiles = 0, out_rect = 0;
     float view_z = 0.0f;
-    const float4 mean = p.means3D[idx];
-    const float* v = p.view;
+    float view[16], proj[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { view[i] = p.view[i]; proj[i] = p.proj[i]; }
+    const float cam0 = p.cam_pos ? p.cam_pos[0] : 0.0f, cam1 = p.cam_pos ? p.cam_pos[1] : 0.0f, cam2 = p.cam_pos ? p.cam_pos[2] : 0.0f;
+    const float4 mean = valid ? p.means3D[idx] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float* v = view;
     const float pvx = v[0] * mean.x + v[4] * mean.y + v[8] * mean.z + v[12];
     const float pvy = v[1] * mean.x + v[5] * mean.y + v[9] * mean.z + v[13];
     const float pvz = v[2] * mean.x + v[6] * mean.y + v[10] * mean.z + v[14];
-    if (!(pvz <= 0.2f)) {
-        const float* m = p.proj;
+    const bool in_front = valid && !(pvz <= 0.2f);
+    float c3[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float pix = 0.0f, piy = 0.0f, ca = 0.0f, cb = 0.0f, cc = 0.0f, det_inv = 0.0f;
+    int ri = 0, x0 = 0, x1 = 0, fy0 = 0, fy1 = 0;
+    bool has_tile = false;
+    if (in_front) {
+        const float* m = proj;
         const float phx = m[0] * mean.x + m[4] * mean.y + m[8] * mean.z + m[12];
         const float phy = m[1] * mean.x + m[5] * mean.y + m[9] * mean.z + m[13];
         const float phw = m[3] * mean.x + m[7] * mean.y + m[11] * mean.z + m[15];
         const float pw = 1.0f / (phw + 0.0000001f);
         const float prx = phx * pw, pry = phy * pw;
-        float c3[6];
         if (p.cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) c3[i] = p.cov3D_precomp[6 * (size_t)idx + i];
@@ -115,10 +133,6 @@ __global__ __launch_bounds__(256) void preprocess_inria_kernel(const InriaParams
             const M3 sigma = mul3(transpose3(mm), mm);
             c3[0] = sigma.m[0][0]; c3[1] = sigma.m[0][1]; c3[2] = sigma.m[0][2];
             c3[3] = sigma.m[1][1]; c3[4] = sigma.m[1][2]; c3[5] = sigma.m[2][2];
-            float2* dst = reinterpret_cast<float2*>(p.cov3Ds + 6 * (size_t)idx);
-            dst[0] = make_float2(c3[0], c3[1]);
-            dst[1] = make_float2(c3[2], c3[3]);
-            dst[2] = make_float2(c3[4], c3[5]);
         }
         const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
         const float tz = pvz;
@@ -139,67 +153,110 @@ __global__ __launch_bounds__(256) void preprocess_inria_kernel(const InriaParams
         vrk.m[1][0] = c3[1]; vrk.m[1][1] = c3[3]; vrk.m[1][2] = c3[4];
         vrk.m[2][0] = c3[2]; vrk.m[2][1] = c3[4]; vrk.m[2][2] = c3[5];
         const M3 cv = mul3(mul3(transpose3(tm), transpose3(vrk)), tm);
-        const float ca = cv.m[0][0] + 0.3f, cb = cv.m[0][1], cc = cv.m[1][1] + 0.3f;
+        ca = cv.m[0][0] + 0.3f; cb = cv.m[0][1]; cc = cv.m[1][1] + 0.3f;
         const float det = ca * cc - cb * cb;
         if (det != 0.0f) {
-            const float det_inv = 1.0f / det;
+            det_inv = 1.0f / det;
             const float mid = 0.5f * (ca + cc);
             const float root = sqrtf(fmaxr(0.1f, mid * mid - det));
             const float my_radius = ceilf(3.0f * sqrtf(fmaxr(mid + root, mid - root)));
-            const float pix = (float)((((double)prx + 1.0) * (double)p.dims.width - 1.0) * 0.5);
-            const float piy = (float)((((double)pry + 1.0) * (double)p.dims.height - 1.0) * 0.5);
-            const int ri = (int)my_radius;
+            pix = (float)((((double)prx + 1.0) * (double)p.dims.width - 1.0) * 0.5);
+            piy = (float)((((double)pry + 1.0) * (double)p.dims.height - 1.0) * 0.5);
+            ri = (int)my_radius;
             const float rf = (float)ri;
-            const int x0 = clampi((int)((pix - rf) / 16.0f), 0, p.dims.grid_x);
-            const int fy0 = clampi((int)((piy - rf) / 16.0f), 0, p.dims.grid_y);
-            const int x1 = clampi((int)((((pix + rf) + 16.0f) - 1.0f) / 16.0f), 0, p.dims.grid_x);
-            const int fy1 = clampi((int)((((piy + rf) + 16.0f) - 1.0f) / 16.0f), 0, p.dims.grid_y);
-            if ((uint32_t)(x1 - x0) * (uint32_t)(fy1 - fy0) != 0) {
-                if (!p.colors_precomp) {
-                    // real SH basis, view direction from the camera centre to the Gaussian
-                    float dx = mean.x - p.cam_pos[0], dy = mean.y - p.cam_pos[1], dz = mean.z - p.cam_pos[2];
-                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                    dx = dx / len; dy = dy / len; dz = dz / len;
-                    const float* sh = p.shs + 48 * (size_t)idx;
-                    float res[3];
+            x0 = clampi((int)((pix - rf) / 16.0f), 0, p.dims.grid_x);
+            fy0 = clampi((int)((piy - rf) / 16.0f), 0, p.dims.grid_y);
+            x1 = clampi((int)((((pix + rf) + 16.0f) - 1.0f) / 16.0f), 0, p.dims.grid_x);
+            fy1 = clampi((int)((((piy + rf) + 16.0f) - 1.0f) / 16.0f), 0, p.dims.grid_y);
+            has_tile = (uint32_t)(x1 - x0) * (uint32_t)(fy1 - fy0) != 0;
+        }
+    }
+
+    // ---- colour of the lanes that have a tile: the wave's SH records, through LDS ----
+    const bool want_sh = !p.colors_precomp;
+    float res[3] = {0.0f, 0.0f, 0.0f};
+    bool neg[3] = {false, false, false};
+    const float opacity = has_tile ? p.opacities[idx] : 0.0f;
+    if (want_sh && __ballot(has_tile) != 0ull) {
+        float* w = s_sh[wave];
+        // the wave's records: floats [first, first + 64 * 48) of shs, 16 bytes per lane and load; a 16-byte piece never
+        // straddles two records (48 is a multiple of 4)
+        const size_t first = ((size_t)blockIdx.x * 256 + (size_t)wave * kWave) * kShFloats;
+        const size_t limit = (size_t)p.n * kShFloats;
+        const int pieces = p.deg > 2 ? 12 : (p.deg > 1 ? 7 : (p.deg > 0 ? 3 : 1));      // 16-byte pieces of a record that hold coefficients 0 .. (deg + 1)^2 - 1
+        float4 piece[12];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float r = SH_C0 * sh[c];
-                        if (p.deg > 0) {
-                            const float x = dx, y = dy, z = dz;
-                            r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
-                            if (p.deg > 1) {
-                                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                                r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] +
-                                    SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] + SH_C2[3] * xz * sh[21 + c] +
-                                    SH_C2[4] * (xx - yy) * sh[24 + c];
-                                if (p.deg > 2) {
-                                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
-                                        SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] +
-                                        SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
-                                        SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
-                                        SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
-                                }
-                            }
+        for (int q = 0; q < 12; ++q) {
+            const int f4 = q * kWave + lane;                      // index of the 16-byte piece inside the wave's block
+            const size_t at = first + 4 * (size_t)f4;
+            const bool needed = (f4 % 12) < pieces;               // pieces of a record beyond the degree in use are not read
+            piece[q] = (needed && at + 3 < limit) ? *reinterpret_cast<const float4*>(p.shs + at) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int f4 = q * kWave + lane;
+            const int rec = f4 / 12, k = (f4 % 12) * 4;
+            float* dst = w + rec * kShStride + k;
+            dst[0] = piece[q].x; dst[1] = piece[q].y; dst[2] = piece[q].z; dst[3] = piece[q].w;
+        }
+        // wave-private LDS: the writes above and the reads below are ordered inside the wave
+        if (has_tile) {
+            const float* sh = w + lane * kShStride;
+            // real SH basis, view direction from the camera centre to the Gaussian
+            float dx = mean.x - cam0, dy = mean.y - cam1, dz = mean.z - cam2;
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float r = SH_C0 * sh[c];
+                if (p.deg > 0) {
+                    const float x = dx, y = dy, z = dz;
+                    r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+                    if (p.deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] +
+                            SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] + SH_C2[3] * xz * sh[21 + c] +
+                            SH_C2[4] * (xx - yy) * sh[24 + c];
+                        if (p.deg > 2) {
+                            r = r + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+                                SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] +
+                                SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                                SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+                                SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
                         }
-                        r += 0.5f;
-                        p.clamped[3 * (size_t)idx + c] = r < 0.0f;
-                        res[c] = fmaxr(r, 0.0f);
                     }
-                    float* o = p.rgb + 3 * (size_t)idx;
-                    o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
                 }
-                const int y0 = clampi(fy0, p.dims.row_begin, p.dims.row_end), y1 = clampi(fy1, p.dims.row_begin, p.dims.row_end);
-                p.depths[idx] = pvz;
-                p.means2D[idx] = make_float2(pix, piy);
-                p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[idx]);
-                out_radius = ri;
-                out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
-                view_z = pvz;
-                if (out_tiles)
-                    out_rect = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - y0) << 24);
+                r += 0.5f;
+                neg[c] = r < 0.0f;
+                res[c] = fmaxr(r, 0.0f);
             }
         }
+    }
+    if (!valid) return;
+
+    // ---- stores from here on ----
+    if (in_front && !p.cov3D_precomp) {
+        float2* dst = reinterpret_cast<float2*>(p.cov3Ds + 6 * (size_t)idx);
+        dst[0] = make_float2(c3[0], c3[1]);
+        dst[1] = make_float2(c3[2], c3[3]);
+        dst[2] = make_float2(c3[4], c3[5]);
+    }
+    if (has_tile) {
+        if (want_sh) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p.clamped[3 * (size_t)idx + c] = neg[c];
+            float* o = p.rgb + 3 * (size_t)idx;
+            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        }
+        const int y0 = clampi(fy0, p.dims.row_begin, p.dims.row_end), y1 = clampi(fy1, p.dims.row_begin, p.dims.row_end);
+        p.depths[idx] = pvz;
+        p.means2D[idx] = make_float2(pix, piy);
+        p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacity);
+        out_radius = ri;
+        out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+        view_z = pvz;
+        if (out_tiles)
+            out_rect = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - y0) << 24);
     }
     p.radii[idx] = out_radius;
     p.tiles_touched[idx] = out_tiles;
