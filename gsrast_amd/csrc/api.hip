@@ -347,6 +347,9 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.sort_info, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
+    // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
+    // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
+    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
     // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
@@ -355,7 +358,7 @@ int gsr_forward(gsr_forward_args* a) {
     if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
     const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
-    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, four_passes ? 4 : 3, stream));
+    if (four_passes) GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream));
     // depth-sorted keys / indices, and the other pair of buffers (free from here on)
     uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k;
     uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v;

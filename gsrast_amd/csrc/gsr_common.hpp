@@ -71,7 +71,8 @@ size_t depth_compact_scratch_bytes(size_t n);
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream);
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
-                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream);
+                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
+                    const uint32_t* n_dev = nullptr);
 
 // Column-major emission (emit.hip): count, column scan and emission. The two events (may be null)
 // are recorded between the N-sized preparation and the emission kernel, for stage timing.

@@ -159,10 +159,13 @@ struct LookBack {
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                            uint32_t n, const DigitSpec spec,
+                                                            uint32_t n_host, const uint32_t* __restrict__ n_dev, const DigitSpec spec,
                                                             const uint32_t* __restrict__ digit_hist,
                                                             unsigned long long* status, uint32_t* ticket,
                                                             uint32_t* error_word) {
+    // n_dev (may be null): the key count lives on the device — the pass was queued before the host knew it, with a
+    // grid sized for an upper bound; workgroups whose ticket lies beyond the last tile leave at once.
+    const uint32_t n = n_dev ? *n_dev : n_host;
     constexpr int RADIX = 1 << BITS;
     constexpr int kLanesPerDigit = (kThreads / RADIX) < kLookLanes ? (kThreads / RADIX) : kLookLanes;
     __shared__ uint32_t wave_hist[kWaves][RADIX];
@@ -357,7 +360,7 @@ inline int radix_bits_for(uint32_t nbins) {
 template <typename KeyT>
 int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
                 const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
-                bool already_cleared) {
+                bool already_cleared, const uint32_t* n_dev = nullptr) {
     const int bits = radix_bits_for(spec.nbins);
     if (bits > 8) return GSR_ERR_INVALID_ARG;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
@@ -367,7 +370,7 @@ int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, ui
     }
 #define GSR_SWEEP(B)                                                                                              \
     hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, \
-                       keys_out, vals_out, n, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
+                       keys_out, vals_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
     switch (bits) {
         case 4: GSR_SWEEP(4); break;
         case 5: GSR_SWEEP(5); break;
@@ -421,8 +424,8 @@ int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* k
 
 int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                    const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
-                   bool already_cleared) {
-    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream, already_cleared);
+                   bool already_cleared, const uint32_t* n_dev) {
+    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream, already_cleared, n_dev);
 }
 
 template <typename KeyT>
@@ -578,8 +581,9 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
 
 // Passes [first, last) of the stable sort of n (key, value) u32 pairs: in -> a -> b -> a -> b. After P
 // passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
+// n_dev (may be null): the true key count on the device, n then being an upper bound that only sizes the grids.
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
-                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream) {
+                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream, const uint32_t* n_dev) {
     if (n == 0) return GSR_OK;
     for (int p = first; p < last; ++p) {
         const uint32_t* src_k = (p == 0) ? keys_in : ((p % 2 == 1) ? a_k : b_k);
@@ -590,7 +594,7 @@ int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n
         spec.mode = kDigitBits; spec.shift = 8 * p; spec.nbins = 256; spec.grid_x = 1; spec.inv_grid_x = 1.0f;
         SweepScratch sc = sc4[p];
         sc.error_word = sc4[0].error_word;
-        const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true);
+        const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev);
         if (rc != GSR_OK) return rc;
     }
     return GSR_OK;

@@ -37,7 +37,7 @@ int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* k
                    bool already_cleared = false);
 int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                    const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
-                   bool already_cleared = false);
+                   bool already_cleared = false, const uint32_t* n_dev = nullptr);
 int sweep_clear(const SweepScratch& sc, uint32_t n, uint32_t nbins, hipStream_t stream);
 
 // Digit counts of `passes` consecutive 8-bit fields starting at begin_bit (the last one
