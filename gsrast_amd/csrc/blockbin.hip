@@ -157,30 +157,35 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
                                                               uint64_t* __restrict__ ent_rd, uint32_t* __restrict__ ent_idx) {
     extern __shared__ uint32_t s_dyn[];
     constexpr int W = CHUNK / 32;                // mask words per block
-    uint32_t* s_mask = s_dyn;                    // [nb][W]
-    uint32_t* s_pre = s_dyn + (size_t)nb * W;    // [nb][W] set bits in the words below
+    // Rows are W + 1 words apart: the lanes of a wave address the SAME word of DIFFERENT blocks (word = lane's
+    // Gaussian >> 5), which at a stride of W = 32 words is one LDS bank for all of them (round 2: 2.7e7 bank-conflict
+    // cycles per launch, a quarter of the kernel's CU time).
+    constexpr int WP = W + 1;
+    uint32_t* s_mask = s_dyn;                    // [nb][WP]
+    uint32_t* s_pre = s_dyn + (size_t)nb * WP;   // [nb][WP] set bits in the words below
     const int r = blockIdx.x * CHUNK + threadIdx.x;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
     if (__syncthreads_or(rect != 0u) == 0) return;          // culled tail of the depth order
-    for (int i = threadIdx.x; i < nb * W; i += CHUNK) s_mask[i] = 0;
+    for (int i = threadIdx.x; i < nb * WP; i += CHUNK) s_mask[i] = 0;
     __syncthreads();
     const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
     uint32_t bx0 = 0, bx1 = 0, by0 = 1, by1 = 0;
     if (rect) { bx0 = x0 / kBW; bx1 = (x0 + w - 1) / kBW; by0 = y0 / kBH; by1 = (y0 + h - 1) / kBH; }
     const uint32_t word = threadIdx.x >> 5, bit = 1u << (threadIdx.x & 31);
     for (uint32_t by = by0; by <= by1; ++by)
-        for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[(by * nbx + bx) * W + word], bit);
+        for (uint32_t bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[(by * nbx + bx) * WP + word], bit);
     __syncthreads();
     // W consecutive lanes scan the W words of one block
     for (int i = threadIdx.x; i < nb * W; i += CHUNK) {
-        const uint32_t c = (uint32_t)__popc(s_mask[i]);
+        const int at = (i / W) * WP + (i & (W - 1));
+        const uint32_t c = (uint32_t)__popc(s_mask[at]);
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < W; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, W);
             if ((int)(threadIdx.x & (W - 1)) >= off) incl += o;
         }
-        s_pre[i] = incl - c;
+        s_pre[at] = incl - c;
     }
     __syncthreads();
     if (!rect) return;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
     for (uint32_t by = by0; by <= by1; ++by)
         for (uint32_t bx = bx0; bx <= bx1; ++bx) {
             const uint32_t b = by * nbx + bx;
-            const uint32_t pos = row[b] + s_pre[b * W + word] + (uint32_t)__popc(s_mask[b * W + word] & (bit - 1u));
+            const uint32_t pos = row[b] + s_pre[b * WP + word] + (uint32_t)__popc(s_mask[b * WP + word] & (bit - 1u));
             ent_rd[pos] = rd;
             ent_idx[pos] = idx;
         }
@@ -691,7 +696,7 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     hipLaunchKernelGGL(blockscan_apply_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial,
                        t.meta.list_start());
     GSR_LAUNCH_CHECK("blockscan_apply_kernel");
-    const size_t mask_bytes = (size_t)t.nb * (t.chunk / 32) * 4 * 2;
+    const size_t mask_bytes = (size_t)t.nb * (t.chunk / 32 + 1) * 4 * 2;
     if (t.chunk == kCoarse) {
         hipLaunchKernelGGL(coarse_emit_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
                            sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
