@@ -123,6 +123,7 @@ SIGNATURES = {
     "gsr_ply_parse_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "gsr_ply_activate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "gsr_footprint_misses_tile": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsr_ply_activate_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]),
 }

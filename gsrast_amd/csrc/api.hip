@@ -243,6 +243,13 @@ int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const ui
     return fail(launch_sort_pairs(keys_in, keys_out, values_in, values_out, n, begin_bit, end_bit, temp, (hipStream_t)stream));
 }
 
+int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_opacity, const int32_t* tile_xy, int width,
+                              int height, uint8_t* misses, void* stream) {
+    g_hip_error[0] = 0;
+    if (n > 0 && (!means2D || !conic_opacity || !tile_xy || !misses || width <= 0 || height <= 0)) return fail(GSR_ERR_INVALID_ARG);
+    return fail(launch_footprint_test(n, means2D, conic_opacity, tile_xy, width, height, misses, (hipStream_t)stream));
+}
+
 int gsr_poll_async_error(void) {
     if (g_rb_last && g_rb_last->host && (g_rb_last->host[1] || g_rb_last->host[2])) return fail(GSR_ERR_INTERNAL);
     return GSR_OK;

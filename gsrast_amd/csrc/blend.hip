@@ -88,7 +88,26 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
 }
 
+// Stage entry point for the tests: the footprint test of blend_core.hpp on n (record, tile) pairs.
+__global__ __launch_bounds__(256) void footprint_test_kernel(int n, const float2* __restrict__ xy, const float4* __restrict__ co,
+                                                             const int2* __restrict__ tile, int width, int height,
+                                                             uint8_t* __restrict__ misses) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    misses[i] = record_misses_tile(xy[i], co[i], tile_box(tile[i].x, tile[i].y, width, height)) ? 1 : 0;
+}
+
 }  // namespace
+
+int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,
+                          uint8_t* misses, hipStream_t stream) {
+    if (n <= 0) return GSR_OK;
+    hipLaunchKernelGGL(footprint_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n,
+                       reinterpret_cast<const float2*>(xy), reinterpret_cast<const float4*>(conic_opacity),
+                       reinterpret_cast<const int2*>(tile_xy), width, height, misses);
+    GSR_LAUNCH_CHECK("footprint_test_kernel");
+    return GSR_OK;
+}
 
 int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
                  const float* means2D, const float* colors, const float* conic_opacity,

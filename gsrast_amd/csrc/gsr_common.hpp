@@ -103,4 +103,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream);
 
+int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,
+                          uint8_t* misses, hipStream_t stream);
+
 }  // namespace gsr

@@ -202,6 +202,13 @@ size_t gsr_sort_temp_bytes(size_t n);
 int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
                            uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, void* stream);
 
+/* The blend's footprint test (csrc/blend_core.hpp), record by record: misses[i] = 1 iff the library would drop record i
+ * (centre means2D[i], conic + opacity conic_opacity[i]) when it stages the list of tile tile_xy[i] = (tx, ty) of a
+ * width x height image, i.e. iff it has PROVEN that no pixel of that tile passes alpha >= 1/255 (GSCuda.cu:645-646).
+ * All pointers are device pointers. For the tests: a dropped record that could light a pixel would be a parity bug. */
+int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_opacity, const int32_t* tile_xy,
+                              int width, int height, uint8_t* misses, void* stream);
+
 /* ---- backward pass (next row after the hot path: BASELINE config 5) ----
  * Gradients of L = sum(dL_dout_color * out_color) of ONE gsr_forward call (gscuda semantics) w.r.t. the
  * per-Gaussian quantities its blend loop reads, and on to the 3-D covariance and the DC harmonics. The

@@ -332,3 +332,64 @@ def test_four_waves_per_tile_blend_matches_one_wave_per_tile():
     st4 = r.map_image_state()
     assert torch.equal(one, four)
     assert torch.equal(st1["nContrib"], st4["nContrib"]) and torch.equal(st1["finalT"], st4["finalT"])
+
+
+def test_footprint_test_never_drops_a_record_that_lights_a_pixel():
+    """The blend drops a record at staging when it has proven that none of the tile's pixels can pass alpha >= 1/255
+    (blend_core.hpp). Brute force over random (record, tile) pairs — thin, rotated, huge, faint, opaque, far-away and
+    degenerate conics; centres inside, near and far from the tile; partial tiles at the image border: wherever the
+    library says "misses", the reference's per-pixel arithmetic (float32, GSCuda.cu:626-646) must agree for all 256
+    pixels; and the test must not be vacuous (it drops most records that indeed miss)."""
+    import torch
+    from gsrast_amd import _capi
+    L = _capi.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 400_000
+    W, H = 1000, 700                                        # 63 x 44 tiles, partial ones on the right / bottom
+    tx = torch.randint(0, 63, (n,), generator=g); ty = torch.randint(0, 44, (n,), generator=g)
+    # covariance = R diag(s1^2, s2^2) R^T + 0.3 I, conic = its inverse (what preprocess produces), sizes over 4 decades
+    s1 = torch.exp(torch.rand(n, generator=g) * 9.0 - 2.0); ratio = torch.exp(-torch.rand(n, generator=g) * 6.0)
+    s2 = s1 * ratio
+    th = torch.rand(n, generator=g) * 3.14159265
+    c, s = torch.cos(th), torch.sin(th)
+    a = c * c * s1 * s1 + s * s * s2 * s2 + 0.3; b = c * s * (s1 * s1 - s2 * s2); d = s * s * s1 * s1 + c * c * s2 * s2 + 0.3
+    det = a * d - b * b
+    conic = torch.stack([d / det, -b / det, a / det], 1).to(torch.float32)
+    op = torch.sigmoid(torch.randn(n, generator=g) * 3.0)
+    op[:2000] = torch.tensor([0.0, 1.0, 1e-3, 0.999]).repeat(500)            # corner opacities
+    op[2000:2100] = 5.0                                                    # opacity above 1 (not a sigmoid's output, but legal input)
+    # centres: within a few footprint radii of the tile, on either side of "just reaches it"
+    reach = 3.5 * torch.sqrt(torch.maximum(a, d))
+    cx = (tx * 16 + 8).float() + (torch.rand(n, generator=g) * 2 - 1) * (0.6 * reach + 16.0)
+    cy = (ty * 16 + 8).float() + (torch.rand(n, generator=g) * 2 - 1) * (0.6 * reach + 16.0)
+    xy = torch.stack([cx, cy], 1).to(torch.float32)
+    co = torch.cat([conic, op[:, None].float()], 1).contiguous()
+    # degenerate records must be KEPT whatever they are
+    co[2100:2110, 0] = -1.0; co[2110:2120, 1] = 1e9; co[2120:2130, 3] = float("nan"); xy[2130:2140, 0] = float("inf")
+    tile = torch.stack([tx, ty], 1).to(torch.int32)
+    xy_d, co_d, tile_d = xy.to(dev), co.to(dev), tile.to(dev)
+    misses = torch.zeros(n, dtype=torch.uint8, device=dev)
+    rc = L.gsr_footprint_misses_tile(n, xy_d.data_ptr(), co_d.data_ptr(), tile_d.data_ptr(), W, H, misses.data_ptr(), None)
+    _capi.check(rc, "gsr_footprint_misses_tile")
+    torch.cuda.synchronize()
+    # brute force, float32, the reference's operation order; pixels outside the image do not exist
+    px = (tile_d[:, 0:1] * 16 + torch.arange(16, device=dev)[None, :]).float()          # [n, 16]
+    py = (tile_d[:, 1:2] * 16 + torch.arange(16, device=dev)[None, :]).float()
+    lit = torch.zeros(n, dtype=torch.bool, device=dev)
+    A, B, Cc, O = co_d[:, 0:1], co_d[:, 1:2], co_d[:, 2:3], co_d[:, 3:4]
+    for r in range(16):
+        dx = xy_d[:, 0:1] - px                                                            # [n, 16]
+        dy = (xy_d[:, 1:2] - py[:, r:r + 1]).expand(-1, 16)
+        power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+        alpha = torch.minimum(torch.full_like(power, 0.99), O * torch.exp(power))
+        alpha = torch.where(torch.isnan(O * torch.exp(power)), torch.full_like(power, 0.99), alpha)   # fminf(0.99, NaN) = 0.99
+        ok = ~(power > 0) & ~(alpha < 1.0 / 255.0) & (px < W) & (py[:, r:r + 1] < H)
+        lit |= ok.any(1)
+    m = misses.bool()
+    wrong = m & lit
+    assert int(wrong.sum()) == 0, (int(wrong.sum()), xy_d[wrong][:3], co_d[wrong][:3], tile_d[wrong][:3])
+    assert not bool(m[2100:2140].any())                                    # degenerate records are kept
+    dark = ~lit
+    assert int(dark.sum()) > 50_000 and int(lit.sum()) > 50_000, (int(dark.sum()), int(lit.sum()))
+    assert int((m & dark).sum()) >= 0.9 * int(dark.sum()), (int((m & dark).sum()), int(dark.sum()))   # and it is sharp
