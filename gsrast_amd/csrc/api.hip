@@ -332,8 +332,10 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));                 // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
+    // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
-                                   gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2)));
+                                   gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2),
+                                   gs.vis_partial, gs.sort_info + 1));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
@@ -346,7 +348,7 @@ int gsr_forward(gsr_forward_args* a) {
     // Only Gaussians with at least one tile in this call take part from here on (V of N: 52 % on the
     // bench frame, a few per cent per rank when the frame is sharded): their (depth key, index) pairs
     // are compacted in index order — the same kernels count the digits of the four sort passes.
-    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream));
+    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would

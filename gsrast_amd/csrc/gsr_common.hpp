@@ -51,8 +51,10 @@ int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, in
 int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
                             uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
 
+// nonzero (u32 per 4096 elements) / nonzero_total: optional — exclusive prefix of the per-tile counts of non-zero
+// elements and their total (the depth order's compaction offsets, radix_sort.hip)
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
-                          unsigned long long* total64 = nullptr);
+                          unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr);
 size_t scan_temp_bytes(size_t n);
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,
@@ -68,8 +70,10 @@ struct SweepScratch;
 // Depth order (radix_sort.hip). sc4: one scratch area per pass, already zeroed by the caller (look-back words,
 // tickets, error word, histograms); the error word and the digit histograms live in sc4[0].
 size_t depth_compact_scratch_bytes(size_t n);
+// offsets_ready: `partial` / info[1] already hold the compaction offsets per 4096 keys and the visible count (the scan of
+// tilesTouched produced them on the way: a key is the sentinel exactly where tilesTouched is 0)
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
-                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream);
+                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready = false);
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
                     const uint32_t* n_dev = nullptr);

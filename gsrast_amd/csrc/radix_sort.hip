@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __
 
 // ---- visible keys first: stable compaction of the keys that are not the 0xFFFFFFFF sentinel --------
 constexpr int kCompactThreads = 256, kCompactRows = 16, kCompactChunk = kCompactThreads * kCompactRows;
+static_assert(kCompactChunk == 4096, "the scan of tilesTouched (scan.hip) counts the visible Gaussians per 4096 elements for this compaction");
 
 __global__ __launch_bounds__(kCompactThreads) void visible_count_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                         uint32_t* __restrict__ partial) {
@@ -564,13 +565,15 @@ size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChu
 // the four sort passes, and (top_digits) the number of distinct top-byte digits: with at most one the
 // fourth pass would move nothing. info[0] = top_digits, info[1] = visible count (device words).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
-                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream) {
+                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready) {
     if (n == 0) return GSR_OK;
     const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
-    hipLaunchKernelGGL(visible_count_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial);
-    GSR_LAUNCH_CHECK("visible_count_kernel");
-    hipLaunchKernelGGL(visible_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, chunks, info + 1);
-    GSR_LAUNCH_CHECK("visible_scan_kernel");
+    if (!offsets_ready) {
+        hipLaunchKernelGGL(visible_count_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial);
+        GSR_LAUNCH_CHECK("visible_count_kernel");
+        hipLaunchKernelGGL(visible_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, chunks, info + 1);
+        GSR_LAUNCH_CHECK("visible_scan_kernel");
+    }
     hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, out_k, out_v,
                        sc4[0].hist);
     GSR_LAUNCH_CHECK("visible_compact_kernel");

@@ -17,6 +17,7 @@ namespace {
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 16;                               // per lane: 4 x uint4
 constexpr int kScanTile = kScanThreads * kScanItems;         // 4096
+static_assert(kScanTile == 4096, "the depth order's compaction (radix_sort.hip) takes its per-chunk offsets from this scan's tiles");
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 #pragma unroll
@@ -64,34 +65,39 @@ __device__ __forceinline__ void load_items(const uint32_t* in, size_t n, size_t 
     }
 }
 
+// nonzero (may be null): also the number of non-zero elements of the tile — gsr_forward's depth order compacts the
+// Gaussians with tilesTouched != 0 in chunks of the same 4096 elements, and this kernel has them in registers anyway.
 __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
-                                                                    uint32_t* __restrict__ partial) {
-    __shared__ uint32_t wave_sums[kScanThreads / kWave];
+                                                                    uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero) {
+    __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave];
     uint32_t v[kScanItems];
     load_items(in, n, blockIdx.x, v);
-    uint32_t s = 0;
+    uint32_t s = 0, z = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) s += v[k];
+    for (int k = 0; k < kScanItems; ++k) { s += v[k]; z += v[k] != 0u ? 1u : 0u; }
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0) wave_sums[threadIdx.x / kWave] = s;
+    for (int off = kWave / 2; off > 0; off >>= 1) { s += __shfl_down(s, off, kWave); z += __shfl_down(z, off, kWave); }
+    if ((threadIdx.x & (kWave - 1)) == 0) { wave_sums[threadIdx.x / kWave] = s; wave_nz[threadIdx.x / kWave] = z; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
+        uint32_t t = 0, tz = 0;
 #pragma unroll
-        for (int w = 0; w < kScanThreads / kWave; ++w) t += wave_sums[w];
+        for (int w = 0; w < kScanThreads / kWave; ++w) { t += wave_sums[w]; tz += wave_nz[w]; }
         partial[blockIdx.x] = t;
+        if (nonzero) nonzero[blockIdx.x] = tz;
     }
 }
 
 // total64 (may be null): the sum of all elements WITHOUT the u32 wrap-around, so that the caller can tell
 // whether the scan's last element is the true total (a tile's own sum cannot wrap: 4096 elements of at most
 // 2^20 tiles each).
+// nonzero / nonzero_total (may be null): the per-tile non-zero counts become their exclusive prefix, the total goes out.
 __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict__ partial, size_t tiles,
-                                                            unsigned long long* __restrict__ total64) {
+                                                            unsigned long long* __restrict__ total64,
+                                                            uint32_t* __restrict__ nonzero, uint32_t* __restrict__ nonzero_total) {
     __shared__ uint32_t wave_sums[1024 / kWave];
     __shared__ unsigned long long wide_sums[1024 / kWave];
-    uint32_t carry = 0;
+    uint32_t carry = 0, carry_nz = 0;
     unsigned long long wide = 0;
     for (size_t base = 0; base < tiles; base += 1024) {
         const size_t i = base + threadIdx.x;
@@ -101,7 +107,15 @@ __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict
         const uint32_t excl = block_exclusive_scan<1024>(v, wave_sums, total);
         if (i < tiles) partial[i] = carry + excl;
         carry += total;
+        if (nonzero) {
+            const uint32_t z = (i < tiles) ? nonzero[i] : 0u;
+            uint32_t total_nz;
+            const uint32_t excl_nz = block_exclusive_scan<1024>(z, wave_sums, total_nz);
+            if (i < tiles) nonzero[i] = carry_nz + excl_nz;
+            carry_nz += total_nz;
+        }
     }
+    if (nonzero && threadIdx.x == 0) *nonzero_total = carry_nz;
     if (total64) {
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) wide += __shfl_down(wide, off, kWave);
@@ -157,13 +171,13 @@ size_t scan_temp_bytes(size_t n) {
 }
 
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
-                          unsigned long long* total64) {
+                          unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total) {
     if (n == 0) return GSR_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
-    hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial);
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero);
     GSR_LAUNCH_CHECK("tile_reduce_kernel");
-    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64);
+    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total);
     GSR_LAUNCH_CHECK("partial_scan_kernel");
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, partial);
     GSR_LAUNCH_CHECK("tile_scan_kernel");
