@@ -216,7 +216,7 @@ class Runner:
         rows = exch.my_tile_rows() if exch else None
         frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not self.distributed, **kw)
         if self.dl_dout is not None:
-            rast.backward(self.dl_dout, profile=profile)
+            rast.backward(self.dl_dout, profile=profile, semantics=kw.get("semantics", "gscuda"), sh_degree=kw.get("sh_degree", 3))
             if profile:
                 self.bw_ms[0] += rast.last_backward_ms[0]
                 self.bw_ms[1] += rast.last_backward_ms[1]

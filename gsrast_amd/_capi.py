@@ -94,6 +94,7 @@ class BackwardArgs(C.Structure):
         ("dL_dmeans3D", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
         ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
         ("stage_ms", C.c_float * 2),
+        ("cam_pos", C.c_void_p), ("shs", C.c_void_p), ("clamped", C.c_void_p), ("sh_dims", C.c_int32),
     ]
 
 

@@ -193,7 +193,52 @@ struct PreprocessBackwardParams {
     float4* dL_dmeans3D;    // vec4[N] (x, y, z, 0): the layout of means3D
     float4* dL_dscales;     // vec4[N] (x, y, z, 0)
     float4* dL_drotations;  // vec4[N], w.r.t. the quaternion as given (not normalised)
+    // the upstream (`inria`) semantics profile, csrc/preprocess_inria.hip: two focal lengths, w epsilon 1e-7, raw
+    // quaternion, colour = max(0, 0.5 + SH(view direction)) on [16][3] coefficients
+    int inria, sh_deg;
+    float focal_x, focal_y, w_eps;
+    const float* shs;
+    const float* cam_pos;
+    const uint8_t* clamped;   // GeometryState::clamped of the forward call: channel c of Gaussian i was clamped at zero
 };
+
+__constant__ float kShC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                               0.5462742152960396f};
+__constant__ float kShC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                               -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+// The 16 real SH basis values at the unit direction (x, y, z) and their gradients (oracle/backward_np.py: sh_basis).
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float (&B)[16], float (&G)[16][3]) {
+    constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { B[k] = 0.0f; G[k][0] = G[k][1] = G[k][2] = 0.0f; }
+    B[0] = C0;
+    if (deg > 0) {
+        B[1] = -C1 * y; B[2] = C1 * z; B[3] = -C1 * x;
+        G[1][1] = -C1; G[2][2] = C1; G[3][0] = -C1;
+    }
+    if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        B[4] = kShC2[0] * xy; B[5] = kShC2[1] * yz; B[6] = kShC2[2] * (2.0f * zz - xx - yy); B[7] = kShC2[3] * xz; B[8] = kShC2[4] * (xx - yy);
+        G[4][0] = kShC2[0] * y; G[4][1] = kShC2[0] * x;
+        G[5][1] = kShC2[1] * z; G[5][2] = kShC2[1] * y;
+        G[6][0] = -2.0f * kShC2[2] * x; G[6][1] = -2.0f * kShC2[2] * y; G[6][2] = 4.0f * kShC2[2] * z;
+        G[7][0] = kShC2[3] * z; G[7][2] = kShC2[3] * x;
+        G[8][0] = 2.0f * kShC2[4] * x; G[8][1] = -2.0f * kShC2[4] * y;
+        if (deg > 2) {
+            B[9] = kShC3[0] * y * (3.0f * xx - yy); B[10] = kShC3[1] * xy * z; B[11] = kShC3[2] * y * (4.0f * zz - xx - yy);
+            B[12] = kShC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); B[13] = kShC3[4] * x * (4.0f * zz - xx - yy);
+            B[14] = kShC3[5] * z * (xx - yy); B[15] = kShC3[6] * x * (xx - 3.0f * yy);
+            G[9][0] = kShC3[0] * 6.0f * xy; G[9][1] = kShC3[0] * (3.0f * xx - 3.0f * yy);
+            G[10][0] = kShC3[1] * yz; G[10][1] = kShC3[1] * xz; G[10][2] = kShC3[1] * xy;
+            G[11][0] = kShC3[2] * -2.0f * xy; G[11][1] = kShC3[2] * (4.0f * zz - xx - 3.0f * yy); G[11][2] = kShC3[2] * 8.0f * yz;
+            G[12][0] = kShC3[3] * -6.0f * xz; G[12][1] = kShC3[3] * -6.0f * yz; G[12][2] = kShC3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+            G[13][0] = kShC3[4] * (4.0f * zz - 3.0f * xx - yy); G[13][1] = kShC3[4] * -2.0f * xy; G[13][2] = kShC3[4] * 8.0f * xz;
+            G[14][0] = kShC3[5] * 2.0f * xz; G[14][1] = kShC3[5] * -2.0f * yz; G[14][2] = kShC3[5] * (xx - yy);
+            G[15][0] = kShC3[6] * (3.0f * xx - 3.0f * yy); G[15][1] = kShC3[6] * -6.0f * xy;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBackwardParams p) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -214,12 +259,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         tx = cx * tz;
         ty = cy * tz;
         // P = J W (2 x 3): cov2D = P Sigma P^T
-        const float j00 = p.focal / tz, j02 = -p.focal * tx / (tz * tz), j12 = -p.focal * ty / (tz * tz);
+        const float fx = p.inria ? p.focal_x : p.focal, fy = p.inria ? p.focal_y : p.focal;
+        const float j00 = fx / tz, j11 = fy / tz, j02 = -fx * tx / (tz * tz), j12 = -fy * ty / (tz * tz);
         float P[2][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             P[0][c] = j00 * v[4 * c + 0] + j02 * v[4 * c + 2];
-            P[1][c] = j00 * v[4 * c + 1] + j12 * v[4 * c + 2];
+            P[1][c] = j11 * v[4 * c + 1] + j12 * v[4 * c + 2];
         }
         const float* c3 = p.cov3D + 6 * (size_t)idx;
         const float s[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
@@ -263,7 +309,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) mw[r][c] = ws[r][0] * v[0 + c] + ws[r][1] * v[4 + c] + ws[r][2] * v[8 + c];
-                const float J[2][3] = {{j00, 0.0f, j02}, {0.0f, j00, j12}};
+                const float J[2][3] = {{j00, 0.0f, j02}, {0.0f, j11, j12}};
                 float jm[2][3], gJ[2][3];
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
@@ -274,9 +320,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
                     gJ[0][c] = 2.0f * (m00 * jm[0][c] + m01 * jm[1][c]);
                     gJ[1][c] = 2.0f * (m01 * jm[0][c] + m11 * jm[1][c]);
                 }
-                const float f_tz2 = p.focal / (tz * tz);
-                const float g_tx = -gJ[0][2] * f_tz2, g_ty = -gJ[1][2] * f_tz2;
-                const float g_tz = -(gJ[0][0] + gJ[1][1]) * f_tz2 + (gJ[0][2] * tx + gJ[1][2] * ty) * (2.0f * p.focal / (tz * tz * tz));
+                const float itz2 = 1.0f / (tz * tz);
+                const float g_tx = -gJ[0][2] * fx * itz2, g_ty = -gJ[1][2] * fy * itz2;
+                const float g_tz = -(gJ[0][0] * fx + gJ[1][1] * fy) * itz2 + (gJ[0][2] * fx * tx + gJ[1][2] * fy * ty) * (2.0f / (tz * tz * tz));
                 const bool clx = rx != cx, cly = ry != cy;          // clamped: t.x (t.y) no longer moves the entry, t.z does
                 const float gt0 = clx ? 0.0f : g_tx, gt1 = cly ? 0.0f : g_ty;
                 const float gt2 = g_tz + (clx ? g_tx * cx : 0.0f) + (cly ? g_ty * cy : 0.0f);
@@ -287,9 +333,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         if (p.dL_dmeans3D) {
             // pixel-space centre: pix = ((proj mean).x / ((proj mean).w + 0.001) * 0.5 + 0.5) * W (GSCuda.cu:302-305, :342)
             const float* pm = p.proj;
-            const float hx = (pm[0] * mean.x + pm[4] * mean.y) + (pm[8] * mean.z + pm[12] * mean.w);
-            const float hy = (pm[1] * mean.x + pm[5] * mean.y) + (pm[9] * mean.z + pm[13] * mean.w);
-            const float wp = 0.001f + ((pm[3] * mean.x + pm[7] * mean.y) + (pm[11] * mean.z + pm[15] * mean.w));
+            const float mw_ = p.inria ? 1.0f : mean.w;          // (the upstream projection takes the point as (x, y, z, 1))
+            const float hx = (pm[0] * mean.x + pm[4] * mean.y) + (pm[8] * mean.z + pm[12] * mw_);
+            const float hy = (pm[1] * mean.x + pm[5] * mean.y) + (pm[9] * mean.z + pm[13] * mw_);
+            const float wp = (p.inria ? p.w_eps : 0.001f) + ((pm[3] * mean.x + pm[7] * mean.y) + (pm[11] * mean.z + pm[15] * mw_));
             const float2 g2 = p.dL_dmean2D[idx];
             const float iw = 1.0f / wp, iw2 = iw * iw;
 #pragma unroll
@@ -300,11 +347,71 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             }
         }
     }
+    if (p.inria && p.dL_dshs) {
+        // colour_c = max(0, 0.5 + sum_k B_k(dir) sh[k][c]), dir = (mean - cam) / |mean - cam|: dL/dsh[k][c] = B_k g_c, and
+        // the direction moves with the mean; a channel clamped at zero passes nothing (oracle: inria_color_backward)
+        float gsh[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) gsh[k] = 0.0f;
+        if (visible) {
+            const float4 mean = p.means3D[idx];
+            float dx = mean.x - p.cam_pos[0], dy = mean.y - p.cam_pos[1], dz = mean.z - p.cam_pos[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz), il = 1.0f / len;
+            dx *= il; dy *= il; dz *= il;
+            float B[16], G[16][3];
+            sh_basis_grad(p.sh_deg, dx, dy, dz, B, G);
+            const float* gc = p.dL_dcolors + 3 * (size_t)idx;
+            float g[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = p.clamped[3 * (size_t)idx + c] ? 0.0f : gc[c];
+            const float* sh = p.shs + 48 * (size_t)idx;
+            float gd[3] = {0.0f, 0.0f, 0.0f};
+            const int terms = (p.sh_deg + 1) * (p.sh_deg + 1);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < terms) {
+                    const float w = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
+                    gd[0] += G[k][0] * w; gd[1] += G[k][1] * w; gd[2] += G[k][2] * w;
+                    gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2];
+                }
+            }
+            const float dot = dx * gd[0] + dy * gd[1] + dz * gd[2];
+            gmean[0] += (gd[0] - dx * dot) * il; gmean[1] += (gd[1] - dy * dot) * il; gmean[2] += (gd[2] - dz * dot) * il;
+        }
+        float4* o = reinterpret_cast<float4*>(p.dL_dshs + 48 * (size_t)idx);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) o[q] = make_float4(gsh[4 * q], gsh[4 * q + 1], gsh[4 * q + 2], gsh[4 * q + 3]);
+    }
     if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4(gmean[0], gmean[1], gmean[2], 0.0f);
     if (p.dL_dscales) {
         // Sigma = M M^T, M = R diag(mod s): gM = 2 gSigma M (off-diagonal stored gradients split over both entries)
         float gsc[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (visible) {
+        if (visible && p.inria) {
+            // Sigma = M M^T, M = R(q) diag(mod s) with the RAW quaternion q = (r, x, y, z) (oracle: inria_cov3d_backward)
+            const float4 sc = p.scales[idx];
+            const float4 rot = p.rotations[idx];
+            const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+            const float R[3][3] = {{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
+                                   {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
+                                   {2.0f * (x * z - r * y), 2.0f * (y * z + r * x), 1.0f - 2.0f * (x * x + y * y)}};
+            const float sv[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
+            const float gS[3][3] = {{out[0], 0.5f * out[1], 0.5f * out[2]}, {0.5f * out[1], out[3], 0.5f * out[4]},
+                                    {0.5f * out[2], 0.5f * out[4], out[5]}};
+            float gR[3][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float gm[3];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) gm[rr] = 2.0f * (gS[rr][0] * R[0][c] + gS[rr][1] * R[1][c] + gS[rr][2] * R[2][c]) * sv[c];
+                gsc[c] = p.scale_modifier * (R[0][c] * gm[0] + R[1][c] * gm[1] + R[2][c] * gm[2]);
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) gR[rr][c] = gm[rr] * sv[c];
+            }
+            gq[0] = 2.0f * (z * (gR[1][0] - gR[0][1]) + y * (gR[0][2] - gR[2][0]) + x * (gR[2][1] - gR[1][2]));
+            gq[1] = 2.0f * (y * (gR[0][1] + gR[1][0]) + z * (gR[0][2] + gR[2][0]) + r * (gR[2][1] - gR[1][2])) - 4.0f * x * (gR[1][1] + gR[2][2]);
+            gq[2] = 2.0f * (x * (gR[0][1] + gR[1][0]) + r * (gR[0][2] - gR[2][0]) + z * (gR[1][2] + gR[2][1])) - 4.0f * y * (gR[0][0] + gR[2][2]);
+            gq[3] = 2.0f * (r * (gR[1][0] - gR[0][1]) + x * (gR[0][2] + gR[2][0]) + y * (gR[1][2] + gR[2][1])) - 4.0f * z * (gR[0][0] + gR[1][1]);
+        } else if (visible) {
             const float4 sc = p.scales[idx];
             const float4 rot = p.rotations[idx];
             const float nrm = sqrtf((rot.x * rot.x + rot.y * rot.y) + (rot.z * rot.z + rot.w * rot.w));
@@ -344,7 +451,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     dst[0] = make_float2(out[0], out[1]);
     dst[1] = make_float2(out[2], out[3]);
     dst[2] = make_float2(out[4], out[5]);
-    if (p.dL_dshs) {
+    if (p.dL_dshs && !p.inria) {
         const float* gc = p.dL_dcolors + 3 * (size_t)idx;
         float* o = p.dL_dshs + 48 * (size_t)idx;
         o[0] = visible ? 0.4f * gc[0] : 0.0f;           // colour = 0.5 + 0.4 DC (GSCuda.cu:362-366)
@@ -372,7 +479,9 @@ static int backward_impl(gsr_backward_args* a) {
     if ((a->dL_dmeans3D || a->dL_dscales || a->dL_drotations) && !a->dL_dcov3D) return GSR_ERR_INVALID_ARG;
     if (a->dL_dmeans3D && !a->proj_matrix) return GSR_ERR_INVALID_ARG;
     if ((a->dL_dscales || a->dL_drotations) && (!a->scales || !a->rotations || !a->dL_dscales)) return GSR_ERR_INVALID_ARG;
-    if (a->flags & GSR_FLAG_SEMANTICS_INRIA) return GSR_ERR_INVALID_ARG;      // gscuda semantics only
+    const bool inria = (a->flags & GSR_FLAG_SEMANTICS_INRIA) != 0;
+    // the upstream profile's chain needs what its colour was computed from
+    if (inria && a->dL_dshs && (!a->shs || !a->cam_pos || !a->clamped || !a->means3D)) return GSR_ERR_INVALID_ARG;
     if (forward_skipped_sorted_lists(a->point_list)) return GSR_ERR_INVALID_ARG;   // the forward call left the sorted lists unwritten
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
@@ -433,6 +542,12 @@ static int backward_impl(gsr_backward_args* a) {
         q.dL_dmeans3D = reinterpret_cast<float4*>(a->dL_dmeans3D);
         q.dL_dscales = reinterpret_cast<float4*>(a->dL_dscales);
         q.dL_drotations = reinterpret_cast<float4*>(a->dL_drotations);
+        q.inria = inria ? 1 : 0;
+        q.sh_deg = a->sh_dims < 0 ? 0 : (a->sh_dims > 3 ? 3 : a->sh_dims);
+        q.focal_x = (float)a->width / (2.0f * a->tan_fovx);
+        q.focal_y = (float)a->height / (2.0f * a->tan_fovy);
+        q.w_eps = 0.0000001f;
+        q.shs = a->shs; q.cam_pos = a->cam_pos; q.clamped = a->clamped;
         hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
         GSR_LAUNCH_CHECK("preprocess_backward_kernel");
     }

@@ -208,11 +208,14 @@ class SplatRasterizer:
 
     # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
     def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
-                 tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0) -> dict:
-        """Gradients of sum(dL_dout * out_color) of the LAST draw() (gscuda semantics) through gsr_backward.
-        Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3] and, with
-        with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (DC triple only), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
+                 tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0, semantics: str = "gscuda",
+                 sh_degree: int = 3) -> dict:
+        """Gradients of sum(dL_dout * out_color) of the LAST draw() through gsr_backward; `semantics` / `sh_degree`
+        must be those of that draw(). Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3]
+        and, with with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (gscuda: the DC triple only; inria: every coefficient
+        up to sh_degree), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
         The tensors are owned by this object and overwritten by the next call."""
+        assert semantics in ("gscuda", "inria")
         n, dev = self.num_gaussians, self.device
         g = dL_dout.to(device=dev, dtype=torch.float32).contiguous()
         assert g.shape == (3, self.height, self.width)
@@ -236,7 +239,9 @@ class SplatRasterizer:
         out = cache
         a = _capi.BackwardArgs()
         a.struct_size = C.sizeof(_capi.BackwardArgs)
-        a.flags = _capi.GSR_FLAG_PROFILE if profile else 0
+        a.flags = (_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_SEMANTICS_INRIA if semantics == "inria" else 0)
+        if semantics == "inria":
+            a.cam_pos, a.shs, a.clamped, a.sh_dims = self._cam_pos.data_ptr(), self.shs.data_ptr(), gst.clamped, int(sh_degree)
         a.num_gaussians, a.width, a.height = n, self.width, self.height
         a.background = self.background.data_ptr()
         a.means2D, a.conic_opacity, a.colors, a.cov3D = gst.means2D, gst.conic_opacity, gst.rgb, gst.cov3D

@@ -224,7 +224,11 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
  *                              (both need dL_dcov3D; not available when the forward call took cov3D_precomp)
  * Hard tests of the forward (power > 0, alpha < 1/255, transmittance cut-off) select a branch; where
  * alpha is clamped to 0.99 its derivative w.r.t. the Gaussian's parameters is zero. The state pointers are
- * those of the forward call's chunks (gsr_*_from_chunk): it must have run on the same inputs, same size. */
+ * those of the forward call's chunks (gsr_*_from_chunk): it must have run on the same inputs, same size.
+ * With flags = GSR_FLAG_SEMANTICS_INRIA (the forward call's flag) the chain is the upstream profile's: two focal
+ * lengths, w epsilon 1e-7, the raw quaternion, and colour = max(0, 0.5 + SH(view direction)) — dL_dshs then receives
+ * all (sh_dims + 1)^2 coefficient triples of every Gaussian (zeros beyond them and for culled Gaussians; a channel
+ * that was clamped at zero passes nothing), and dL_dmeans3D the term through the view direction. */
 typedef struct gsr_backward_args {
     uint32_t struct_size;          /* = sizeof(gsr_backward_args) */
     uint32_t flags;                /* GSR_FLAG_PROFILE */
@@ -262,6 +266,11 @@ typedef struct gsr_backward_args {
     void* stream;
     int32_t tile_row_begin, tile_row_end;   /* as gsr_forward: the rows the forward call processed */
     float stage_ms[2];             /* with GSR_FLAG_PROFILE: render backward, covariance / colour chain */
+    /* ---- GSR_FLAG_SEMANTICS_INRIA: the forward call ran with the upstream semantics ---- */
+    const float* cam_pos;          /* inputs of the forward call (needed with dL_dshs) */
+    const float* shs;              /* device f32[48 N], [16][3] per Gaussian */
+    const uint8_t* clamped;        /* geometry chunk: bool[3 N], colour channel was clamped at zero */
+    int32_t sh_dims;               /* SH degree the forward call evaluated (0..3) */
 } gsr_backward_args;
 int gsr_backward(gsr_backward_args* args);
 

@@ -321,3 +321,165 @@ def conic_backward_mean(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic):
     gt = np.array([0.0 if clamped_x else g_tx, 0.0 if clamped_y else g_ty,
                    g_tz + (g_tx * cx if clamped_x else 0.0) + (g_ty * cy if clamped_y else 0.0)])
     return W.T @ gt
+
+
+# ---- the upstream (`inria`) semantics profile: per-Gaussian forward functions and their gradients ----------------
+# Forward restated in float64 from csrc/preprocess_inria.hip / oracle/inria_np.py (SURVEY.md divergence table D1-D9):
+# real SH up to degree 3 with + 0.5 and a clamp at zero, raw (not re-normalised) quaternion, separate focal lengths,
+# w epsilon 1e-7, pixel centre ((ndc + 1) S - 1) / 2. Parity unpinned (no upstream source in the tree); the analytic
+# gradients are checked against central finite differences of these same functions (tests/test_backward_oracle.py).
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435)
+
+
+def sh_basis(d, deg):
+    """The 16 basis values B_k at the unit direction d (zeros beyond `deg`) and their gradients dB_k/dd [16,3]."""
+    x, y, z = d
+    B = np.zeros(16)
+    G = np.zeros((16, 3))
+    B[0] = SH_C0
+    if deg > 0:
+        B[1], B[2], B[3] = -SH_C1 * y, SH_C1 * z, -SH_C1 * x
+        G[1, 1], G[2, 2], G[3, 0] = -SH_C1, SH_C1, -SH_C1
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        B[4:9] = (SH_C2[0] * xy, SH_C2[1] * yz, SH_C2[2] * (2 * zz - xx - yy), SH_C2[3] * xz, SH_C2[4] * (xx - yy))
+        G[4] = (SH_C2[0] * y, SH_C2[0] * x, 0.0)
+        G[5] = (0.0, SH_C2[1] * z, SH_C2[1] * y)
+        G[6] = (-2 * SH_C2[2] * x, -2 * SH_C2[2] * y, 4 * SH_C2[2] * z)
+        G[7] = (SH_C2[3] * z, 0.0, SH_C2[3] * x)
+        G[8] = (2 * SH_C2[4] * x, -2 * SH_C2[4] * y, 0.0)
+        if deg > 2:
+            B[9:16] = (SH_C3[0] * y * (3 * xx - yy), SH_C3[1] * xy * z, SH_C3[2] * y * (4 * zz - xx - yy),
+                       SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy), SH_C3[4] * x * (4 * zz - xx - yy), SH_C3[5] * z * (xx - yy),
+                       SH_C3[6] * x * (xx - 3 * yy))
+            G[9] = (SH_C3[0] * 6 * xy, SH_C3[0] * (3 * xx - 3 * yy), 0.0)
+            G[10] = (SH_C3[1] * yz, SH_C3[1] * xz, SH_C3[1] * xy)
+            G[11] = (SH_C3[2] * -2 * xy, SH_C3[2] * (4 * zz - xx - 3 * yy), SH_C3[2] * 8 * yz)
+            G[12] = (SH_C3[3] * -6 * xz, SH_C3[3] * -6 * yz, SH_C3[3] * (6 * zz - 3 * xx - 3 * yy))
+            G[13] = (SH_C3[4] * (4 * zz - 3 * xx - yy), SH_C3[4] * -2 * xy, SH_C3[4] * 8 * xz)
+            G[14] = (SH_C3[5] * 2 * xz, SH_C3[5] * -2 * yz, SH_C3[5] * (xx - yy))
+            G[15] = (SH_C3[6] * (3 * xx - 3 * yy), SH_C3[6] * -6 * xy, 0.0)
+    return B, G
+
+
+def inria_color(mean3, cam_pos, sh, deg):
+    """colour[3] = max(0, 0.5 + sum_k B_k(dir) sh[k]) with dir = (mean - cam) / |mean - cam|; sh: [16,3]."""
+    v = np.asarray(mean3, np.float64) - np.asarray(cam_pos, np.float64)
+    B, _ = sh_basis(v / np.linalg.norm(v), deg)
+    return np.maximum(B @ np.asarray(sh, np.float64).reshape(16, 3) + 0.5, 0.0)
+
+
+def inria_color_backward(mean3, cam_pos, sh, deg, g_col):
+    """(dL/dsh [16,3], dL/dmean3 [3]) from dL/dcolour[3]; a channel clamped at zero passes no gradient."""
+    sh = np.asarray(sh, np.float64).reshape(16, 3)
+    v = np.asarray(mean3, np.float64) - np.asarray(cam_pos, np.float64)
+    ln = np.linalg.norm(v)
+    d = v / ln
+    B, G = sh_basis(d, deg)
+    raw = B @ sh + 0.5
+    g = np.where(raw < 0.0, 0.0, np.asarray(g_col, np.float64))
+    g_sh = np.outer(B, g)
+    g_d = G.T @ (sh @ g)                       # sum_k dB_k/dd * (sh[k] . g)
+    return g_sh, (g_d - d * (d @ g_d)) / ln
+
+
+def inria_rotation(q):
+    """The matrix upstream builds from the RAW quaternion (real part first), math rows / columns."""
+    r, x, y, z = np.asarray(q, np.float64)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                     [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                     [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+
+
+def inria_cov3d(scale, rot, mod=1.0):
+    m = inria_rotation(rot) @ np.diag(mod * np.asarray(scale, np.float64)[:3])
+    s = m @ m.T
+    return np.array([s[0, 0], s[0, 1], s[0, 2], s[1, 1], s[1, 2], s[2, 2]])
+
+
+def inria_cov3d_backward(scale, rot, mod, g6):
+    """dL/dscale[3], dL/drot[4] (raw quaternion: no normalisation in the forward, none here)."""
+    r, x, y, z = np.asarray(rot, np.float64)
+    R = inria_rotation(rot)
+    s = mod * np.asarray(scale, np.float64)[:3]
+    M = R @ np.diag(s)
+    gS = np.array([[g6[0], 0.5 * g6[1], 0.5 * g6[2]], [0.5 * g6[1], g6[3], 0.5 * g6[4]], [0.5 * g6[2], 0.5 * g6[4], g6[5]]])
+    gM = 2.0 * gS @ M
+    g_scale = mod * (R * gM).sum(0)
+    gR = gM * s[None, :]
+    dR = {"r": np.array([[0, -2 * z, 2 * y], [2 * z, 0, -2 * x], [-2 * y, 2 * x, 0]]),
+          "x": np.array([[0, 2 * y, 2 * z], [2 * y, -4 * x, -2 * r], [2 * z, 2 * r, -4 * x]]),
+          "y": np.array([[-4 * y, 2 * x, 2 * r], [2 * x, 0, 2 * z], [-2 * r, 2 * z, -4 * y]]),
+          "z": np.array([[-4 * z, -2 * r, 2 * x], [2 * r, -4 * z, 2 * y], [2 * x, 2 * y, 0]])}
+    return g_scale, np.array([(gR * dR[k]).sum() for k in "rxyz"])
+
+
+def _inria_jw(mean3, view, fx, fy, tan_fovx, tan_fovy):
+    v = np.asarray(view, np.float64)
+    t = np.array([v[0] * mean3[0] + v[4] * mean3[1] + v[8] * mean3[2] + v[12],
+                  v[1] * mean3[0] + v[5] * mean3[1] + v[9] * mean3[2] + v[13],
+                  v[2] * mean3[0] + v[6] * mean3[1] + v[10] * mean3[2] + v[14]])
+    limx, limy = 1.3 * tan_fovx, 1.3 * tan_fovy
+    rx, ry = t[0] / t[2], t[1] / t[2]
+    cx, cy = min(limx, max(-limx, rx)), min(limy, max(-limy, ry))
+    tx, ty, tz = cx * t[2], cy * t[2], t[2]
+    J = np.array([[fx / tz, 0.0, -fx * tx / (tz * tz)], [0.0, fy / tz, -fy * ty / (tz * tz)]])
+    W = np.array([[v[0], v[4], v[8]], [v[1], v[5], v[9]], [v[2], v[6], v[10]]])
+    return J, W, (tx, ty, tz), (rx != cx, ry != cy, cx, cy)
+
+
+def inria_cov2d_conic(c3, mean3, view, fx, fy, tan_fovx, tan_fovy):
+    J, W, _, _ = _inria_jw(mean3, view, fx, fy, tan_fovx, tan_fovy)
+    P = J @ W
+    cov = P @ _sigma(c3) @ P.T
+    a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+    det = a * c - b * b
+    return np.array([c / det, -b / det, a / det])
+
+
+def inria_conic_backward(c3, mean3, view, fx, fy, tan_fovx, tan_fovy, dL_dconic):
+    """(dL/d(6 covariance numbers), dL/dmean3 through the Jacobian's dependence on the view-space position)."""
+    J, W, (tx, ty, tz), (clx, cly, cx, cy) = _inria_jw(mean3, view, fx, fy, tan_fovx, tan_fovy)
+    P = J @ W
+    Mw = W @ _sigma(c3) @ W.T
+    cov = J @ Mw @ J.T
+    a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
+    det = a * c - b * b
+    K = np.array([[c, -b], [-b, a]]) / det
+    gA, gB, gC = dL_dconic
+    gcov = -K @ np.array([[gA, 0.5 * gB], [0.5 * gB, gC]]) @ K
+    gS = P.T @ gcov @ P
+    g6 = np.array([gS[0, 0], 2.0 * gS[0, 1], 2.0 * gS[0, 2], gS[1, 1], 2.0 * gS[1, 2], gS[2, 2]])
+    gJ = 2.0 * gcov @ J @ Mw
+    g_tx = gJ[0, 2] * (-fx / (tz * tz))
+    g_ty = gJ[1, 2] * (-fy / (tz * tz))
+    g_tz = (-gJ[0, 0] * fx - gJ[1, 1] * fy) / (tz * tz) + (gJ[0, 2] * fx * tx + gJ[1, 2] * fy * ty) * (2.0 / tz ** 3)
+    gt = np.array([0.0 if clx else g_tx, 0.0 if cly else g_ty,
+                   g_tz + (g_tx * cx if clx else 0.0) + (g_ty * cy if cly else 0.0)])
+    return g6, W.T @ gt
+
+
+def inria_project_mean2d(mean3, proj, width, height):
+    p = np.asarray(proj, np.float64)
+    hx = p[0] * mean3[0] + p[4] * mean3[1] + p[8] * mean3[2] + p[12]
+    hy = p[1] * mean3[0] + p[5] * mean3[1] + p[9] * mean3[2] + p[13]
+    hw = p[3] * mean3[0] + p[7] * mean3[1] + p[11] * mean3[2] + p[15]
+    ow = 1.0 / (hw + 1e-7)
+    return np.array([((hx * ow + 1.0) * width - 1.0) * 0.5, ((hy * ow + 1.0) * height - 1.0) * 0.5])
+
+
+def inria_project_mean2d_backward(mean3, proj, width, height, g2):
+    p = np.asarray(proj, np.float64)
+    hx = p[0] * mean3[0] + p[4] * mean3[1] + p[8] * mean3[2] + p[12]
+    hy = p[1] * mean3[0] + p[5] * mean3[1] + p[9] * mean3[2] + p[13]
+    wp = 1e-7 + (p[3] * mean3[0] + p[7] * mean3[1] + p[11] * mean3[2] + p[15])
+    g = np.zeros(3)
+    for j in range(3):
+        dx = 0.5 * width * (p[4 * j + 0] / wp - hx * p[4 * j + 3] / (wp * wp))
+        dy = 0.5 * height * (p[4 * j + 1] / wp - hy * p[4 * j + 3] / (wp * wp))
+        g[j] = dx * g2[0] + dy * g2[1]
+    return g

@@ -78,3 +78,38 @@ def check_backward_chain(got, g, scene, cam, w, h, ids):
         mag = np.maximum(np.abs(e).max(1), 1e-3 * np.abs(e).max())
         assert (err <= tol * np.maximum(mag, 1e-30)).all(), (name, float((err / np.maximum(mag, 1e-30)).max()))
     return [float(np.abs(e).max()) if m else 0.0 for e in (exp_cov, exp_mean, exp_scale, exp_rot)]
+
+
+def check_backward_chain_inria(got, g, scene, cam, w, h, ids, deg, clamped):
+    """The upstream profile's per-Gaussian chain for the Gaussians `ids` against oracle/backward_np.py (inria_*), fed with
+    the GPU's own upstream gradients. clamped: bool[N,3] of the forward call. Returns the largest expected magnitudes of
+    (dL_dcov3D, dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs)."""
+    from oracle import backward_np as B
+    fx, fy = w / (2.0 * cam.tan_fovx), h / (2.0 * cam.tan_fovy)
+    m = len(ids)
+    exp_cov, exp_mean, exp_scale, exp_rot, exp_sh = np.zeros((m, 6)), np.zeros((m, 3)), np.zeros((m, 3)), np.zeros((m, 4)), np.zeros((m, 48))
+    for j, i in enumerate(ids):
+        c3 = g["cov3D"][i].astype(np.float64)
+        m3 = scene["means3D"][i, :3].astype(np.float64)
+        dconic = got["dL_dconic_opacity"][i, :3].astype(np.float64)
+        exp_cov[j], g_mean_j = B.inria_conic_backward(c3, m3, cam.view, fx, fy, cam.tan_fovx, cam.tan_fovy, dconic)
+        g_sh, g_mean_c = B.inria_color_backward(m3, cam.cam_pos, scene["shs"][i].reshape(16, 3), deg, got["dL_dcolors"][i].astype(np.float64))
+        # the oracle decides the clamp from its own float64 colour; the kernel uses the forward's flags: they must agree
+        raw_negative = B.inria_color(m3, cam.cam_pos, scene["shs"][i].reshape(16, 3), deg) == 0.0
+        assert (raw_negative == clamped[i]).all() or np.abs(g["rgb"][i]).min() < 1e-6
+        exp_sh[j] = g_sh.reshape(48)
+        exp_mean[j] = (B.inria_project_mean2d_backward(m3, cam.proj, w, h, got["dL_dmean2D"][i].astype(np.float64)) + g_mean_j + g_mean_c)
+        exp_scale[j], exp_rot[j] = B.inria_cov3d_backward(scene["scales"][i, :3], scene["rotations"][i], 1.0,
+                                                          got["dL_dcov3D"][i].astype(np.float64))
+    ids = np.asarray(ids)
+    for name, e, gotv, tol in (("dL_dcov3D", exp_cov, got["dL_dcov3D"][ids], 2e-3),
+                               ("dL_dmeans3D", exp_mean, got["dL_dmeans3D"][ids][:, :3], 3e-3),
+                               ("dL_dscales", exp_scale, got["dL_dscales"][ids][:, :3], 3e-3),
+                               ("dL_drotations", exp_rot, got["dL_drotations"][ids], 3e-3),
+                               ("dL_dshs", exp_sh, got["dL_dshs"][ids], 1e-4)):
+        if m == 0:
+            continue
+        err = np.abs(gotv - e).max(1)
+        mag = np.maximum(np.abs(e).max(1), 1e-3 * np.abs(e).max())
+        assert (err <= tol * np.maximum(mag, 1e-30)).all(), (name, float((err / np.maximum(mag, 1e-30)).max()))
+    return [float(np.abs(e).max()) if m else 0.0 for e in (exp_cov, exp_mean, exp_scale, exp_rot, exp_sh)]

@@ -130,3 +130,53 @@ def test_vectorised_tile_backward_matches_the_per_pixel_loops():
         assert (nc < 40).any() and (ft < 0.01).any()
         for k in g:
             assert np.abs(acc[k] - g[k]).max() <= 1e-9 * max(1.0, np.abs(g[k]).max()), k
+
+
+def test_upstream_profile_chain_matches_finite_differences():
+    """The per-Gaussian functions of the `inria` profile (SH colour with its view direction and clamp, raw-quaternion
+    covariance, two focal lengths, its pixel-centre formula) against central differences."""
+    rng = np.random.default_rng(7)
+    view = np.array([0.96, 0.1, -0.26, 0, -0.05, 0.98, 0.19, 0, 0.27, -0.17, 0.95, 0, 0.3, -0.2, 4.0, 1.0])
+    proj = np.array([1.7, 0.1, 0.3, 0.28, -0.1, 2.4, 0.2, -0.17, 0.3, -0.2, 1.0, 0.95, 0.4, -0.3, 3.8, 4.0])
+    fx, fy, tx_, ty_ = 900.0, 1150.0, 0.9, 0.5
+    for trial in range(6):
+        mean = rng.uniform(-1.5, 1.5, 3)
+        if trial == 4:
+            mean = np.array([6.0, 0.3, 1.0])                 # far off axis: the +-1.3 tan(fov) clamp engages
+        cam = rng.uniform(-3, 3, 3)
+        sh = rng.normal(0, 0.5, (16, 3))
+        if trial == 2:
+            sh[0] = (-6.0, 0.2, 0.1)                         # red channel clamped at zero
+        g_col = rng.normal(size=3)
+        for deg in (0, 1, 2, 3):
+            col = B.inria_color(mean, cam, sh, deg)
+            g_sh, g_mean = B.inria_color_backward(mean, cam, sh, deg, g_col)
+            fd_sh = B.finite_difference(lambda s_: float(B.inria_color(mean, cam, s_, deg) @ g_col), sh, 1e-6)
+            fd_mean = B.finite_difference(lambda m_: float(B.inria_color(m_, cam, sh, deg) @ g_col), mean, 1e-6)
+            assert np.abs(g_sh - fd_sh).max() <= 1e-6 * max(1.0, np.abs(fd_sh).max())
+            assert np.abs(g_mean - fd_mean).max() <= 2e-6 * max(1.0, np.abs(fd_mean).max())
+            if trial == 2:
+                assert col[0] == 0.0 and (g_sh[:, 0] == 0).all()
+            assert (g_sh[(deg + 1) ** 2:] == 0).all()
+        scale = np.exp(rng.uniform(-3, -0.5, 3))
+        quat = rng.normal(size=4)                            # not a unit quaternion: the forward does not normalise
+        c3 = B.inria_cov3d(scale, quat, 1.3)
+        g6 = rng.normal(size=6)
+        g_scale, g_rot = B.inria_cov3d_backward(scale, quat, 1.3, g6)
+        fd_s = B.finite_difference(lambda s_: float(B.inria_cov3d(s_, quat, 1.3) @ g6), scale, 1e-7)
+        fd_q = B.finite_difference(lambda q_: float(B.inria_cov3d(scale, q_, 1.3) @ g6), quat, 1e-6)
+        assert np.abs(g_scale - fd_s).max() <= 1e-5 * max(1e-3, np.abs(fd_s).max())
+        assert np.abs(g_rot - fd_q).max() <= 1e-5 * max(1e-3, np.abs(fd_q).max())
+        gk = rng.normal(size=3)
+        g_c3, g_mean_j = B.inria_conic_backward(c3, mean, view, fx, fy, tx_, ty_, gk)
+        fd_c3 = B.finite_difference(lambda c_: float(B.inria_cov2d_conic(c_, mean, view, fx, fy, tx_, ty_) @ gk), c3, 1e-7)
+        fd_mj = B.finite_difference(lambda m_: float(B.inria_cov2d_conic(c3, m_, view, fx, fy, tx_, ty_) @ gk), mean, 1e-6)
+        assert np.abs(g_c3 - fd_c3).max() <= 2e-5 * max(1e-6, np.abs(fd_c3).max())
+        assert np.abs(g_mean_j - fd_mj).max() <= 2e-5 * max(1e-6, np.abs(fd_mj).max())
+        g2 = rng.normal(size=2)
+        g_m = B.inria_project_mean2d_backward(mean, proj, 1920, 1080, g2)
+        fd_m = B.finite_difference(lambda m_: float(B.inria_project_mean2d(m_, proj, 1920, 1080) @ g2), mean, 1e-6)
+        assert np.abs(g_m - fd_m).max() <= 1e-6 * max(1.0, np.abs(fd_m).max())
+    # and the two profiles agree where they coincide: a unit quaternion gives the same covariance
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    assert np.abs(B.inria_cov3d(scale, q, 1.0) - B.cov3d(scale, q, 1.0)).max() <= 1e-12

@@ -67,6 +67,59 @@ def test_backward_matches_float64_oracle(w, h, n, seed, bg):
     assert (sh[:, 3:] == 0).all()
 
 
+@pytest.mark.parametrize("w,h,n,seed,deg", [(96, 64, 600, 4, 3), (64, 48, 300, 6, 1), (80, 80, 500, 8, 0)])
+def test_backward_of_the_upstream_profile_matches_float64_oracle(w, h, n, seed, deg):
+    """GSR_FLAG_SEMANTICS_INRIA through gsr_backward: the render backward on the forward state of that profile
+    (transmittance cut-off 1e-4), then its own chain — SH colour with the view direction and the clamp, raw quaternion,
+    two focal lengths — against oracle/backward_np.py (inria_*, pinned by finite differences on the CPU)."""
+    import torch
+    from helpers import check_backward_chain_inria
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    from oracle import backward_np as B
+    scene = scenes.garden_like_scene(n, seed=seed)
+    scene["means3D"][:, :3] *= 0.25
+    rng = np.random.default_rng(seed)
+    scene["shs"] = rng.normal(0, 0.35, (n, 48)).astype(np.float32)                 # [N][16][3]
+    scene["rotations"] *= rng.uniform(0.7, 1.4, (n, 1)).astype(np.float32)         # not unit: the profile does not normalise
+    cam = camera.default_camera(w, h, near=0.05, far=50.0)
+    bg = (0.2, 0.5, 0.9)
+    r = SplatRasterizer(w, h, background=bg)
+    r.configure_from_scene(scene)
+    img = r.draw(cam, semantics="inria", sh_degree=deg).cpu().numpy()
+    assert r.last_num_rendered > 0
+    g, im, b = _forward_state(r)
+    st = r.map_geometry_state()
+    dL = rng.normal(size=(3, h, w)).astype(np.float32)
+    got = {k: v.cpu().numpy() for k, v in r.backward(torch.from_numpy(dL), semantics="inria", sh_degree=deg).items()}
+    ranges = im["ranges"].view(np.uint32).astype(np.int64)
+    plist = b["values"].view(np.uint32).astype(np.int64)
+    out64, ft64, nc64 = B.blend_forward(g["means2D"], g["conicOpacity"], g["rgb"], ranges, plist, w, h, bg, t_cutoff=1e-4)
+    assert np.abs(out64 - img).max() <= 1e-4
+    assert (nc64 != im["nContrib"].view(np.uint32)).sum() <= 2
+    exp = B.blend_backward(g["means2D"], g["conicOpacity"], g["rgb"], ranges, plist, nc64, ft64, w, h, bg, dL)
+    _close(got["dL_dmean2D"], exp["dL_dmean2D"], "dL_dmean2D")
+    _close(got["dL_dconic_opacity"][:, :3], exp["dL_dconic"], "dL_dconic")
+    _close(got["dL_dconic_opacity"][:, 3], exp["dL_dopacity"], "dL_dopacity")
+    _close(got["dL_dcolors"], exp["dL_dcolor"], "dL_dcolors")
+    # the chain
+    import ctypes as C
+    from gsrast_amd import _capi
+    gst = _capi.GeometryState()
+    r.lib.gsr_geometry_from_chunk(r.geom.base(), n, C.byref(gst))
+    clamped = r.geom.view(gst.clamped, 3 * n, torch.uint8).view(n, 3).cpu().numpy().astype(bool)
+    vis = np.nonzero(g["radii"] > 0)[0]
+    clamped[g["radii"] <= 0] = False
+    mags = check_backward_chain_inria(got, g, scene, cam, w, h, vis, deg, clamped)
+    assert all(m > 0 for m in mags)
+    culled = g["radii"] <= 0
+    for k in ("dL_dcov3D", "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dshs"):
+        assert (got[k][culled] == 0).all(), k
+    assert (got["dL_dshs"][:, 3 * (deg + 1) ** 2:] == 0).all()                     # nothing beyond the degree in use
+    if deg == 3:
+        assert clamped[vis].any()                                                   # the clamp is exercised
+
+
 def test_backward_of_a_single_gaussian_closed_form():
     """One isotropic Gaussian on the optical axis, dL_dout = 1 on one channel: the colour gradient is the sum of
     alpha over the pixels, the opacity gradient the sum of G * c (no transmittance in front, nothing behind)."""
