@@ -190,7 +190,7 @@ def cpu_baseline(scene, cam, every: int):
     return {
         "value": round(n / t["total_s"] / 1e6, 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
         "sample": (f"every {every}th splat of the workload (n={n}, R={st['num_rendered']}) at the same camera and "
-                   f"resolution; preprocess+sort single-thread, tile loop on {cores} std::threads; "
+                   f"resolution; preprocess and key duplication single-thread, stable sort and tile loop on {cores} std::threads; "
                    f"total {t['total_s']:.2f}s = preprocess {t['preprocess_s']:.2f} + bin/sort {t['bin_s']:.2f} + "
                    f"blend {t['blend_s']:.2f}"),
     }

@@ -97,10 +97,11 @@ def forward(scene: dict, cam, background=(0.0, 0.0, 0.0), use_rects: bool = True
     o["records_staged"] = 0
     t2 = t3 = t1
     if R > 0:   # GSCuda.cu:775-778: R == 0 returns before anything else is written
-        L.gsro_bin(ctypes.c_int(n), ctypes.c_int(W), ctypes.c_int(H), _p(o["radii"]), _p(o["means2D"]),
-                   _p(o["depths"]), _p(o["pointOffsets"]), _p(o["rects"]), ctypes.c_uint64(R),
-                   _p(o["keys_unsorted"]), _p(o["values_unsorted"]), _p(o["keys"]), _p(o["values"]),
-                   _p(o["ranges"]))
+        # (the stable sort runs on `threads` host threads: same result as the single-thread std::stable_sort)
+        L.gsro_bin_mt(ctypes.c_int(n), ctypes.c_int(W), ctypes.c_int(H), _p(o["radii"]), _p(o["means2D"]),
+                      _p(o["depths"]), _p(o["pointOffsets"]), _p(o["rects"]), ctypes.c_uint64(R),
+                      _p(o["keys_unsorted"]), _p(o["values_unsorted"]), _p(o["keys"]), _p(o["values"]),
+                      _p(o["ranges"]), ctypes.c_int(threads))
         t2 = time.perf_counter()
         o["records_staged"] = int(L.gsro_blend(
             ctypes.c_int(W), ctypes.c_int(H), _p(o["ranges"]), _p(o["values"]), _p(o["means2D"]), _p(o["rgb"]),

@@ -148,6 +148,42 @@ inline uint32_t f2bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; 
 
 }  // namespace
 
+// Stable sort of `order` by `less` on `threads` host threads: the chunks are sorted independently, then merged pairwise
+// (std::merge keeps the elements of the left range in front of equal ones of the right range: the result is the one
+// std::stable_sort gives, whatever the thread count). Used by the timed CPU baseline; threads <= 1 is std::stable_sort.
+template <typename Less>
+static void parallel_stable_sort(std::vector<uint64_t>& order, int threads, Less less) {
+    const size_t n = order.size();
+    if (threads <= 1 || n < (size_t)1 << 16) {
+        std::stable_sort(order.begin(), order.end(), less);
+        return;
+    }
+    size_t parts = 1;
+    while (parts * 2 <= (size_t)threads && parts < 1024) parts *= 2;
+    std::vector<size_t> cut(parts + 1);
+    for (size_t p = 0; p <= parts; ++p) cut[p] = n * p / parts;
+    {
+        std::vector<std::thread> pool;
+        for (size_t p = 0; p < parts; ++p)
+            pool.emplace_back([&, p] { std::stable_sort(order.begin() + cut[p], order.begin() + cut[p + 1], less); });
+        for (auto& t : pool) t.join();
+    }
+    std::vector<uint64_t> tmp(n);
+    std::vector<uint64_t>* src = &order;
+    std::vector<uint64_t>* dst = &tmp;
+    for (size_t width = 1; width < parts; width *= 2) {
+        std::vector<std::thread> pool;
+        for (size_t p = 0; p < parts; p += 2 * width)
+            pool.emplace_back([&, p] {
+                const size_t a = cut[p], m = cut[std::min(p + width, parts)], b = cut[std::min(p + 2 * width, parts)];
+                std::merge(src->begin() + a, src->begin() + m, src->begin() + m, src->begin() + b, dst->begin() + a, less);
+            });
+        for (auto& t : pool) t.join();
+        std::swap(src, dst);
+    }
+    if (src != &order) order.swap(tmp);
+}
+
 extern "C" {
 
 // GSCuda.cu:481-502 getHigherMsb
@@ -239,10 +275,23 @@ uint64_t gsro_preprocess(int n, const float* means3d /*vec4*/, const float* scal
 // GSCuda.cu:422-475 duplicateWithKeys, :794-797 stable radix sort on the low
 // (32 + getHigherMsb(tiles)) bits, :504-538 identifyTileRanges (with the R==1 quirk).
 // `ranges` holds 2 u32 per tile and must be zeroed by the caller (:800 memset).
+void gsro_bin_mt(int n, int width, int height, const int* radii, const float* means2d,
+                 const float* depths, const uint32_t* point_offsets, const int* rects,
+                 uint64_t num_rendered, uint64_t* keys_unsorted, uint32_t* values_unsorted,
+                 uint64_t* keys, uint32_t* values, uint32_t* ranges, int threads);
+
 void gsro_bin(int n, int width, int height, const int* radii, const float* means2d,
               const float* depths, const uint32_t* point_offsets, const int* rects,
               uint64_t num_rendered, uint64_t* keys_unsorted, uint32_t* values_unsorted,
               uint64_t* keys, uint32_t* values, uint32_t* ranges) {
+    gsro_bin_mt(n, width, height, radii, means2d, depths, point_offsets, rects, num_rendered, keys_unsorted, values_unsorted,
+                keys, values, ranges, 1);
+}
+
+void gsro_bin_mt(int n, int width, int height, const int* radii, const float* means2d,
+                 const float* depths, const uint32_t* point_offsets, const int* rects,
+                 uint64_t num_rendered, uint64_t* keys_unsorted, uint32_t* values_unsorted,
+                 uint64_t* keys, uint32_t* values, uint32_t* ranges, int threads) {
     const int grid_x = (width + kTile - 1) / kTile, grid_y = (height + kTile - 1) / kTile;
     for (int idx = 0; idx < n; ++idx) {
         if (radii[idx] <= 0) continue;
@@ -266,7 +315,7 @@ void gsro_bin(int n, int width, int height, const int* radii, const float* means
     const uint64_t mask = (bits >= 64) ? ~0ull : ((1ull << bits) - 1ull);
     std::vector<uint64_t> order(num_rendered);
     std::iota(order.begin(), order.end(), 0ull);
-    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+    parallel_stable_sort(order, threads, [&](uint64_t a, uint64_t b) {
         return (keys_unsorted[a] & mask) < (keys_unsorted[b] & mask);
     });
     for (uint64_t i = 0; i < num_rendered; ++i) {
