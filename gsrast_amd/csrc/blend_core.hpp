@@ -17,7 +17,7 @@ constexpr int kBatch = 256;
 // (GSCuda.cu:646). Such a record changes nothing but the numbering of the records behind it, so it is dropped
 // when the batch is staged (one lane per record), not walked by the compositing loop (one wave per record):
 //   power(d) = -0.5 (A dx^2 + C dy^2) - B dx dy is concave for a positive definite conic, so its maximum over
-//   the tile's pixel rectangle is 0 if the centre lies inside and otherwise sits on one of the four edges, where
+//   the tile's pixel rectangle is 0 if the centre lies inside and otherwise sits on an edge facing the centre, where
 //   it is a 1-D parabola with a closed-form clamped maximiser. A pixel can pass the alpha test only if
 //   opacity * exp(power) >= 1/255, i.e. power >= -ln(255 * opacity).
 // The bound is evaluated over the real rectangle (a superset of the integer pixel centres) with a margin for
@@ -46,12 +46,13 @@ __device__ __forceinline__ bool record_misses_tile(const float2 xy, const float4
     const bool pd = A > 0.0f && C > 0.0f && A * C - B * B > 0.0f && fabsf(xy.x) < 1e30f && fabsf(xy.y) < 1e30f;
     // d = centre - pixel (GSCuda.cu:626): d ranges over [centre - hi, centre - lo]
     const float dx_lo = xy.x - box.x_hi, dx_hi = xy.x - box.x_lo, dy_lo = xy.y - box.y_hi, dy_hi = xy.y - box.y_lo;
-    const bool inside = dx_lo <= 0.0f && dx_hi >= 0.0f && dy_lo <= 0.0f && dy_hi >= 0.0f;
-    const float inv_a = 1.0f / A, inv_c = 1.0f / C;
-    float best = edge_power_bound(A, B, C, inv_c, dx_lo, dy_lo, dy_hi);
-    best = fmaxf(best, edge_power_bound(A, B, C, inv_c, dx_hi, dy_lo, dy_hi));
-    best = fmaxf(best, edge_power_bound(C, B, A, inv_a, dy_lo, dx_lo, dx_hi));
-    best = fmaxf(best, edge_power_bound(C, B, A, inv_a, dy_hi, dx_lo, dx_hi));
+    // the point of the rectangle nearest to the centre (0 where the centre lies inside that range): the maximum over the
+    // rectangle sits on an edge through it that faces the centre - the vertical one, the horizontal one, or either
+    const float ex = clampf(0.0f, dx_lo, dx_hi), ey = clampf(0.0f, dy_lo, dy_hi);
+    const bool inside = ex == 0.0f && ey == 0.0f;
+    // v_rcp_f32 (1 ulp) only places the clamped maximiser, where the parabola is flat
+    const float inv_a = __builtin_amdgcn_rcpf(A), inv_c = __builtin_amdgcn_rcpf(C);
+    const float best = fmaxf(edge_power_bound(A, B, C, inv_c, ex, dy_lo, dy_hi), edge_power_bound(C, B, A, inv_a, ey, dx_lo, dx_hi));
     const float threshold = -__logf(255.0f * co.w);             // NaN for opacity <= 0 or NaN: the comparison below is then false
     return pd && !inside && (best + 2e-3f < threshold);
 }
