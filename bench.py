@@ -441,6 +441,14 @@ def main() -> int:
             b["blend_ms_per_million_staged_records"] = round(e["stage_ms"].get("blend", 0.0) / max(e["records_staged"], 1) * 1e6, 5)
             extras["blend_bound_pose_outside"] = b
             run.rast.opacities = saved
+            # (d) BASELINE config 5: forward + backward on the headline frame, with the sorted lists and without them
+            # (gsr_backward then walks the block lists the forward left)
+            run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
+            e = run.measure(cam, **short, **draw_kw)
+            extras["forward_backward"] = brief(e, n_splats, "BASELINE config 5: forward + backward (all gradients down to the inputs) on the headline frame")
+            e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
+            extras["forward_backward_no_sorted_lists"] = brief(e, n_splats, "the same with GSR_FLAG_NO_SORTED_LISTS: the backward reads the tile lists from the block lists")
+            run.dl_dout = None
         else:
             # BASELINE config 3: the same scene at 3840 x 2160, tile rows sharded over the ranks
             run4k = Runner(dev_scene, 3840, 2160, device, distributed, args)
@@ -533,6 +541,8 @@ def main() -> int:
 
 def brief(e, n_splats, what):
     """Compact record of an extra (untimed-for-the-headline) measurement."""
+    if sum(e.get("backward_ms") or [0.0]) > 0:
+        e["stage_ms"] = {**e["stage_ms"], "render_backward": e["backward_ms"][0], "chain_backward": e["backward_ms"][1]}
     return {"what": what, "ms_per_step": round(e["ms_per_step"], 4), "fps": round(1e3 / e["ms_per_step"], 2),
             "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
             "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],

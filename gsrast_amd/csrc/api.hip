@@ -10,6 +10,7 @@
 #include <map>
 
 #include "gsr_common.hpp"
+#include "blockbin.hpp"
 #include "radix_sort.hpp"
 
 namespace gsr {
@@ -103,6 +104,7 @@ struct Readback {
     uint32_t* host = nullptr;          // [0] numRendered, [1] / [2] onesweep error words, [3] top digits, [4] V,
                                        // [5..6] u64 un-wrapped instance count, [8..9] staged count
     const void* lists_skipped = nullptr;   // `values` of the last call made with GSR_FLAG_NO_SORTED_LISTS under the block plan
+    BlockFeed feed = {};                   // ... and where that call's block lists are (what gsr_backward reads instead)
     unsigned long long* staged_dev = nullptr;
     unsigned long long* staged_host = nullptr;
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
@@ -156,6 +158,11 @@ int current_readback(Readback*& out) {
 
 bool forward_skipped_sorted_lists(const void* point_list) {
     return g_rb_last && g_rb_last->lists_skipped && g_rb_last->lists_skipped == point_list;
+}
+bool forward_left_block_feed(const void* point_list, BlockFeed* out) {
+    if (!forward_skipped_sorted_lists(point_list)) return false;
+    *out = g_rb_last->feed;
+    return true;
 }
 
 }  // namespace gsr
@@ -435,6 +442,7 @@ int gsr_forward(gsr_forward_args* a) {
         // bytes of sorted keys / values altogether. keys / values are then left unwritten.
         if (a->flags & GSR_FLAG_NO_SORTED_LISTS) {
             g_rb.lists_skipped = bin.values;
+            g_rb.feed = block_feed(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
             a->plan_used |= GSR_PLAN_LISTS_SKIPPED;
         } else {
             if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));

@@ -18,13 +18,15 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "blend_core.hpp"
+#include "blockbin.hpp"
 
 namespace gsr {
 namespace {
 
 struct RenderBackwardParams {
     const uint2* ranges;
-    const uint32_t* point_list;
+    const uint32_t* point_list;      // the sorted list of Gaussian indices, or null: the tile lists come from `feed`
+    BlockFeed feed;                  // (block plan with GSR_FLAG_NO_SORTED_LISTS: the lists as the forward blend read them)
     const float2* means2D;
     const float* colors;
     const float4* conic_opacity;
@@ -90,17 +92,13 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     const uint2 range = p.ranges[tile];
     const TileBox box = tile_box(tx, ty, p.dims.width, p.dims.height);
 
-    for (int c = (int)((hi - 1) / kWave); c >= 0; --c) {
-        const uint32_t first = (uint32_t)c * kWave;
-        const uint32_t cnt = min((uint32_t)kWave, hi - first);
-        // As in the forward blend (blend_core.hpp): most records of a tile's list cannot light any of its pixels;
-        // they are dropped here, one lane per record, instead of being walked by the whole wave.
-        uint32_t id = 0;
+    // One batch of up to 64 list entries, lane l holding the entry at 0-based list position idx_l (descending batches,
+    // ascending lanes): as in the forward blend (blend_core.hpp) most records of a tile's list cannot light any of its
+    // pixels; they are dropped here, one lane per record, instead of being walked by the whole wave.
+    auto walk_batch = [&](const bool present, const uint32_t id, const uint32_t idx_l) {
         float2 xy_l = make_float2(0.0f, 0.0f);
         float4 co_l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const bool present = (uint32_t)lane < cnt;
         if (present) {
-            id = p.point_list[range.x + first + (uint32_t)lane];
             xy_l = p.means2D[id];
             co_l = p.conic_opacity[id];
         }
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             s_xy[slot] = xy_l;
             s_co[slot] = co_l;
             const float* col = p.colors + 3 * (size_t)id;
-            s_rgb[slot] = make_float4(col[0], col[1], col[2], __uint_as_float(first + (uint32_t)lane));
+            s_rgb[slot] = make_float4(col[0], col[1], col[2], __uint_as_float(idx_l));
         }
         // wave-private LDS: the writes above and the reads below are ordered inside the wave
         for (int j = (int)__popcll(kept_mask) - 1; j >= 0; --j) {
@@ -167,6 +165,51 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
                 unsafeAtomicAdd(p.dL_dcolors + 3 * id + 1, a_g);
                 unsafeAtomicAdd(p.dL_dcolors + 3 * id + 2, a_b);
             }
+        }
+    };
+
+    if (p.point_list) {
+        for (int c = (int)((hi - 1) / kWave); c >= 0; --c) {
+            const uint32_t first = (uint32_t)c * kWave;
+            const uint32_t cnt = min((uint32_t)kWave, hi - first);
+            const bool present = (uint32_t)lane < cnt;
+            const uint32_t id = present ? p.point_list[range.x + first + (uint32_t)lane] : 0u;
+            walk_batch(present, id, first + (uint32_t)lane);
+        }
+        return;
+    }
+    // ---- the tile's list read from the block lists, back to front (BlockFeed, blockbin.hpp) ----
+    const BlockFeed& f = p.feed;
+    const uint32_t b = (uint32_t)(ty / kBH) * (uint32_t)f.nbx + (uint32_t)(tx / kBW);
+    const uint32_t col = (uint32_t)(tx % kBW), row = 8u + (uint32_t)(ty % kBH), t_in_block = (uint32_t)((ty % kBH) * kBW + tx % kBW);
+    const uint32_t u0 = f.meta.unit_start()[b], u1 = f.meta.unit_start()[b + 1];
+    const uint32_t list0 = f.meta.list_start()[b];
+    // the last unit whose first entry of this tile lies in front of position hi
+    uint32_t below = 0;
+    for (uint32_t k = u0; k < u1; k += kWave) {
+        const uint32_t u = k + (uint32_t)lane;
+        below += (uint32_t)__popcll(__ballot(u < u1 && f.prefix[(size_t)u * 64 + t_in_block] < hi));
+    }
+    if (below == 0u) return;                   // (cannot happen: the first unit's prefix is 0 < hi)
+    for (uint32_t u = u0 + below; u-- > u0;) {
+        const uint32_t base = f.prefix[(size_t)u * 64 + t_in_block];
+        const uint2* um = f.unit_masks + (size_t)u * 16 * kBatches + (lane & (kBatches - 1));
+        const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
+        const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
+        const uint32_t c = (uint32_t)__popc(tm_lo) + (uint32_t)__popc(tm_hi);
+        const uint32_t start_v = base + prefix32_inclusive(c) - c;      // lane w < 32: list position of batch w's first entry
+        uint32_t nz = (uint32_t)__ballot(c != 0u && start_v < hi);       // batches with an entry in front of hi
+        while (nz != 0u) {
+            const int w = 31 - __builtin_clz(nz);                        // (wave-uniform: nz comes from a ballot)
+            nz &= ~(1u << w);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
+            const uint32_t hi_m = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
+            const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)start_v, w);
+            const unsigned long long mask = ((unsigned long long)hi_m << 32) | lo;
+            const uint32_t idx_l = start + __builtin_amdgcn_mbcnt_hi(hi_m, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            const bool present = __builtin_amdgcn_inverse_ballot_w64(mask) && idx_l < hi;
+            const uint32_t id = present ? f.ent_idx[list0 + (u - u0) * kUnit + (uint32_t)w * kWave + (uint32_t)lane] : 0u;
+            walk_batch(present, id, idx_l);
         }
     }
 }
@@ -482,7 +525,9 @@ static int backward_impl(gsr_backward_args* a) {
     const bool inria = (a->flags & GSR_FLAG_SEMANTICS_INRIA) != 0;
     // the upstream profile's chain needs what its colour was computed from
     if (inria && a->dL_dshs && (!a->shs || !a->cam_pos || !a->clamped || !a->means3D)) return GSR_ERR_INVALID_ARG;
-    if (forward_skipped_sorted_lists(a->point_list)) return GSR_ERR_INVALID_ARG;   // the forward call left the sorted lists unwritten
+    // the forward call left the sorted lists unwritten (GSR_FLAG_NO_SORTED_LISTS): its block lists are read instead
+    BlockFeed feed = {};
+    const bool from_blocks = forward_left_block_feed(a->point_list, &feed);
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
     if (profile && !g_bw_ev[0])
@@ -502,7 +547,8 @@ static int backward_impl(gsr_backward_args* a) {
     if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[0], stream));
     RenderBackwardParams r;
     r.ranges = reinterpret_cast<const uint2*>(a->ranges);
-    r.point_list = a->point_list;
+    r.point_list = from_blocks ? nullptr : a->point_list;
+    r.feed = feed;
     r.means2D = reinterpret_cast<const float2*>(a->means2D);
     r.colors = a->colors;
     r.conic_opacity = reinterpret_cast<const float4*>(a->conic_opacity);

@@ -26,27 +26,14 @@
 #include <stdlib.h>
 
 #include "blend_core.hpp"
+#include "blockbin.hpp"
 
 namespace gsr {
 namespace {
 
-constexpr int kBW = 8, kBH = 8;          // tiles per block: one lane per tile
 constexpr int kCoarse = 1024;            // Gaussians per workgroup of the coarse passes ...
 constexpr int kCoarseSmall = 512;        // ... with more than 256 blocks (4K): half the LDS mask table, two workgroups per CU
-constexpr int kUnit = 2048;              // block-list entries per emission unit
 constexpr int kScanRows = 64;            // table rows per workgroup of the block scan
-constexpr int kMaxBlocks = 512;          // 8 x 8-tile blocks per frame (4K: 30 x 17 = 510)
-
-struct BlockMeta {                       // u32 words in HBM
-    // [0, nbp]            list_start : entry index where the list of block b starts (nbp + 1 words)
-    // [nbp+1, 2nbp+1]     unit_start : first unit of block b (nbp + 1 words; [nb] = total units)
-    // then                ticket_count, ticket_emit (work queues of the two persistent kernels)
-    uint32_t* w;
-    int nbp;
-    __host__ __device__ uint32_t* list_start() const { return w; }
-    __host__ __device__ uint32_t* unit_start() const { return w + nbp + 1; }
-    __host__ __device__ uint32_t* tickets() const { return w + 2 * (nbp + 1); }
-};
 
 inline size_t align128(size_t v) { return (v + 127) / 128 * 128; }
 
@@ -230,17 +217,6 @@ __device__ __forceinline__ void writelane_mask(uint32_t& lo, uint32_t& hi, unsig
         : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "s"(lane_select));
 }
 
-// inclusive prefix sum over lanes 0..31 (and, separately, 32..63): row_shr 1, 2, 4, 8 + row_bcast:15
-__device__ __forceinline__ uint32_t prefix32_inclusive(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    return v;
-}
-
-constexpr int kBatches = kUnit / kWave;      // 32: one lane per batch in the transposed masks
 
 // Coverage masks of one unit, transposed. Lane = entry: per batch of 64 entries, 16 ballots give, for
 // each of the 8 tile columns and 8 tile rows of the block, which entries cover it; v_writelane files
@@ -673,6 +649,17 @@ PlanTables plan_tables(int n, int grid_x, int grid_y, uint32_t r_total, char* ge
     return t;
 }
 }  // namespace
+
+BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch) {
+    const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
+    BlockFeed f;
+    f.meta = t.meta;
+    f.nbx = t.nbx;
+    f.unit_masks = t.unit_masks;
+    f.prefix = t.cnt;
+    f.ent_idx = ent_idx;
+    return f;
+}
 
 // Everything of the block plan up to (not including) the emission: block lists, unit masks, prefixes and
 // the tile ranges. rect_packed: out, u32[n] in depth order. ent_rd / ent_idx: R-sized scratch for the

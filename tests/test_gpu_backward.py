@@ -22,8 +22,14 @@ def _forward_state(r):
     return g, im, b
 
 
-@pytest.mark.parametrize("w,h,n,seed,bg", [(64, 48, 300, 1, (0.0, 0.0, 0.0)), (100, 70, 1200, 2, (0.2, 0.5, 0.9))])
-def test_backward_matches_float64_oracle(w, h, n, seed, bg):
+@pytest.mark.parametrize("w,h,n,seed,bg,feed", [(64, 48, 300, 1, (0.0, 0.0, 0.0), "sorted"),
+                                                (100, 70, 1200, 2, (0.2, 0.5, 0.9), "sorted"),
+                                                (100, 70, 1200, 2, (0.2, 0.5, 0.9), "blocks"),
+                                                (200, 136, 7000, 3, (0.1, 0.0, 0.3), "blocks")])
+def test_backward_matches_float64_oracle(w, h, n, seed, bg, feed):
+    """feed = "blocks": the forward call ran with GSR_FLAG_NO_SORTED_LISTS, so gsr_backward walks the tile lists out of
+    the block lists (several units per block and several blocks in the last case); the oracle gets the sorted list of
+    an ordinary call on the same inputs."""
     import torch
     from gsrast_amd import camera, scenes
     from gsrast_amd.rasterizer import SplatRasterizer
@@ -33,9 +39,14 @@ def test_backward_matches_float64_oracle(w, h, n, seed, bg):
     cam = camera.default_camera(w, h, near=0.05, far=50.0)
     r = SplatRasterizer(w, h, background=bg)
     r.configure_from_scene(scene)
-    img = r.draw(cam).cpu().numpy()
+    img = r.draw(cam, plan="blocks" if feed == "blocks" else "auto").cpu().numpy()
     assert r.last_num_rendered > 0
     g, im, b = _forward_state(r)
+    if feed == "blocks":
+        r.map_binning_state()["values"].fill_(-1)
+        assert np.array_equal(r.draw(cam, plan="blocks", sorted_lists=False).cpu().numpy(), img)
+        assert r.last_plan == "blocks" and not r.last_lists_written
+        assert bool((r.map_binning_state()["values"] == -1).all())
     rng = np.random.default_rng(seed)
     dL = rng.normal(size=(3, h, w)).astype(np.float32)
     got = {k: v.cpu().numpy() for k, v in r.backward(torch.from_numpy(dL)).items()}
