@@ -443,6 +443,8 @@ int gsr_forward(gsr_forward_args* a) {
         if (a->flags & GSR_FLAG_NO_SORTED_LISTS) {
             g_rb.lists_skipped = bin.values;
             g_rb.feed = block_feed(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
+            g_rb.feed.acc = reinterpret_cast<float*>(bin.keys);       // (per-entry gradient sums of gsr_backward)
+            g_rb.feed.acc_floats = 2ull * (unsigned long long)R;
             a->plan_used |= GSR_PLAN_LISTS_SKIPPED;
         } else {
             if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));

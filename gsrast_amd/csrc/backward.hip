@@ -54,6 +54,65 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// Per-entry sums (block feed). A Gaussian that covers hundreds of tiles receives its nine sums from every one of them,
+// and atomics to ONE address from all over the chip serialise: on the bench frame that was 0.31 of the kernel's 0.59 ms
+// (timing builds: atomics spread over per-tile or per-block addresses 0.31 ms, no atomics 0.25 ms). With the block feed
+// a record is an ENTRY of its block's list, shared by at most the 64 tiles of the block: the tiles add into nine floats
+// per entry (scratch: the sorted keys' 8 R bytes, unused by such a call), and flush_block_acc_kernel then adds every
+// entry's sums to its Gaussian's — one lane per entry, different addresses in one instruction, and a Gaussian is hit
+// once per block it touches instead of once per tile. Needs 36 bytes per entry: E <= R / 4.5, else the direct path.
+// Decided per block: the sums of the part of the list that the forward blend looked into (BlockMeta::walked, whole
+// units) are cleared before and flushed after the kernel, which pays where that part is short — at most kAccMaxUnits
+// units; bench frame, 1-2 units per block: render backward 0.59 -> 0.38 ms. A block whose tiles walk deep lists (the
+// frame from outside the cloud: 10 000 entries per tile, small splats, little contention) keeps the direct atomics:
+// with per-entry sums for every block that frame went from 1.26 to 1.38 ms.
+constexpr uint32_t kAccMaxUnits = 4;
+__device__ __forceinline__ bool block_acc_fits(const BlockFeed& f, uint32_t b) {
+    return f.acc != nullptr && 9ull * (unsigned long long)f.meta.list_start()[f.meta.nbp] <= f.acc_floats &&
+           f.meta.walked()[b] <= kAccMaxUnits;
+}
+
+// Both helpers: workgroup (b, part) of kAccParts takes a slice of the entries of block b that the forward blend
+// looked into (whole units from the front of the block's list; a pixel's last contributor lies there).
+constexpr uint32_t kAccParts = 4;
+__device__ __forceinline__ void walked_slice(const BlockFeed& f, size_t& e0, size_t& e1) {
+    const uint32_t b = blockIdx.x / kAccParts, part = blockIdx.x % kAccParts;
+    e0 = e1 = 0;
+    if (!block_acc_fits(f, b)) return;
+    const size_t first = f.meta.list_start()[b], end = f.meta.list_start()[b + 1];
+    const size_t upto = min(end, first + (size_t)f.meta.walked()[b] * kUnit);
+    const size_t per = ((upto - first + kAccParts - 1) / kAccParts + 3) / 4 * 4;
+    e0 = min(upto, first + part * per);
+    e1 = min(upto, e0 + per);
+}
+
+__global__ __launch_bounds__(256) void zero_block_acc_kernel(const BlockFeed f) {
+    size_t e0, e1;
+    walked_slice(f, e0, e1);
+    for (size_t i = 9 * e0 + threadIdx.x; i < 9 * e1; i += 256) f.acc[i] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void flush_block_acc_kernel(const BlockFeed f, float* __restrict__ dL_dmean2D,
+                                                              float* __restrict__ dL_dconic_opacity, float* __restrict__ dL_dcolors) {
+    size_t e0, e1;
+    walked_slice(f, e0, e1);
+    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const float* a = f.acc + 9 * e;
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = a[k];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) any = any || v[k] != 0.0f;
+        if (!any) continue;
+        const size_t id = f.ent_idx[e];
+        unsafeAtomicAdd(dL_dmean2D + 2 * id, v[0]); unsafeAtomicAdd(dL_dmean2D + 2 * id + 1, v[1]);
+        unsafeAtomicAdd(dL_dconic_opacity + 4 * id, v[2]); unsafeAtomicAdd(dL_dconic_opacity + 4 * id + 1, v[3]);
+        unsafeAtomicAdd(dL_dconic_opacity + 4 * id + 2, v[4]); unsafeAtomicAdd(dL_dconic_opacity + 4 * id + 3, v[5]);
+        unsafeAtomicAdd(dL_dcolors + 3 * id, v[6]); unsafeAtomicAdd(dL_dcolors + 3 * id + 1, v[7]); unsafeAtomicAdd(dL_dcolors + 3 * id + 2, v[8]);
+    }
+}
+
 __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwardParams p) {
     __shared__ uint32_t s_id[kWave];
     __shared__ float2 s_xy[kWave];
@@ -95,7 +154,10 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     // One batch of up to 64 list entries, lane l holding the entry at 0-based list position idx_l (descending batches,
     // ascending lanes): as in the forward blend (blend_core.hpp) most records of a tile's list cannot light any of its
     // pixels; they are dropped here, one lane per record, instead of being walked by the whole wave.
-    auto walk_batch = [&](const bool present, const uint32_t id, const uint32_t idx_l) {
+    // `key` is what the record's sums are filed under: the Gaussian's index, or (block feed with room for per-entry
+    // sums, see below) the record's entry number in the block lists.
+    bool per_entry = false;
+    auto walk_batch = [&](const bool present, const uint32_t id, const uint32_t idx_l, const uint32_t key) {
         float2 xy_l = make_float2(0.0f, 0.0f);
         float4 co_l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (present) {
@@ -106,7 +168,7 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
         const unsigned long long kept_mask = __ballot(keep);
         if (keep) {
             const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(kept_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept_mask, 0u));
-            s_id[slot] = id;
+            s_id[slot] = key;
             s_xy[slot] = xy_l;
             s_co[slot] = co_l;
             const float* col = p.colors + 3 * (size_t)id;
@@ -153,7 +215,12 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             a_A = wave_sum_to_lane63(a_A); a_B = wave_sum_to_lane63(a_B); a_C = wave_sum_to_lane63(a_C);
             a_op = wave_sum_to_lane63(a_op);
             a_r = wave_sum_to_lane63(a_r); a_g = wave_sum_to_lane63(a_g); a_b = wave_sum_to_lane63(a_b);
-            if (lane == kWave - 1) {
+            if (lane == kWave - 1 && per_entry) {
+                float* acc = p.feed.acc + 9 * (size_t)s_id[j];
+                unsafeAtomicAdd(acc + 0, a_mx); unsafeAtomicAdd(acc + 1, a_my);
+                unsafeAtomicAdd(acc + 2, a_A); unsafeAtomicAdd(acc + 3, a_B); unsafeAtomicAdd(acc + 4, a_C); unsafeAtomicAdd(acc + 5, a_op);
+                unsafeAtomicAdd(acc + 6, a_r); unsafeAtomicAdd(acc + 7, a_g); unsafeAtomicAdd(acc + 8, a_b);
+            } else if (lane == kWave - 1) {
                 const size_t id = s_id[j];
                 unsafeAtomicAdd(p.dL_dmean2D + 2 * id, a_mx);
                 unsafeAtomicAdd(p.dL_dmean2D + 2 * id + 1, a_my);
@@ -174,13 +241,14 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             const uint32_t cnt = min((uint32_t)kWave, hi - first);
             const bool present = (uint32_t)lane < cnt;
             const uint32_t id = present ? p.point_list[range.x + first + (uint32_t)lane] : 0u;
-            walk_batch(present, id, first + (uint32_t)lane);
+            walk_batch(present, id, first + (uint32_t)lane, id);
         }
         return;
     }
     // ---- the tile's list read from the block lists, back to front (BlockFeed, blockbin.hpp) ----
     const BlockFeed& f = p.feed;
     const uint32_t b = (uint32_t)(ty / kBH) * (uint32_t)f.nbx + (uint32_t)(tx / kBW);
+    per_entry = block_acc_fits(f, b);
     const uint32_t col = (uint32_t)(tx % kBW), row = 8u + (uint32_t)(ty % kBH), t_in_block = (uint32_t)((ty % kBH) * kBW + tx % kBW);
     const uint32_t u0 = f.meta.unit_start()[b], u1 = f.meta.unit_start()[b + 1];
     const uint32_t list0 = f.meta.list_start()[b];
@@ -208,8 +276,9 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             const unsigned long long mask = ((unsigned long long)hi_m << 32) | lo;
             const uint32_t idx_l = start + __builtin_amdgcn_mbcnt_hi(hi_m, __builtin_amdgcn_mbcnt_lo(lo, 0u));
             const bool present = __builtin_amdgcn_inverse_ballot_w64(mask) && idx_l < hi;
-            const uint32_t id = present ? f.ent_idx[list0 + (u - u0) * kUnit + (uint32_t)w * kWave + (uint32_t)lane] : 0u;
-            walk_batch(present, id, idx_l);
+            const uint32_t e = list0 + (u - u0) * kUnit + (uint32_t)w * kWave + (uint32_t)lane;
+            const uint32_t id = present ? f.ent_idx[e] : 0u;
+            walk_batch(present, id, idx_l, per_entry ? e : id);
         }
     }
 }
@@ -283,15 +352,35 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
     }
 }
 
+// Memory schedule: every load of the Gaussian first, all stores last (a store may alias a later load as far as the
+// compiler knows, and a load issued behind a store waits for the store's acknowledgement too: the round-1 kernel
+// stored dL_dmeans3D before it fetched the scales and the quaternion). INRIA selects the upstream profile's chain at
+// compile time: the 48 SH gradients of that profile do not cost the reference's profile their registers.
+template <bool INRIA>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBackwardParams p) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.n) return;
     float out[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     float gmean[3] = {0.0f, 0.0f, 0.0f};
     const bool visible = p.radii[idx] > 0;
+    // ---- loads ----
+    float4 mean = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g = mean, sc = mean, rot = mean;
+    float2 g2 = make_float2(0.0f, 0.0f), c3a = g2, c3b = g2, c3c = g2;
+    float gc[3] = {0.0f, 0.0f, 0.0f};
+    if (visible) {
+        mean = p.means3D[idx];
+        const float2* c3p = reinterpret_cast<const float2*>(p.cov3D + 6 * (size_t)idx);
+        c3a = c3p[0]; c3b = c3p[1]; c3c = c3p[2];
+        g = p.dL_dconic_opacity[idx];
+        if (p.dL_dmeans3D) g2 = p.dL_dmean2D[idx];
+        if (p.dL_dscales) { sc = p.scales[idx]; rot = p.rotations[idx]; }
+        if (p.dL_dshs) {
+            const float* gcp = p.dL_dcolors + 3 * (size_t)idx;
+            gc[0] = gcp[0]; gc[1] = gcp[1]; gc[2] = gcp[2];
+        }
+    }
     if (visible) {
         const float* v = p.view;
-        const float4 mean = p.means3D[idx];
         // t, clamped as in computeCov2D (GSCuda.cu:201-210)
         float tx = (v[0] * mean.x + v[4] * mean.y) + (v[8] * mean.z + v[12] * 1.0f);
         float ty = (v[1] * mean.x + v[5] * mean.y) + (v[9] * mean.z + v[13] * 1.0f);
@@ -302,7 +391,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         tx = cx * tz;
         ty = cy * tz;
         // P = J W (2 x 3): cov2D = P Sigma P^T
-        const float fx = p.inria ? p.focal_x : p.focal, fy = p.inria ? p.focal_y : p.focal;
+        const float fx = INRIA ? p.focal_x : p.focal, fy = INRIA ? p.focal_y : p.focal;
         const float j00 = fx / tz, j11 = fy / tz, j02 = -fx * tx / (tz * tz), j12 = -fy * ty / (tz * tz);
         float P[2][3];
 #pragma unroll
@@ -310,7 +399,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             P[0][c] = j00 * v[4 * c + 0] + j02 * v[4 * c + 2];
             P[1][c] = j11 * v[4 * c + 1] + j12 * v[4 * c + 2];
         }
-        const float* c3 = p.cov3D + 6 * (size_t)idx;
+        const float c3[6] = {c3a.x, c3a.y, c3b.x, c3b.y, c3c.x, c3c.y};
         const float s[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
         float ps[2][3];
 #pragma unroll
@@ -324,7 +413,6 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         if (det != 0.0f) {
             const float inv = 1.0f / det;
             const float k00 = cc * inv, k01 = -b * inv, k11 = a * inv;         // K = cov2D^-1 = the conic
-            const float4 g = p.dL_dconic_opacity[idx];
             const float q00 = g.x, q01 = 0.5f * g.y, q11 = g.z;                // gradient w.r.t. the full symmetric K
             // gM = -K gK K
             const float r00 = k00 * q00 + k01 * q01, r01 = k00 * q01 + k01 * q11;
@@ -376,11 +464,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         if (p.dL_dmeans3D) {
             // pixel-space centre: pix = ((proj mean).x / ((proj mean).w + 0.001) * 0.5 + 0.5) * W (GSCuda.cu:302-305, :342)
             const float* pm = p.proj;
-            const float mw_ = p.inria ? 1.0f : mean.w;          // (the upstream projection takes the point as (x, y, z, 1))
+            const float mw_ = INRIA ? 1.0f : mean.w;          // (the upstream projection takes the point as (x, y, z, 1))
             const float hx = (pm[0] * mean.x + pm[4] * mean.y) + (pm[8] * mean.z + pm[12] * mw_);
             const float hy = (pm[1] * mean.x + pm[5] * mean.y) + (pm[9] * mean.z + pm[13] * mw_);
-            const float wp = (p.inria ? p.w_eps : 0.001f) + ((pm[3] * mean.x + pm[7] * mean.y) + (pm[11] * mean.z + pm[15] * mw_));
-            const float2 g2 = p.dL_dmean2D[idx];
+            const float wp = (INRIA ? p.w_eps : 0.001f) + ((pm[3] * mean.x + pm[7] * mean.y) + (pm[11] * mean.z + pm[15] * mw_));
             const float iw = 1.0f / wp, iw2 = iw * iw;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -390,20 +477,18 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             }
         }
     }
-    if (p.inria && p.dL_dshs) {
+    float gsh[INRIA ? 48 : 1];
+    if (INRIA && p.dL_dshs) {
         // colour_c = max(0, 0.5 + sum_k B_k(dir) sh[k][c]), dir = (mean - cam) / |mean - cam|: dL/dsh[k][c] = B_k g_c, and
         // the direction moves with the mean; a channel clamped at zero passes nothing (oracle: inria_color_backward)
-        float gsh[48];
 #pragma unroll
-        for (int k = 0; k < 48; ++k) gsh[k] = 0.0f;
+        for (int k = 0; k < (INRIA ? 48 : 1); ++k) gsh[k] = 0.0f;
         if (visible) {
-            const float4 mean = p.means3D[idx];
             float dx = mean.x - p.cam_pos[0], dy = mean.y - p.cam_pos[1], dz = mean.z - p.cam_pos[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz), il = 1.0f / len;
             dx *= il; dy *= il; dz *= il;
             float B[16], G[16][3];
             sh_basis_grad(p.sh_deg, dx, dy, dz, B, G);
-            const float* gc = p.dL_dcolors + 3 * (size_t)idx;
             float g[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[c] = p.clamped[3 * (size_t)idx + c] ? 0.0f : gc[c];
@@ -415,24 +500,18 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
                 if (k < terms) {
                     const float w = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
                     gd[0] += G[k][0] * w; gd[1] += G[k][1] * w; gd[2] += G[k][2] * w;
-                    gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2];
+                    if constexpr (INRIA) { gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2]; }
                 }
             }
             const float dot = dx * gd[0] + dy * gd[1] + dz * gd[2];
             gmean[0] += (gd[0] - dx * dot) * il; gmean[1] += (gd[1] - dy * dot) * il; gmean[2] += (gd[2] - dz * dot) * il;
         }
-        float4* o = reinterpret_cast<float4*>(p.dL_dshs + 48 * (size_t)idx);
-#pragma unroll
-        for (int q = 0; q < 12; ++q) o[q] = make_float4(gsh[4 * q], gsh[4 * q + 1], gsh[4 * q + 2], gsh[4 * q + 3]);
     }
-    if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4(gmean[0], gmean[1], gmean[2], 0.0f);
+    float gsc[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (p.dL_dscales) {
         // Sigma = M M^T, M = R diag(mod s): gM = 2 gSigma M (off-diagonal stored gradients split over both entries)
-        float gsc[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (visible && p.inria) {
+        if (visible && INRIA) {
             // Sigma = M M^T, M = R(q) diag(mod s) with the RAW quaternion q = (r, x, y, z) (oracle: inria_cov3d_backward)
-            const float4 sc = p.scales[idx];
-            const float4 rot = p.rotations[idx];
             const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
             const float R[3][3] = {{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
                                    {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
@@ -455,8 +534,6 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             gq[2] = 2.0f * (x * (gR[0][1] + gR[1][0]) + r * (gR[0][2] - gR[2][0]) + z * (gR[1][2] + gR[2][1])) - 4.0f * y * (gR[0][0] + gR[2][2]);
             gq[3] = 2.0f * (r * (gR[1][0] - gR[0][1]) + x * (gR[0][2] + gR[2][0]) + y * (gR[1][2] + gR[2][1])) - 4.0f * z * (gR[0][0] + gR[1][1]);
         } else if (visible) {
-            const float4 sc = p.scales[idx];
-            const float4 rot = p.rotations[idx];
             const float nrm = sqrtf((rot.x * rot.x + rot.y * rot.y) + (rot.z * rot.z + rot.w * rot.w));
             const float inv = 1.0f / nrm;
             const float x = rot.x * inv, y = rot.y * inv, z = rot.z * inv, w = rot.w * inv;
@@ -487,6 +564,17 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             const float dot = x * gx + y * gy + z * gz + w * gw;
             gq[0] = (gx - x * dot) * inv; gq[1] = (gy - y * dot) * inv; gq[2] = (gz - z * dot) * inv; gq[3] = (gw - w * dot) * inv;
         }
+    }
+    // ---- stores ----
+    if constexpr (INRIA) {
+        if (p.dL_dshs) {
+            float4* o = reinterpret_cast<float4*>(p.dL_dshs + 48 * (size_t)idx);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) o[q] = make_float4(gsh[4 * q], gsh[4 * q + 1], gsh[4 * q + 2], gsh[4 * q + 3]);
+        }
+    }
+    if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4(gmean[0], gmean[1], gmean[2], 0.0f);
+    if (p.dL_dscales) {
         p.dL_dscales[idx] = make_float4(gsc[0], gsc[1], gsc[2], 0.0f);
         if (p.dL_drotations) p.dL_drotations[idx] = make_float4(gq[0], gq[1], gq[2], gq[3]);
     }
@@ -494,12 +582,15 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     dst[0] = make_float2(out[0], out[1]);
     dst[1] = make_float2(out[2], out[3]);
     dst[2] = make_float2(out[4], out[5]);
-    if (p.dL_dshs && !p.inria) {
-        const float* gc = p.dL_dcolors + 3 * (size_t)idx;
-        float* o = p.dL_dshs + 48 * (size_t)idx;
-        o[0] = visible ? 0.4f * gc[0] : 0.0f;           // colour = 0.5 + 0.4 DC (GSCuda.cu:362-366)
-        o[1] = visible ? 0.4f * gc[1] : 0.0f;
-        o[2] = visible ? 0.4f * gc[2] : 0.0f;
+    if (p.dL_dshs && !INRIA) {
+        // colour = 0.5 + 0.4 DC (GSCuda.cu:362-366). The triple goes out as the whole 64 bytes it lies in (the 13 floats
+        // behind it are gradients of coefficients the colour does not depend on: zero). 12 bytes at a 192-byte stride
+        // are a partial write per Gaussian, a read-modify-write in the memory: measured for 16 / 32 / 64 / 128 / 192
+        // bytes per Gaussian the chain takes 0.47 / 0.48 / 0.38 / 0.57 / 0.68 ms on the bench frame (0.20 without dL_dshs).
+        float4* o = reinterpret_cast<float4*>(p.dL_dshs + 48 * (size_t)idx);
+        o[0] = visible ? make_float4(0.4f * gc[0], 0.4f * gc[1], 0.4f * gc[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) o[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -561,9 +652,20 @@ static int backward_impl(gsr_backward_args* a) {
     r.dL_dcolors = a->dL_dcolors;
     r.dims = d;
     r.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
+    // (all blocks of the frame, also in a sharded call: the blocks outside the band were not walked)
+    const unsigned acc_wgs = (unsigned)(((d.grid_x + kBW - 1) / kBW) * ((d.grid_y + kBH - 1) / kBH)) * kAccParts;
     if (r.num_tiles > 0) {
+        if (from_blocks && feed.acc) {
+            hipLaunchKernelGGL(zero_block_acc_kernel, dim3(acc_wgs), dim3(256), 0, stream, feed);
+            GSR_LAUNCH_CHECK("zero_block_acc_kernel");
+        }
         hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)r.num_tiles), dim3(kWave), 0, stream, r);
         GSR_LAUNCH_CHECK("render_backward_kernel");
+        if (from_blocks && feed.acc) {
+            hipLaunchKernelGGL(flush_block_acc_kernel, dim3(acc_wgs), dim3(256), 0, stream, feed, a->dL_dmean2D, a->dL_dconic_opacity,
+                               a->dL_dcolors);
+            GSR_LAUNCH_CHECK("flush_block_acc_kernel");
+        }
     }
     if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[1], stream));
     if (a->dL_dcov3D) {
@@ -594,7 +696,8 @@ static int backward_impl(gsr_backward_args* a) {
         q.focal_y = (float)a->height / (2.0f * a->tan_fovy);
         q.w_eps = 0.0000001f;
         q.shs = a->shs; q.cam_pos = a->cam_pos; q.clamped = a->clamped;
-        hipLaunchKernelGGL(preprocess_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
+        if (inria) hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
         GSR_LAUNCH_CHECK("preprocess_backward_kernel");
     }
     if (profile) {

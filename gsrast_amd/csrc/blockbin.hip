@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kMaxBlocks) void blockscan_partials_kernel(uint32_t
     const uint32_t us = block_exclusive((len + kUnit - 1) / kUnit, s_ws, &total_units);
     meta.list_start()[threadIdx.x] = ls;
     meta.unit_start()[threadIdx.x] = us;
+    meta.walked()[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         meta.list_start()[nbp] = total_entries;
         meta.unit_start()[nbp] = total_units;
@@ -595,6 +596,10 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
     }
     tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
+    // how far into the block's list this tile looked (gsr_backward after GSR_FLAG_NO_SORTED_LISTS keeps per-entry sums
+    // for that part of the list only)
+    const uint32_t units = it_u - u0 + (it_loaded ? 1u : 0u);
+    if (lane == 0 && units != 0u) atomicMax(&p.meta.walked()[b], units);
 }
 
 }  // namespace
@@ -612,7 +617,7 @@ static size_t blockbin_partial_bytes(size_t n) {
 }
 // per-Gaussian scratch (geometry chunk): chunk table, row-group partials, block meta, tile counts / starts
 size_t blockbin_geo_bytes(size_t n) {
-    return blockbin_table_bytes(n) + blockbin_partial_bytes(n) + align128((2 * (kMaxBlocks + 1) + 2) * 4) +
+    return blockbin_table_bytes(n) + blockbin_partial_bytes(n) + align128(kBlockMetaWords * 4) +
            2 * align128((65536 + 1) * 4);
 }
 // per-instance scratch (binning chunk): keys per (unit, tile) + the units' transposed coverage masks
@@ -641,7 +646,7 @@ PlanTables plan_tables(int n, int grid_x, int grid_y, uint32_t r_total, char* ge
     char* p = geo_scratch;
     t.table = reinterpret_cast<uint32_t*>(p); p += blockbin_table_bytes((size_t)n);
     t.partial = reinterpret_cast<uint32_t*>(p); p += blockbin_partial_bytes((size_t)n);
-    t.meta.w = reinterpret_cast<uint32_t*>(p); t.meta.nbp = t.nbp; p += align128((2 * (kMaxBlocks + 1) + 2) * 4);
+    t.meta.w = reinterpret_cast<uint32_t*>(p); t.meta.nbp = t.nbp; p += align128(kBlockMetaWords * 4);
     t.tile_count = reinterpret_cast<uint32_t*>(p); p += align128((65536 + 1) * 4);
     t.tile_start = reinterpret_cast<uint32_t*>(p);
     t.cnt = reinterpret_cast<uint32_t*>(bin_scratch);
@@ -658,6 +663,8 @@ BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_
     f.unit_masks = t.unit_masks;
     f.prefix = t.cnt;
     f.ent_idx = ent_idx;
+    f.acc = nullptr;
+    f.acc_floats = 0;
     return f;
 }
 

@@ -14,12 +14,15 @@ struct BlockMeta {                       // u32 words in HBM
     // [0, nbp]            list_start : entry index where the list of block b starts (nbp + 1 words)
     // [nbp+1, 2nbp+1]     unit_start : first unit of block b (nbp + 1 words; [nb] = total units)
     // then                ticket_count, ticket_emit (work queues of the two persistent kernels)
+    // then                walked : per block, how many of its units the forward blend looked into (max over its tiles)
     uint32_t* w;
     int nbp;
     __host__ __device__ uint32_t* list_start() const { return w; }
     __host__ __device__ uint32_t* unit_start() const { return w + nbp + 1; }
     __host__ __device__ uint32_t* tickets() const { return w + 2 * (nbp + 1); }
+    __host__ __device__ uint32_t* walked() const { return w + 2 * (nbp + 1) + 2; }
 };
+constexpr size_t kBlockMetaWords = 2 * (kMaxBlocks + 1) + 2 + kMaxBlocks;
 
 // A tile (tx, ty) belongs to block b = (ty / 8) * nbx + tx / 8; its list is, unit after unit of the block's list and
 // batch after batch (64 entries) of a unit, the entries whose bit is set in
@@ -32,6 +35,9 @@ struct BlockFeed {
     const uint2* unit_masks;
     const uint32_t* prefix;
     const uint32_t* ent_idx;
+    // scratch for per-entry gradient sums (render backward): the sorted keys' 8 R bytes, which such a call leaves unused
+    float* acc;
+    unsigned long long acc_floats;
 };
 BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch);
 
