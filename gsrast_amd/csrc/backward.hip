@@ -356,13 +356,18 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
 // compiler knows, and a load issued behind a store waits for the store's acknowledgement too: the round-1 kernel
 // stored dL_dmeans3D before it fetched the scales and the quaternion). INRIA selects the upstream profile's chain at
 // compile time: the 48 SH gradients of that profile do not cost the reference's profile their registers.
+constexpr int kShRow = 49;      // LDS floats per SH record: odd, so that the 64 lanes' accesses to coefficient k spread over the banks
 template <bool INRIA>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBackwardParams p) {
+    // (upstream profile: the wave's 64 x 48 SH coefficients come in, and their gradients go out, through LDS — 16 bytes
+    // per lane of consecutive memory per instruction instead of 64 records touched by each; lanes past n stay for that)
+    __shared__ float s_sh[INRIA ? 4 * kWave * kShRow : 1];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.n) return;
+    const bool valid = idx < p.n;
+    if (!INRIA && !valid) return;
     float out[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     float gmean[3] = {0.0f, 0.0f, 0.0f};
-    const bool visible = p.radii[idx] > 0;
+    const bool visible = valid && p.radii[idx] > 0;
     // ---- loads ----
     float4 mean = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g = mean, sc = mean, rot = mean;
     float2 g2 = make_float2(0.0f, 0.0f), c3a = g2, c3b = g2, c3c = g2;
@@ -477,34 +482,61 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             }
         }
     }
-    float gsh[INRIA ? 48 : 1];
-    if (INRIA && p.dL_dshs) {
-        // colour_c = max(0, 0.5 + sum_k B_k(dir) sh[k][c]), dir = (mean - cam) / |mean - cam|: dL/dsh[k][c] = B_k g_c, and
-        // the direction moves with the mean; a channel clamped at zero passes nothing (oracle: inria_color_backward)
-#pragma unroll
-        for (int k = 0; k < (INRIA ? 48 : 1); ++k) gsh[k] = 0.0f;
-        if (visible) {
-            float dx = mean.x - p.cam_pos[0], dy = mean.y - p.cam_pos[1], dz = mean.z - p.cam_pos[2];
-            const float len = sqrtf(dx * dx + dy * dy + dz * dz), il = 1.0f / len;
-            dx *= il; dy *= il; dz *= il;
-            float B[16], G[16][3];
-            sh_basis_grad(p.sh_deg, dx, dy, dz, B, G);
-            float g[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = p.clamped[3 * (size_t)idx + c] ? 0.0f : gc[c];
-            const float* sh = p.shs + 48 * (size_t)idx;
-            float gd[3] = {0.0f, 0.0f, 0.0f};
+    [[maybe_unused]] const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    [[maybe_unused]] float* sh_rows = s_sh + (INRIA ? wave * kWave * kShRow : 0);
+    [[maybe_unused]] const size_t sh_first = ((size_t)blockIdx.x * 256 + (size_t)wave * kWave) * 48, sh_limit = (size_t)p.n * 48;
+    if constexpr (INRIA) {
+        if (p.dL_dshs) {
+            // colour_c = max(0, 0.5 + sum_k B_k(dir) sh[k][c]), dir = (mean - cam) / |mean - cam|: dL/dsh[k][c] = B_k g_c, and
+            // the direction moves with the mean; a channel clamped at zero passes nothing (oracle: inria_color_backward)
             const int terms = (p.sh_deg + 1) * (p.sh_deg + 1);
+            if (__ballot(visible) != 0ull) {
+                const int pieces = p.sh_deg > 2 ? 12 : (p.sh_deg > 1 ? 7 : (p.sh_deg > 0 ? 3 : 1));   // 16-byte pieces of a record in use
+                float4 piece[12];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < terms) {
-                    const float w = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
-                    gd[0] += G[k][0] * w; gd[1] += G[k][1] * w; gd[2] += G[k][2] * w;
-                    if constexpr (INRIA) { gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2]; }
+                for (int q = 0; q < 12; ++q) {
+                    const int f4 = q * kWave + lane;
+                    const size_t at = sh_first + 4 * (size_t)f4;
+                    piece[q] = ((f4 % 12) < pieces && at + 3 < sh_limit) ? *reinterpret_cast<const float4*>(p.shs + at)
+                                                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    const int f4 = q * kWave + lane;
+                    float* dst = sh_rows + (f4 / 12) * kShRow + (f4 % 12) * 4;
+                    dst[0] = piece[q].x; dst[1] = piece[q].y; dst[2] = piece[q].z; dst[3] = piece[q].w;
                 }
             }
-            const float dot = dx * gd[0] + dy * gd[1] + dz * gd[2];
-            gmean[0] += (gd[0] - dx * dot) * il; gmean[1] += (gd[1] - dy * dot) * il; gmean[2] += (gd[2] - dz * dot) * il;
+            // wave-private LDS: ordered inside the wave. From here a lane reads and then overwrites its own row only.
+            float* row = sh_rows + lane * kShRow;
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f, il = 0.0f;
+            float B[16], G[16][3];
+            float g[3] = {0.0f, 0.0f, 0.0f};
+            if (visible) {
+                dx = mean.x - p.cam_pos[0]; dy = mean.y - p.cam_pos[1]; dz = mean.z - p.cam_pos[2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                il = 1.0f / len;
+                dx *= il; dy *= il; dz *= il;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = p.clamped[3 * (size_t)idx + c] ? 0.0f : gc[c];
+            }
+            sh_basis_grad(p.sh_deg, dx, dy, dz, B, G);
+            float gd[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool on = visible && k < terms;
+                if (on) {
+                    const float w = row[3 * k] * g[0] + row[3 * k + 1] * g[1] + row[3 * k + 2] * g[2];
+                    gd[0] += G[k][0] * w; gd[1] += G[k][1] * w; gd[2] += G[k][2] * w;
+                }
+                row[3 * k] = on ? B[k] * g[0] : 0.0f;
+                row[3 * k + 1] = on ? B[k] * g[1] : 0.0f;
+                row[3 * k + 2] = on ? B[k] * g[2] : 0.0f;
+            }
+            if (visible) {
+                const float dot = dx * gd[0] + dy * gd[1] + dz * gd[2];
+                gmean[0] += (gd[0] - dx * dot) * il; gmean[1] += (gd[1] - dy * dot) * il; gmean[2] += (gd[2] - dz * dot) * il;
+            }
         }
     }
     float gsc[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -568,10 +600,15 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     // ---- stores ----
     if constexpr (INRIA) {
         if (p.dL_dshs) {
-            float4* o = reinterpret_cast<float4*>(p.dL_dshs + 48 * (size_t)idx);
 #pragma unroll
-            for (int q = 0; q < 12; ++q) o[q] = make_float4(gsh[4 * q], gsh[4 * q + 1], gsh[4 * q + 2], gsh[4 * q + 3]);
+            for (int q = 0; q < 12; ++q) {
+                const int f4 = q * kWave + lane;
+                const size_t at = sh_first + 4 * (size_t)f4;
+                const float* src = sh_rows + (f4 / 12) * kShRow + (f4 % 12) * 4;
+                if (at + 3 < sh_limit) *reinterpret_cast<float4*>(p.dL_dshs + at) = make_float4(src[0], src[1], src[2], src[3]);
+            }
         }
+        if (!valid) return;
     }
     if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4(gmean[0], gmean[1], gmean[2], 0.0f);
     if (p.dL_dscales) {
