@@ -62,6 +62,7 @@ def main():
     write_trace("head", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras   (the headline frame)")
     write_trace("outside", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --pose 0,0,-14")
     write_trace("bound", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --opacity-scale 0.1")
+    write_trace("backward_nolists", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --backward --no-sorted-lists")
     with open(f"{DST}/r02_pmc.txt", "w") as o:
         o.write("# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras [frame]\n"
                 "# one run per counter set; per-kernel averages over dispatches. FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE\n"
@@ -107,7 +108,7 @@ def main():
         if v:
             out[f"blend_insts_{name.split('_')[0]}"] = v
     json.dump(out, open(f"{DST}/pmc_traffic_r02.json", "w"), indent=1)
-    for name in ("bench_default", "bench_backward", "bench_backward_outside", "bench_4k", "bench_overlap", "bench_stress50M",
+    for name in ("bench_default", "bench_backward", "bench_backward_outside", "bench_backward_nolists", "bench_backward_nolists_inria_sh3", "bench_4k", "bench_overlap", "bench_stress50M",
                  "bench_stress50M_blocks", "bench_stress50M_inria_sh3", "bench_forced_dist_1rank"):
         d = bench_line(f"{SRC}/{name}.json")
         if d is None:

@@ -41,6 +41,9 @@ pmc bound_fetch "FETCH_SIZE" $SHORT --opacity-scale 0.1
 # 5. the other configurations (bench lines only)
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --backward > $OUT/bench_backward.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --backward --pose 0,0,-14 > $OUT/bench_backward_outside.json 2>/dev/null
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --backward --no-sorted-lists > $OUT/bench_backward_nolists.json 2>/dev/null
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --backward --no-sorted-lists --semantics inria --sh-degree 3 > $OUT/bench_backward_nolists_inria_sh3.json 2>/dev/null
+trace backward_nolists $SHORT --backward --no-sorted-lists
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --width 3840 --height 2160 > $OUT/bench_4k.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --overlap > $OUT/bench_overlap.json 2>/dev/null
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --scene stress --splats 50000000 > $OUT/bench_stress50M.json 2>/dev/null
