@@ -104,7 +104,8 @@ struct Readback {
     uint32_t* host = nullptr;          // [0] numRendered, [1] / [2] onesweep error words, [3] top digits, [4] V,
                                        // [5..6] u64 un-wrapped instance count, [8..9] staged count
     const void* lists_skipped = nullptr;   // `values` of the last call made with GSR_FLAG_NO_SORTED_LISTS under the block plan
-    BlockFeed feed = {};                   // ... and where that call's block lists are (what gsr_backward reads instead)
+    const void* feed_for = nullptr;        // `values` of the last call that ran the block plan ...
+    BlockFeed feed = {};                   // ... and where that call left its block lists (gsr_backward reads tile lists there)
     unsigned long long* staged_dev = nullptr;
     unsigned long long* staged_host = nullptr;
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
@@ -160,7 +161,7 @@ bool forward_skipped_sorted_lists(const void* point_list) {
     return g_rb_last && g_rb_last->lists_skipped && g_rb_last->lists_skipped == point_list;
 }
 bool forward_left_block_feed(const void* point_list, BlockFeed* out) {
-    if (!forward_skipped_sorted_lists(point_list)) return false;
+    if (!(g_rb_last && g_rb_last->feed_for && g_rb_last->feed_for == point_list)) return false;
     *out = g_rb_last->feed;
     return true;
 }
@@ -289,6 +290,7 @@ int gsr_forward(gsr_forward_args* a) {
     Readback& g_rb = *rbp;
     g_rb_last = rbp;
     g_rb.lists_skipped = nullptr;
+    g_rb.feed_for = nullptr;
     if ((rc = g_rb.ensure()) != GSR_OK) return fail(rc);
     if (profile && (rc = g_rb.ensure_events()) != GSR_OK) return fail(rc);
     if (count_staged && (rc = g_rb.ensure_staged()) != GSR_OK) return fail(rc);
@@ -437,14 +439,18 @@ int gsr_forward(gsr_forward_args* a) {
             emit_stream = g_rb.side;
             forked = true;
         }
+        // What a gsr_backward call after this one may use: the block lists (read by nothing else once this call is
+        // complete) and, for its per-entry gradient sums, the 8 R bytes of keysUnsorted — the (rectangle | depth) halves
+        // of the block-list entries there are dead after the unit masks and the emission.
+        g_rb.feed = block_feed(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
+        g_rb.feed.acc = reinterpret_cast<float*>(bin.keys_unsorted);
+        g_rb.feed.acc_floats = 2ull * (unsigned long long)R;
+        g_rb.feed_for = bin.values;
         // GSR_FLAG_NO_SORTED_LISTS: this plan's blend reads the block lists, and no caller of the reference reads
         // BinningState (GSGaussians.cpp:214-219 maps GeometryState only): a forward-only caller may skip the 12 R
         // bytes of sorted keys / values altogether. keys / values are then left unwritten.
         if (a->flags & GSR_FLAG_NO_SORTED_LISTS) {
             g_rb.lists_skipped = bin.values;
-            g_rb.feed = block_feed(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
-            g_rb.feed.acc = reinterpret_cast<float*>(bin.keys);       // (per-entry gradient sums of gsr_backward)
-            g_rb.feed.acc_floats = 2ull * (unsigned long long)R;
             a->plan_used |= GSR_PLAN_LISTS_SKIPPED;
         } else {
             if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));

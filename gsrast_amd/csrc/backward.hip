@@ -58,15 +58,17 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // and atomics to ONE address from all over the chip serialise: on the bench frame that was 0.31 of the kernel's 0.59 ms
 // (timing builds: atomics spread over per-tile or per-block addresses 0.31 ms, no atomics 0.25 ms). With the block feed
 // a record is an ENTRY of its block's list, shared by at most the 64 tiles of the block: the tiles add into nine floats
-// per entry (scratch: the sorted keys' 8 R bytes, unused by such a call), and flush_block_acc_kernel then adds every
+// per entry (scratch: the 8 R bytes of keysUnsorted, dead after the forward call), and flush_block_acc_kernel then adds every
 // entry's sums to its Gaussian's — one lane per entry, different addresses in one instruction, and a Gaussian is hit
 // once per block it touches instead of once per tile. Needs 36 bytes per entry: E <= R / 4.5, else the direct path.
 // Decided per block: the sums of the part of the list that the forward blend looked into (BlockMeta::walked, whole
 // units) are cleared before and flushed after the kernel, which pays where that part is short — at most kAccMaxUnits
-// units; bench frame, 1-2 units per block: render backward 0.59 -> 0.38 ms. A block whose tiles walk deep lists (the
-// frame from outside the cloud: 10 000 entries per tile, small splats, little contention) keeps the direct atomics:
-// with per-entry sums for every block that frame went from 1.26 to 1.38 ms.
-constexpr uint32_t kAccMaxUnits = 4;
+// units; bench frame, 1-2 units per block: render backward 0.59 -> 0.38 ms. A block whose tiles walk deeper lists (the
+// frame from outside the cloud: up to 10 000 entries per tile, small splats, little contention) keeps the direct
+// atomics and, where the forward wrote them, the sorted lists (a plain array of indices is quicker to walk than the
+// block lists): with per-entry sums for every block that frame went from 1.26 to 1.38 ms, with a limit of four units
+// from 1.04 to 1.14 ms, with two it is unchanged.
+constexpr uint32_t kAccMaxUnits = 2;
 __device__ __forceinline__ bool block_acc_fits(const BlockFeed& f, uint32_t b) {
     return f.acc != nullptr && 9ull * (unsigned long long)f.meta.list_start()[f.meta.nbp] <= f.acc_floats &&
            f.meta.walked()[b] <= kAccMaxUnits;
@@ -235,7 +237,10 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
         }
     };
 
-    if (p.point_list) {
+    const BlockFeed& f = p.feed;
+    const uint32_t b = (uint32_t)(ty / kBH) * (uint32_t)f.nbx + (uint32_t)(tx / kBW);
+    per_entry = f.ent_idx != nullptr && block_acc_fits(f, b);
+    if (p.point_list && !per_entry) {
         for (int c = (int)((hi - 1) / kWave); c >= 0; --c) {
             const uint32_t first = (uint32_t)c * kWave;
             const uint32_t cnt = min((uint32_t)kWave, hi - first);
@@ -246,9 +251,6 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
         return;
     }
     // ---- the tile's list read from the block lists, back to front (BlockFeed, blockbin.hpp) ----
-    const BlockFeed& f = p.feed;
-    const uint32_t b = (uint32_t)(ty / kBH) * (uint32_t)f.nbx + (uint32_t)(tx / kBW);
-    per_entry = block_acc_fits(f, b);
     const uint32_t col = (uint32_t)(tx % kBW), row = 8u + (uint32_t)(ty % kBH), t_in_block = (uint32_t)((ty % kBH) * kBW + tx % kBW);
     const uint32_t u0 = f.meta.unit_start()[b], u1 = f.meta.unit_start()[b + 1];
     const uint32_t list0 = f.meta.list_start()[b];
@@ -653,9 +655,12 @@ static int backward_impl(gsr_backward_args* a) {
     const bool inria = (a->flags & GSR_FLAG_SEMANTICS_INRIA) != 0;
     // the upstream profile's chain needs what its colour was computed from
     if (inria && a->dL_dshs && (!a->shs || !a->cam_pos || !a->clamped || !a->means3D)) return GSR_ERR_INVALID_ARG;
-    // the forward call left the sorted lists unwritten (GSR_FLAG_NO_SORTED_LISTS): its block lists are read instead
+    // The forward call ran the block plan: its block lists serve the tiles of shallow blocks (per-entry gradient sums,
+    // see block_acc_fits) and, if it left the sorted lists unwritten (GSR_FLAG_NO_SORTED_LISTS), all tiles.
     BlockFeed feed = {};
     const bool from_blocks = forward_left_block_feed(a->point_list, &feed);
+    const bool lists_written = !forward_skipped_sorted_lists(a->point_list);
+    if (!from_blocks && !lists_written) return GSR_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
     if (profile && !g_bw_ev[0])
@@ -675,7 +680,7 @@ static int backward_impl(gsr_backward_args* a) {
     if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[0], stream));
     RenderBackwardParams r;
     r.ranges = reinterpret_cast<const uint2*>(a->ranges);
-    r.point_list = from_blocks ? nullptr : a->point_list;
+    r.point_list = lists_written ? a->point_list : nullptr;
     r.feed = feed;
     r.means2D = reinterpret_cast<const float2*>(a->means2D);
     r.colors = a->colors;

@@ -35,14 +35,14 @@ struct BlockFeed {
     const uint2* unit_masks;
     const uint32_t* prefix;
     const uint32_t* ent_idx;
-    // scratch for per-entry gradient sums (render backward): the sorted keys' 8 R bytes, which such a call leaves unused
+    // scratch for per-entry gradient sums (render backward): the 8 R bytes of keysUnsorted, dead once the forward call is complete
     float* acc;
     unsigned long long acc_floats;
 };
 BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch);
 
-// The feed of the calling thread's most recent gsr_forward call, if that call ran the block plan with
-// GSR_FLAG_NO_SORTED_LISTS and `point_list` is the (unwritten) values array of its binning chunk.
+// The feed of the calling thread's most recent gsr_forward call, if that call ran the block plan and `point_list` is
+// the values array of its binning chunk (written or, with GSR_FLAG_NO_SORTED_LISTS, not).
 bool forward_left_block_feed(const void* point_list, BlockFeed* out);
 
 // inclusive prefix sum over lanes 0..31 (and, separately, 32..63): row_shr 1, 2, 4, 8 + row_bcast:15

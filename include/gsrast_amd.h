@@ -120,8 +120,7 @@ enum {
  * keys / values, and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
  * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
  * UNWRITTEN, plan_used carries GSR_PLAN_LISTS_SKIPPED, and a gsr_backward call that follows (same thread and
- * device, chunks untouched, `point_list` = that unwritten values array) walks the tile lists out of the block lists
- * (and uses the bytes of BinningState.keys as scratch).
+ * device, chunks untouched, `point_list` = that unwritten values array) walks the tile lists out of the block lists.
  * Pixels, ranges, finalT, nContrib and numRendered are unchanged. Ignored under the other plans, whose blend
  * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
 #define GSR_FLAG_NO_SORTED_LISTS 0x40u
@@ -247,8 +246,10 @@ typedef struct gsr_backward_args {
     const uint32_t* ranges;        /* image chunk */
     const uint32_t* n_contrib;
     const float* final_t;          /* accum_alpha */
-    const uint32_t* point_list;    /* binning chunk: values (left unwritten by a GSR_FLAG_NO_SORTED_LISTS call: the block
-                                      lists in that call's geometry / binning chunks are read instead) */
+    const uint32_t* point_list;    /* binning chunk: values. When this is the values array of the thread's most recent
+                                      gsr_forward call and that call ran the block plan, the block lists it left in its
+                                      chunks are used too (all tiles if GSR_FLAG_NO_SORTED_LISTS left `values` unwritten,
+                                      else the tiles with short lists), and keysUnsorted serves as scratch */
     /* inputs of the forward call that the covariance chain needs again (only with dL_dcov3D) */
     const float* means3D;
     const float* view_matrix;

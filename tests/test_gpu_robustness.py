@@ -228,7 +228,7 @@ def test_forward_only_calls_may_skip_the_sorted_lists():
     # of different tiles land in a different order, so equality is up to what two runs of one path differ by)
     got = r.backward(dl)
     b = r.map_binning_state()
-    assert bool((b["values"] == -1).all())      # still nobody wrote them (the keys' bytes serve the backward as scratch)
+    assert bool((b["keys"] == -1).all()) and bool((b["values"] == -1).all())      # still nobody wrote them
     assert set(ref) <= set(got)
     for k, v in ref.items():
         scale = float(v.abs().max()) + 1e-30
