@@ -171,3 +171,61 @@ def test_backward_rejects_bad_arguments():
     assert L.gsr_backward(C.byref(a)) == _capi.GSR_ERR_INVALID_ARG
     a.struct_size = C.sizeof(_capi.BackwardArgs)
     assert L.gsr_backward(C.byref(a)) == _capi.GSR_ERR_INVALID_ARG and L.gsr_last_error() == _capi.GSR_ERR_INVALID_ARG
+
+
+def _base_sums(r, dl):
+    import torch
+    out = r.backward(dl, with_cov3D=False)
+    return {k: out[k].clone() for k in ("dL_dmean2D", "dL_dconic_opacity", "dL_dcolors")}
+
+
+def _assert_same_sums(got, ref, noise, what):
+    for k, v in ref.items():
+        scale = float(v.abs().max()) + 1e-30
+        err = float((got[k] - v).abs().max())
+        assert err <= max(4.0 * noise[k], 2e-4 * scale), (what, k, err, noise[k], scale)
+        assert float(v.abs().sum()) > 0, (what, k)
+
+
+def test_backward_from_the_block_lists_corner_cases():
+    """The block-list feed of gsr_backward (csrc/blockbin.hpp BlockFeed) where its bookkeeping could go wrong: a second call
+    on the same forward state (per-entry sums cleared again), a call confined to a band of tile rows, a forward state that
+    a later sort-plan call replaced, and a frame of tiny splats under a forced block plan, where the per-entry sums do not
+    fit (E > R / 4.5) and every tile falls back to direct atomics. Reference: the sorted-list path after a sort-plan call."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    W, H = 640, 400
+    dl = torch.from_numpy(np.random.default_rng(11).normal(size=(3, H, W)).astype(np.float32))
+    for name, scene, cam in (
+            ("garden", scenes.garden_like_scene(120_000, seed=43), camera.default_camera(W, H, near=0.05, far=80.0)),
+            ("tiny splats", scenes.stress_scene(400_000, seed=44), camera.default_camera(W, H, near=0.1, far=100.0, position=(0.0, 0.0, -25.0)))):
+        r = SplatRasterizer(W, H, background=(0.3, 0.1, 0.2))
+        r.configure_from_scene(scene)
+        img = r.draw(cam, plan="sort").clone()
+        assert r.last_plan == "sort" and r.last_num_rendered > 0
+        ref = _base_sums(r, dl)
+        again = _base_sums(r, dl)
+        noise = {k: float((again[k] - v).abs().max()) for k, v in ref.items()}
+        # block plan, sorted lists written: shallow blocks take the block lists, twice in a row
+        assert torch.equal(r.draw(cam, plan="blocks"), img) and r.last_plan == "blocks"
+        _assert_same_sums(_base_sums(r, dl), ref, noise, name + ": block plan")
+        _assert_same_sums(_base_sums(r, dl), ref, noise, name + ": block plan, second call")
+        # without the sorted lists
+        r.draw(cam, plan="blocks", sorted_lists=False)
+        assert not r.last_lists_written
+        _assert_same_sums(_base_sums(r, dl), ref, noise, name + ": no sorted lists")
+        # a sort-plan call in between: the block lists of the earlier call must not be used any more
+        r.draw(cam, plan="blocks", sorted_lists=False)
+        r.draw(cam, plan="sort")
+        _assert_same_sums(_base_sums(r, dl), ref, noise, name + ": sort plan after a block-plan call")
+    # a band of tile rows (the sharded call): forward and backward confined to rows [7, 19) of 25
+    r.draw(cam, plan="sort", tile_rows=(7, 19))
+    out = r.backward(dl, with_cov3D=False, tile_rows=(7, 19))
+    ref = {k: out[k].clone() for k in ("dL_dmean2D", "dL_dconic_opacity", "dL_dcolors")}
+    out = r.backward(dl, with_cov3D=False, tile_rows=(7, 19))
+    noise = {k: float((out[k] - v).abs().max()) for k, v in ref.items()}
+    for lists in (True, False):
+        r.draw(cam, plan="blocks", tile_rows=(7, 19), sorted_lists=lists)
+        out = r.backward(dl, with_cov3D=False, tile_rows=(7, 19))
+        _assert_same_sums(out, ref, noise, f"band, sorted lists {lists}")
