@@ -5,7 +5,7 @@ from the three forward states (sorted lists of the sort plan; block plan: block 
 lists; block plan without sorted lists: block lists only): the sums the render backward leaves (dL_dmean2D, dL_dconic_opacity, dL_dcolors) must agree to within a
 small multiple of what two runs of ONE path differ by (float atomics land in a different order every run); the chain
 outputs computed from them are reported.
-Usage: python scripts/soak_r02.py [poses] [bw_every]"""
+Usage: python scripts/soak_r02.py [poses] [bw_every] [width height] [gscuda|inria]"""
 import os
 import sys
 
@@ -17,7 +17,8 @@ from gsrast_amd.rasterizer import SplatRasterizer
 
 poses = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bw_every = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-W, H = 1920, 1080
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+SEM = sys.argv[5] if len(sys.argv) > 5 else "gscuda"
 scene = scenes.garden_like_scene(1_500_000, seed=91)
 span = float(np.max(scene["means3D"][:, :3].max(0) - scene["means3D"][:, :3].min(0)))
 r = SplatRasterizer(W, H, background=(0.1, 0.2, 0.3))
@@ -43,7 +44,7 @@ def same(a, b):
 
 
 def grads():
-    return {k: v.clone() for k, v in r.backward(dl).items() if isinstance(v, torch.Tensor)}
+    return {k: v.clone() for k, v in r.backward(dl, semantics=SEM).items() if isinstance(v, torch.Tensor)}
 
 
 bad = frames = bw_frames = 0
@@ -55,17 +56,17 @@ for i in range(poses):
     cam = camera.first_person_camera(pos, float(rng.uniform(-3.14, 3.14)), float(rng.uniform(-0.8, 0.8)), float(np.radians(45.0)),
                                      0.001 * span, span, W, H, True)
     do_bw = i % bw_every == 0
-    s_sort = frame_state(r.draw(cam, plan="sort", count_staged=True))
+    s_sort = frame_state(r.draw(cam, plan="sort", count_staged=True, semantics=SEM))
     if s_sort[5] == 0:
         continue
     frames += 1
     d_sort = lists_digest()
     g_sort = grads() if do_bw else None
     g_sort2 = grads() if do_bw else None
-    s_blk = frame_state(r.draw(cam, plan="blocks", count_staged=True))
+    s_blk = frame_state(r.draw(cam, plan="blocks", count_staged=True, semantics=SEM))
     d_blk = lists_digest()
     g_blk = grads() if do_bw else None
-    s_nol = frame_state(r.draw(cam, plan="blocks", count_staged=True, sorted_lists=False))
+    s_nol = frame_state(r.draw(cam, plan="blocks", count_staged=True, sorted_lists=False, semantics=SEM))
     assert not r.last_lists_written
     g_nol = grads() if do_bw else None
     ok = same(s_sort, s_blk) and same(s_sort, s_nol) and d_sort == d_blk
