@@ -766,8 +766,11 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
                       const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
-    // two workgroups (8 waves) per CU: 12 or 16 waves per CU measured the same, the write path is the limit
-    const uint32_t emit_wgs = std::min<uint32_t>((t.max_units + kEmitWaves - 1) / kEmitWaves, 256u * 2u);
+    // Workgroups (of four waves) per CU: two where the Gaussians cover many tiles each (long, dense runs: three or four
+    // measured 1.5 % slower on the bench frame and at 4K), four where they cover few (short runs, the waves wait more than
+    // they store: 0.416 -> 0.366 ms from outside the cloud, R / V = 23 against 88 on the bench frame).
+    const uint32_t per_cu = (uint64_t)r_total >= 48ull * (uint64_t)n ? 2u : 4u;
+    const uint32_t emit_wgs = std::min<uint32_t>((t.max_units + kEmitWaves - 1) / kEmitWaves, 256u * per_cu);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, t.meta, t.nb, t.nbx, grid_x, grid_y,
                        ent_rd, ent_idx, t.unit_masks, t.cnt, t.tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");
