@@ -163,11 +163,20 @@ __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_
     __shared__ uint32_t s_tmp[4][256];          // per wave: run starts of the rectangle being expanded
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int g = threadIdx.x;
-    const int r = blockIdx.x * kChunk + g;
+    // Which chunk: workgroup b runs on XCD b % 8. Consecutive chunks write adjacent pieces of every column's run (a few
+    // keys each when the splats are small), so 32 consecutive chunks go to ONE XCD: the pieces of a line then meet in
+    // that XCD's L2 and leave as whole lines instead of as one partial write per chunk.
+    int chunk = (int)blockIdx.x;
+    {
+        constexpr int kPer = 32, kGroupChunks = 8 * kPer;          // (8 / 32 / 128 chunks in a row: 1.24 / 1.20 / 1.19 ms at 50 M, 1.48 before)
+        const int group0 = chunk / kGroupChunks * kGroupChunks;
+        if (group0 + kGroupChunks <= (int)gridDim.x) chunk = group0 + ((chunk - group0) % 8) * kPer + (chunk - group0) / 8;
+    }
+    const int r = chunk * kChunk + g;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
     if (__syncthreads_or(rect != 0u) == 0) return;              // culled tail of the depth order
     s_rect[g] = rect;
-    s_col[g] = (g < stride) ? table[(size_t)blockIdx.x * stride + g] : 0u;
+    s_col[g] = (g < stride) ? table[(size_t)chunk * stride + g] : 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         s_mask[g][k] = 0;
