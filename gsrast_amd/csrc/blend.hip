@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
 
-    const int tile_local = tile_of_workgroup((int)blockIdx.x);
+    const int tile_local = tile_of_workgroup((int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    if (tile_local < 0) return;
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
@@ -128,7 +129,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     p.dims = d;
     p.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
     if (p.num_tiles <= 0) return GSR_OK;
-    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)p.num_tiles), dim3(kWave), 0, stream, p);
+    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)patch_workgroups(d.grid_x, d.row_end - d.row_begin)), dim3(kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;
 }

@@ -231,10 +231,26 @@ __device__ __forceinline__ void tile_lanes_write(const TileLanes& s, int width, 
     }
 }
 
-// Tile of a workgroup: tiles are dealt to workgroups in tile order, so the eight XCDs (workgroups b and b + 8 share
-// one) each get every eighth tile. Giving every XCD one contiguous run of tiles instead (so that neighbouring
-// tiles gather their Gaussians through one L2) measured 6-23 % SLOWER: the image's busy rows then land on two or
-// three XCDs while the others idle (headline frame 0.31 vs 0.29 ms, pose outside the cloud 6.3 vs 5.4 ms).
-__device__ __forceinline__ int tile_of_workgroup(int b) { return b; }
+// Tile of a workgroup. Workgroup b runs on XCD b % 8, and each XCD has its own L2. Tiles dealt in tile order put every
+// eighth tile on an XCD: perfectly level, but the eight neighbours of a tile — which gather largely the same Gaussians —
+// are on the seven other L2s. Giving every XCD one contiguous eighth of the image measured 6-23 % SLOWER (the image's
+// busy rows land on two or three XCDs while the others idle). In between: 64 consecutive workgroups are eight patches
+// of 4 x 2 tiles, one patch per XCD. Measured against tile order (same box, `r02_blend_exp13-14.txt`): bench frame 0.117 ->
+// 0.116 ms, from outside the cloud 0.668 -> 0.663 ms, the blend-bound frame 2.06 -> 1.95 ms. Larger patches trade the short
+// frames for the long ones (4 x 4: 0.116 -> 0.121 ms and 2.03 -> 1.79 ms; 8 x 4: 0.117 -> 0.120 ms and 2.06 -> 1.73 ms).
+constexpr int kPatchW = 4, kPatchH = 2, kPatchTiles = kPatchW * kPatchH;
+// workgroups to launch for a band of `rows` tile rows (the patch grid is padded to whole groups of eight patches)
+__host__ __device__ inline int patch_workgroups(int grid_x, int rows) {
+    const int patches = ((grid_x + kPatchW - 1) / kPatchW) * ((rows + kPatchH - 1) / kPatchH);
+    return (patches + 7) / 8 * 8 * kPatchTiles;
+}
+// tile (relative to the band) of workgroup b, or -1 if b falls into the padding
+__device__ __forceinline__ int tile_of_workgroup(int b, int grid_x, int rows) {
+    const int group = b / (8 * kPatchTiles), within = b % (8 * kPatchTiles);
+    const int patch = group * 8 + within % 8, j = within / 8;
+    const int ppr = (grid_x + kPatchW - 1) / kPatchW;
+    const int tx = (patch % ppr) * kPatchW + j % kPatchW, ty = (patch / ppr) * kPatchH + j / kPatchW;
+    return (tx < grid_x && ty < rows) ? ty * grid_x + tx : -1;
+}
 
 }  // namespace gsr

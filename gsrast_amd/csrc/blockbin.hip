@@ -575,7 +575,8 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
     const int wpt = p.waves_per_tile;
-    const int tile_local = tile_of_workgroup((int)blockIdx.x / wpt);
+    const int tile_local = tile_of_workgroup((int)blockIdx.x / wpt, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    if (tile_local < 0) return;
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
@@ -805,7 +806,8 @@ int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_s
     // tile: four waves per tile then, one 16 x 4 strip each. (Not when the staged records are counted:
     // that count is per tile, the reference's "whole tile done" test.)
     p.waves_per_tile = (p.num_tiles <= 1536 && !staged_counter) ? 4 : 1;     // (measured: 960 tiles 0.17 -> 0.13 ms, 4080 tiles 0.16 -> 0.29 ms)
-    hipLaunchKernelGGL(blend_blocks_kernel, dim3((unsigned)(p.num_tiles * p.waves_per_tile)), dim3(kWave), 0, stream, p);
+    hipLaunchKernelGGL(blend_blocks_kernel, dim3((unsigned)(patch_workgroups(d.grid_x, d.row_end - d.row_begin) * p.waves_per_tile)),
+                       dim3(kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_blocks_kernel");
     return GSR_OK;
 }
