@@ -121,7 +121,10 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
 
-    const int tile = p.dims.row_begin * p.dims.grid_x + (int)blockIdx.x;
+    // (tiles dealt to the XCDs in patches, as in the forward blend: blend_core.hpp)
+    const int tile_local = tile_of_workgroup((int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    if (tile_local < 0) return;
+    const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
     const int px = tx * kTile + (lane & 15), py0 = ty * kTile + (lane >> 4);
@@ -711,7 +714,7 @@ static int backward_impl(gsr_backward_args* a) {
             hipLaunchKernelGGL(zero_block_acc_kernel, dim3(acc_wgs), dim3(256), 0, stream, feed);
             GSR_LAUNCH_CHECK("zero_block_acc_kernel");
         }
-        hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)r.num_tiles), dim3(kWave), 0, stream, r);
+        hipLaunchKernelGGL(render_backward_kernel, dim3((unsigned)patch_workgroups(d.grid_x, d.row_end - d.row_begin)), dim3(kWave), 0, stream, r);
         GSR_LAUNCH_CHECK("render_backward_kernel");
         if (from_blocks && feed.acc) {
             hipLaunchKernelGGL(flush_block_acc_kernel, dim3(acc_wgs), dim3(256), 0, stream, feed, a->dL_dmean2D, a->dL_dconic_opacity,
