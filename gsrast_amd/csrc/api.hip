@@ -101,7 +101,8 @@ BinScratch carve_bin_scratch(char* base, size_t r) {
 // Pinned landing zone for the numRendered read-back plus the events / side stream of a call: one per host
 // thread AND device (events and streams belong to the device that was current when they were created).
 struct Readback {
-    uint32_t* host = nullptr;          // [0] numRendered, [1] / [2] onesweep error words, [3] top digits, [4] V,
+    uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
+    uint32_t* host = nullptr;          // [0] unused, [1] / [2] onesweep error words (written by the kernels themselves), [3] top digits, [4] V,
                                        // [5..6] u64 un-wrapped instance count, [8..9] staged count
     const void* lists_skipped = nullptr;   // `values` of the last call made with GSR_FLAG_NO_SORTED_LISTS under the block plan
     const void* feed_for = nullptr;        // `values` of the last call that ran the block plan ...
@@ -126,7 +127,8 @@ struct Readback {
     }
     int ensure() {
         if (!host) {
-            GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocDefault));
+            GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocMapped));
+            GSR_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), host, 0));
             staged_host = reinterpret_cast<unsigned long long*>(host + 8);
         }
         if (!ev_r) GSR_HIP_TRY(hipEventCreateWithFlags(&ev_r, hipEventDisableTiming));
@@ -353,7 +355,10 @@ int gsr_forward(gsr_forward_args* a) {
     // one clear for the four passes' look-back words, tickets, the error word and the digit histograms
     // (the four scratch areas are adjacent in the chunk)
     GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, 4 * sweep_scratch_bytes((size_t)n), stream));
-    const SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
+    SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
+    // "a bounded look-back spin gave up" is written by the kernel straight into the pinned host words (it never
+    // happens on a healthy device; a copy at the end of every frame for it cost 5 us of stream time)
+    for (auto& f : four) f.error_word = g_rb.host_dev + 1;
     // Only Gaussians with at least one tile in this call take part from here on (V of N: 52 % on the
     // bench frame, a few per cent per rank when the frame is sharded): their (depth key, index) pairs
     // are compacted in index order — the same kernels count the digits of the four sort passes.
@@ -362,7 +367,7 @@ int gsr_forward(gsr_forward_args* a) {
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
     // move nothing.
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host, geom.point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    // (one copy: numRendered is the low word of the un-wrapped instance count that comes with them)
     GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.sort_info, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
@@ -381,7 +386,7 @@ int gsr_forward(gsr_forward_args* a) {
     uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k;
     uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v;
     uint32_t* const spare_k = four_passes ? gs.a_k : gs.b_k;
-    const uint32_t R = *g_rb.host;
+    const uint32_t R = (uint32_t)true_total;               // (= pointOffsets[N - 1], GSCuda.cu:772)
     a->num_rendered = R;
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
     if (R == 0) {
@@ -465,7 +470,9 @@ int gsr_forward(gsr_forward_args* a) {
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
         uint32_t* rect_packed = spare_k;
-        if (d.grid_y > 1) GSR_STEP(sweep_clear(bs.sweep, R, (uint32_t)d.grid_y, stream));
+        SweepScratch bsw = bs.sweep;
+        bsw.error_word = g_rb.host_dev + 2;
+        if (d.grid_y > 1) GSR_STEP(sweep_clear(bsw, R, (uint32_t)d.grid_y, stream));
         // one pass: with a single tile row the column-major list is already the sorted list
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
         uint32_t* emit_v = d.grid_y > 1 ? bin.values_unsorted : bin.values;
@@ -483,7 +490,7 @@ int gsr_forward(gsr_forward_args* a) {
             sy.mode = kDigitTileY; sy.shift = 0; sy.nbins = (uint32_t)d.grid_y; sy.grid_x = (uint32_t)d.grid_x;
             sy.inv_grid_x = 1.0f / (float)d.grid_x;
             GSR_BEGIN(GSR_STAGE_SORT_PASS2);
-            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, sy, hist_y, bs.sweep, stream, true));
+            GSR_STEP(sweep_pass_u64(bin.keys_unsorted, bin.values_unsorted, bin.keys, bin.values, R, sy, hist_y, bsw, stream, true));
             GSR_END(GSR_STAGE_SORT_PASS2);
         } else {
             // keep the "unsorted" arrays populated as the reference does
@@ -501,7 +508,7 @@ int gsr_forward(gsr_forward_args* a) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
         GSR_BEGIN(GSR_STAGE_SORT_PASS2);
         GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, 32, end_bit,
-                                   bin.sorting_space, stream));
+                                   bin.sorting_space, stream, g_rb.host_dev + 2));
         GSR_END(GSR_STAGE_SORT_PASS2);
     }
     // :800-801 — under the block plan the ranges are the tile starts it has already computed
@@ -524,9 +531,6 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_END(GSR_STAGE_BLEND);
     if (forked) GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));      // the sorted lists are complete too
 
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 1, gs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    if (!use_blocks)
-        GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 2, bs.sweep.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     if (profile || count_staged) {
         if (count_staged)
             GSR_HIP_TRY(hipMemcpyAsync(g_rb.staged_host, g_rb.staged_dev, sizeof(unsigned long long),

@@ -64,7 +64,7 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
                      uint64_t* keys, uint32_t* values, uint32_t* hist_x, uint32_t* hist_y, hipStream_t stream);
 
 int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
-                      uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream);
+                      uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word = nullptr);
 size_t sort_temp_bytes(size_t n);
 struct SweepScratch;
 // Depth order (radix_sort.hip). sc4: one scratch area per pass, already zeroed by the caller (look-back words,

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
             const uint32_t used = lb.consume(lane);
             if (lb.found) break;
             if (used == 0) {
-                if (++lb.spins > kSpinLimit) { s_fail = 1; atomicExch(error_word, 1u); break; }
+                if (++lb.spins > kSpinLimit) { s_fail = 1; *reinterpret_cast<volatile uint32_t*>(error_word) = 1u; break; }      // (may be host memory)
                 __builtin_amdgcn_s_sleep(1);
             }
             lb.issue(status);
@@ -609,7 +609,7 @@ size_t sort_temp_bytes(size_t n) {
 }
 
 int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in, uint32_t* values_out,
-                      size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream) {
+                      size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word) {
     if (n == 0) return GSR_OK;
     if (n >= 0xFFFFFFFFull) return GSR_ERR_TOO_LARGE;
     if (end_bit > 64) end_bit = 64;
@@ -618,8 +618,9 @@ int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_
     const int passes = (end_bit - begin_bit + 7) / 8;
     uint64_t* tmp_k = reinterpret_cast<uint64_t*>(temp);
     uint32_t* tmp_v = reinterpret_cast<uint32_t*>(temp + align_up(n * sizeof(uint64_t), 128));
-    const SweepScratch sc = carve_sweep_scratch(temp + align_up(n * sizeof(uint64_t), 128) + align_up(n * sizeof(uint32_t), 128), n);
-    GSR_HIP_TRY(hipMemsetAsync(sc.error_word, 0, sizeof(uint32_t), stream));
+    SweepScratch sc = carve_sweep_scratch(temp + align_up(n * sizeof(uint64_t), 128) + align_up(n * sizeof(uint32_t), 128), n);
+    if (error_word) sc.error_word = error_word;          // (the caller's word, cleared by the caller; may be host memory)
+    else GSR_HIP_TRY(hipMemsetAsync(sc.error_word, 0, sizeof(uint32_t), stream));
     int rc = histogram_bits_u64(keys_in, n, begin_bit, end_bit, sc.hist, stream);
     if (rc != GSR_OK) return rc;
     const uint64_t* src_k = keys_in;
