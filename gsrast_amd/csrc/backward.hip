@@ -54,6 +54,38 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// Sums of NINE per-lane values over the 64 lanes in about half the steps of nine separate reductions: v_permlane32_swap
+// and v_permlane16_swap (gfx950) fold the lanes while packing the values side by side — after the first fold a register
+// holds value 2i in its lower 32 lanes and value 2i + 1 in its upper ones, after the second a row of 16 lanes per value —
+// then one select + row_ror:8 packs two registers into one and three quad / half-row steps finish. On return lane
+// 0 / 32 / 16 / 48 / 8 / 40 / 24 / 56 holds the total of value 0 / 1 / ... / 7 and lane 63 that of value 8.
+__device__ __forceinline__ float wave_sum9(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+    const int lane = threadIdx.x & (kWave - 1);
+    auto swap32 = [](float& x, float& y) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+    };
+    auto swap16 = [](float& x, float& y) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+    };
+#define GSR_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    swap32(a0, a1); float p = a0 + a1;           // rows 0, 1: value 0 (lanes l and l + 32 added); rows 2, 3: value 1
+    swap32(a2, a3); float q = a2 + a3;
+    swap32(a4, a5); float r = a4 + a5;
+    swap32(a6, a7); float t = a6 + a7;
+    swap16(p, q); const float t0 = p + q;        // rows: value 0, 2, 1, 3, each added over the four 16-lane groups
+    swap16(r, t); const float t1 = r + t;        // rows: value 4, 6, 5, 7
+    const bool upper = (lane & 8) != 0;
+    float u = (upper ? t1 : t0) + GSR_DPP(upper ? t0 : t1, 0x128);      // row_ror:8: lanes 0-7 of a row now carry t0, lanes 8-15 t1
+    u += GSR_DPP(u, 0xB1);                       // quad_perm [1,0,3,2]
+    u += GSR_DPP(u, 0x4E);                       // quad_perm [2,3,0,1]
+    u += GSR_DPP(u, 0x141);                      // row_half_mirror
+#undef GSR_DPP
+    const float v = wave_sum_to_lane63(a8);
+    return lane == kWave - 1 ? v : u;
+}
+
 // Per-entry sums (block feed). A Gaussian that covers hundreds of tiles receives its nine sums from every one of them,
 // and atomics to ONE address from all over the chip serialise: on the bench frame that was 0.31 of the kernel's 0.59 ms
 // (timing builds: atomics spread over per-tile or per-block addresses 0.31 ms, no atomics 0.25 ms). With the block feed
@@ -159,6 +191,12 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     // One batch of up to 64 list entries, lane l holding the entry at 0-based list position idx_l (descending batches,
     // ascending lanes): as in the forward blend (blend_core.hpp) most records of a tile's list cannot light any of its
     // pixels; they are dropped here, one lane per record, instead of being walked by the whole wave.
+    // Which of a record's nine sums this lane files (wave_sum9 leaves them in lanes 0, 8, ..., 56 and 63), and where:
+    // one atomic instruction with nine lanes instead of nine instructions with one.
+    constexpr int kSumOfRow[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    const int my_sum = lane == kWave - 1 ? 8 : ((lane & 7) == 0 ? kSumOfRow[lane >> 3] : -1);
+    float* direct_base = my_sum < 2 ? p.dL_dmean2D + my_sum : (my_sum < 6 ? p.dL_dconic_opacity + (my_sum - 2) : p.dL_dcolors + (my_sum - 6));
+    const uint32_t direct_stride = my_sum < 2 ? 2u : (my_sum < 6 ? 4u : 3u);
     // `key` is what the record's sums are filed under: the Gaussian's index, or (block feed with room for per-entry
     // sums, see below) the record's entry number in the block lists.
     bool per_entry = false;
@@ -216,26 +254,11 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
                 a_my += (-co.z * dy - co.y * dx) * dpow;
             }
             if (__ballot(any) == 0ull) continue;
-            a_mx = wave_sum_to_lane63(a_mx); a_my = wave_sum_to_lane63(a_my);
-            a_A = wave_sum_to_lane63(a_A); a_B = wave_sum_to_lane63(a_B); a_C = wave_sum_to_lane63(a_C);
-            a_op = wave_sum_to_lane63(a_op);
-            a_r = wave_sum_to_lane63(a_r); a_g = wave_sum_to_lane63(a_g); a_b = wave_sum_to_lane63(a_b);
-            if (lane == kWave - 1 && per_entry) {
-                float* acc = p.feed.acc + 9 * (size_t)s_id[j];
-                unsafeAtomicAdd(acc + 0, a_mx); unsafeAtomicAdd(acc + 1, a_my);
-                unsafeAtomicAdd(acc + 2, a_A); unsafeAtomicAdd(acc + 3, a_B); unsafeAtomicAdd(acc + 4, a_C); unsafeAtomicAdd(acc + 5, a_op);
-                unsafeAtomicAdd(acc + 6, a_r); unsafeAtomicAdd(acc + 7, a_g); unsafeAtomicAdd(acc + 8, a_b);
-            } else if (lane == kWave - 1) {
-                const size_t id = s_id[j];
-                unsafeAtomicAdd(p.dL_dmean2D + 2 * id, a_mx);
-                unsafeAtomicAdd(p.dL_dmean2D + 2 * id + 1, a_my);
-                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id, a_A);
-                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id + 1, a_B);
-                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id + 2, a_C);
-                unsafeAtomicAdd(p.dL_dconic_opacity + 4 * id + 3, a_op);
-                unsafeAtomicAdd(p.dL_dcolors + 3 * id, a_r);
-                unsafeAtomicAdd(p.dL_dcolors + 3 * id + 1, a_g);
-                unsafeAtomicAdd(p.dL_dcolors + 3 * id + 2, a_b);
+            const float total = wave_sum9(a_mx, a_my, a_A, a_B, a_C, a_op, a_r, a_g, a_b);
+            if (my_sum >= 0) {
+                const size_t key = s_id[j];
+                float* dst = per_entry ? p.feed.acc + 9 * key + my_sum : direct_base + direct_stride * key;
+                unsafeAtomicAdd(dst, total);
             }
         }
     };
