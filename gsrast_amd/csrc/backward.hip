@@ -200,13 +200,8 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     // `key` is what the record's sums are filed under: the Gaussian's index, or (block feed with room for per-entry
     // sums, see below) the record's entry number in the block lists.
     bool per_entry = false;
-    auto walk_batch = [&](const bool present, const uint32_t id, const uint32_t idx_l, const uint32_t key) {
-        float2 xy_l = make_float2(0.0f, 0.0f);
-        float4 co_l = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (present) {
-            xy_l = p.means2D[id];
-            co_l = p.conic_opacity[id];
-        }
+    auto walk_batch = [&](const bool present, const uint32_t id, const uint32_t idx_l, const uint32_t key, const float2 xy_l,
+                          const float4 co_l) {
         const bool keep = present && !record_misses_tile(xy_l, co_l, box);
         const unsigned long long kept_mask = __ballot(keep);
         if (keep) {
@@ -263,51 +258,89 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
         }
     };
 
+    // The batches come from one of two iterators, back to front — the sorted list (a plain array), or the block lists
+    // (BlockFeed, blockbin.hpp) — and pass two stations before they are walked, one loop iteration apart, as in the forward
+    // blend: ids two batches ahead, records one batch ahead (loads unconditional: lanes without an entry read Gaussian 0).
+    struct Batch {
+        bool valid = false, present = false;
+        uint32_t id = 0, idx_l = 0, key = 0;
+        float2 xy = {0.0f, 0.0f};
+        float4 co = {0.0f, 0.0f, 0.0f, 0.0f};
+    };
     const BlockFeed& f = p.feed;
     const uint32_t b = (uint32_t)(ty / kBH) * (uint32_t)f.nbx + (uint32_t)(tx / kBW);
     per_entry = f.ent_idx != nullptr && block_acc_fits(f, b);
-    if (p.point_list && !per_entry) {
-        for (int c = (int)((hi - 1) / kWave); c >= 0; --c) {
-            const uint32_t first = (uint32_t)c * kWave;
-            const uint32_t cnt = min((uint32_t)kWave, hi - first);
-            const bool present = (uint32_t)lane < cnt;
-            const uint32_t id = present ? p.point_list[range.x + first + (uint32_t)lane] : 0u;
-            walk_batch(present, id, first + (uint32_t)lane, id);
-        }
-        return;
-    }
-    // ---- the tile's list read from the block lists, back to front (BlockFeed, blockbin.hpp) ----
+    const bool sorted = p.point_list && !per_entry;
+    // -- sorted list: batch c = list positions [64 c, 64 c + 64) below hi
+    int it_c = (int)((hi - 1) / kWave);
+    // -- block lists: unit it_u of the block, its batches still to come in it_nz (highest first)
     const uint32_t col = (uint32_t)(tx % kBW), row = 8u + (uint32_t)(ty % kBH), t_in_block = (uint32_t)((ty % kBH) * kBW + tx % kBW);
-    const uint32_t u0 = f.meta.unit_start()[b], u1 = f.meta.unit_start()[b + 1];
-    const uint32_t list0 = f.meta.list_start()[b];
-    // the last unit whose first entry of this tile lies in front of position hi
-    uint32_t below = 0;
-    for (uint32_t k = u0; k < u1; k += kWave) {
-        const uint32_t u = k + (uint32_t)lane;
-        below += (uint32_t)__popcll(__ballot(u < u1 && f.prefix[(size_t)u * 64 + t_in_block] < hi));
-    }
-    if (below == 0u) return;                   // (cannot happen: the first unit's prefix is 0 < hi)
-    for (uint32_t u = u0 + below; u-- > u0;) {
-        const uint32_t base = f.prefix[(size_t)u * 64 + t_in_block];
-        const uint2* um = f.unit_masks + (size_t)u * 16 * kBatches + (lane & (kBatches - 1));
-        const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
-        const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
-        const uint32_t c = (uint32_t)__popc(tm_lo) + (uint32_t)__popc(tm_hi);
-        const uint32_t start_v = base + prefix32_inclusive(c) - c;      // lane w < 32: list position of batch w's first entry
-        uint32_t nz = (uint32_t)__ballot(c != 0u && start_v < hi);       // batches with an entry in front of hi
-        while (nz != 0u) {
-            const int w = 31 - __builtin_clz(nz);                        // (wave-uniform: nz comes from a ballot)
-            nz &= ~(1u << w);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
-            const uint32_t hi_m = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
-            const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)start_v, w);
-            const unsigned long long mask = ((unsigned long long)hi_m << 32) | lo;
-            const uint32_t idx_l = start + __builtin_amdgcn_mbcnt_hi(hi_m, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-            const bool present = __builtin_amdgcn_inverse_ballot_w64(mask) && idx_l < hi;
-            const uint32_t e = list0 + (u - u0) * kUnit + (uint32_t)w * kWave + (uint32_t)lane;
-            const uint32_t id = present ? f.ent_idx[e] : 0u;
-            walk_batch(present, id, idx_l, per_entry ? e : id);
+    uint32_t u0 = 0, list0 = 0, it_u = 0, it_nz = 0, tm_lo = 0, tm_hi = 0, start_v = 0;
+    if (!sorted) {
+        u0 = f.meta.unit_start()[b];
+        const uint32_t u1 = f.meta.unit_start()[b + 1];
+        list0 = f.meta.list_start()[b];
+        // the last unit whose first entry of this tile lies in front of position hi
+        uint32_t below = 0;
+        for (uint32_t k = u0; k < u1; k += kWave) {
+            const uint32_t u = k + (uint32_t)lane;
+            below += (uint32_t)__popcll(__ballot(u < u1 && f.prefix[(size_t)u * 64 + t_in_block] < hi));
         }
+        it_u = u0 + below;                     // (units [u0, it_u) to come, last first)
+    }
+    auto next_batch = [&]() {
+        Batch nb;
+        if (sorted) {
+            if (it_c < 0) return nb;
+            const uint32_t first = (uint32_t)it_c * kWave;
+            --it_c;
+            nb.valid = true;
+            nb.present = (uint32_t)lane < min((uint32_t)kWave, hi - first);
+            nb.idx_l = first + (uint32_t)lane;
+            nb.id = p.point_list[range.x + (nb.present ? nb.idx_l : 0u)];
+            nb.key = nb.id;
+            return nb;
+        }
+        while (it_nz == 0u) {
+            if (it_u == u0) return nb;
+            --it_u;
+            const uint32_t base = f.prefix[(size_t)it_u * 64 + t_in_block];
+            const uint2* um = f.unit_masks + (size_t)it_u * 16 * kBatches + (lane & (kBatches - 1));
+            const uint2 xm = um[col * kBatches], ym = um[row * kBatches];
+            tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u;
+            tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
+            const uint32_t c = (uint32_t)__popc(tm_lo) + (uint32_t)__popc(tm_hi);
+            start_v = base + prefix32_inclusive(c) - c;                  // lane w < 32: list position of batch w's first entry
+            it_nz = (uint32_t)__ballot(c != 0u && start_v < hi);          // batches with an entry in front of hi
+        }
+        const int w = 31 - __builtin_clz(it_nz);                          // (wave-uniform: it_nz comes from a ballot)
+        it_nz &= ~(1u << w);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tm_lo, w);
+        const uint32_t hi_m = (uint32_t)__builtin_amdgcn_readlane((int)tm_hi, w);
+        const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)start_v, w);
+        const unsigned long long mask = ((unsigned long long)hi_m << 32) | lo;
+        nb.valid = true;
+        nb.idx_l = start + __builtin_amdgcn_mbcnt_hi(hi_m, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        nb.present = __builtin_amdgcn_inverse_ballot_w64(mask) && nb.idx_l < hi;
+        const uint32_t e = list0 + (it_u - u0) * kUnit + (uint32_t)w * kWave + (uint32_t)lane;
+        nb.id = f.ent_idx[nb.present ? e : list0];
+        nb.key = per_entry ? e : nb.id;
+        return nb;
+    };
+    auto fetch = [&](Batch& nb) {
+        const uint32_t at = (nb.valid && nb.present) ? nb.id : 0u;
+        nb.xy = p.means2D[at];
+        nb.co = p.conic_opacity[at];
+    };
+    Batch b0 = next_batch();
+    fetch(b0);
+    Batch b1 = next_batch();
+    while (b0.valid) {
+        fetch(b1);
+        Batch b2 = next_batch();
+        walk_batch(b0.present, b0.id, b0.idx_l, b0.key, b0.xy, b0.co);
+        b0 = b1;
+        b1 = b2;
     }
 }
 
