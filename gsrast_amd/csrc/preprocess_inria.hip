@@ -234,24 +234,26 @@ __global__ __launch_bounds__(256) void preprocess_inria_kernel(const InriaParams
     }
     if (!valid) return;
 
-    // ---- stores from here on ----
+    // ---- stores from here on ---- (the records as streaming stores, as in preprocess.hip)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (in_front && !p.cov3D_precomp) {
-        float2* dst = reinterpret_cast<float2*>(p.cov3Ds + 6 * (size_t)idx);
-        dst[0] = make_float2(c3[0], c3[1]);
-        dst[1] = make_float2(c3[2], c3[3]);
-        dst[2] = make_float2(c3[4], c3[5]);
+        f32x2* dst = reinterpret_cast<f32x2*>(p.cov3Ds + 6 * (size_t)idx);
+        __builtin_nontemporal_store((f32x2){c3[0], c3[1]}, dst);
+        __builtin_nontemporal_store((f32x2){c3[2], c3[3]}, dst + 1);
+        __builtin_nontemporal_store((f32x2){c3[4], c3[5]}, dst + 2);
     }
     if (has_tile) {
         if (want_sh) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) p.clamped[3 * (size_t)idx + c] = neg[c];
             float* o = p.rgb + 3 * (size_t)idx;
-            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+            __builtin_nontemporal_store(res[0], o); __builtin_nontemporal_store(res[1], o + 1); __builtin_nontemporal_store(res[2], o + 2);
         }
         const int y0 = clampi(fy0, p.dims.row_begin, p.dims.row_end), y1 = clampi(fy1, p.dims.row_begin, p.dims.row_end);
-        p.depths[idx] = pvz;
-        p.means2D[idx] = make_float2(pix, piy);
-        p.conic_opacity[idx] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacity);
+        __builtin_nontemporal_store(pvz, p.depths + idx);
+        __builtin_nontemporal_store((f32x2){pix, piy}, reinterpret_cast<f32x2*>(p.means2D + idx));
+        __builtin_nontemporal_store((f32x4){cc * det_inv, -cb * det_inv, ca * det_inv, opacity}, reinterpret_cast<f32x4*>(p.conic_opacity + idx));
         out_radius = ri;
         out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
         view_z = pvz;
