@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     const float one_over_w = 1.0f / (0.001f + ph.w);
     const float prx = one_over_w * ph.x, pry = one_over_w * ph.y, prz = one_over_w * ph.z;
     const bool in_frustum = !(prz < 0.0f || prz > 1.0f || prx < -1.3f || prx > 1.3f || pry < -1.3f || pry > 1.3f);
+    // what the stores at the end write (zeros where the reference writes nothing: see there)
+    float o_c3[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, o_rgb[3] = {0.0f, 0.0f, 0.0f}, o_pix = 0.0f, o_piy = 0.0f, o_depth = 0.0f;
+    float o_co[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int o_ex = 0, o_ey = 0;
     if (in_frustum) {
         // ---- every remaining load of this Gaussian ----
         float c3[6];
@@ -206,35 +210,49 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
             }
         }
 
-        // ---- stores from here on ---- (the per-Gaussian records leave as streaming stores: 0.46 GB that the blend reads
-        // a few per cent of, much later — written through the L2 they cost the kernel 7 %: 0.357 -> 0.333 ms; what the
-        // next kernels read at once — radii, tilesTouched, depth keys, packed rectangles — stays cached)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        typedef int i32x2 __attribute__((ext_vector_type(2)));
-        if (!p.cov3D_precomp) {
-            f32x2* dst = reinterpret_cast<f32x2*>(p.cov3Ds + 6 * (size_t)idx);
-            __builtin_nontemporal_store((f32x2){c3[0], c3[1]}, dst);
-            __builtin_nontemporal_store((f32x2){c3[2], c3[3]}, dst + 1);
-            __builtin_nontemporal_store((f32x2){c3[4], c3[5]}, dst + 2);
-        }
+        // ---- what this Gaussian stores (GSCuda.cu:189-194 cov3D for every Gaussian inside the frustum, :353 rects once det != 0,
+        // :362-374 the rest once it has a tile) ----
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o_c3[i] = c3[i];
         if (det != 0.0f) {
-            if (p.rects) __builtin_nontemporal_store((i32x2){ex, ey}, reinterpret_cast<i32x2*>(p.rects + idx));
+            o_ex = ex; o_ey = ey;
             if (band_area != 0) {
-                if (!p.colors_precomp) {
-                    float* o = p.rgb + 3 * (size_t)idx;
-                    __builtin_nontemporal_store(0.5f + 0.4f * dc0, o);
-                    __builtin_nontemporal_store(0.5f + 0.4f * dc1, o + 1);
-                    __builtin_nontemporal_store(0.5f + 0.4f * dc2, o + 2);
-                }
-                __builtin_nontemporal_store(prz, p.depths + idx);
-                __builtin_nontemporal_store((f32x2){pix, piy}, reinterpret_cast<f32x2*>(p.means2D + idx));
-                __builtin_nontemporal_store((f32x4){cc * det_inv, -cb * det_inv, ca * det_inv, opacity}, reinterpret_cast<f32x4*>(p.conic_opacity + idx));
+                o_rgb[0] = 0.5f + 0.4f * dc0; o_rgb[1] = 0.5f + 0.4f * dc1; o_rgb[2] = 0.5f + 0.4f * dc2;
+                o_depth = prz;
+                o_pix = pix; o_piy = piy;
+                o_co[0] = cc * det_inv; o_co[1] = -cb * det_inv; o_co[2] = ca * det_inv; o_co[3] = opacity;
                 out_radius = (int)my_radius;
                 out_tiles = band_area;
                 out_rect = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y1 - y0) << 24);
             }
         }
+    }
+    // ---- stores from here on ----
+    // EVERY Gaussian stores every record, zeros where the reference stores nothing (it leaves those entries of its chunk
+    // as they were; nothing reads them: a culled Gaussian is in no list). A store that skips half the lanes of a wave
+    // leaves half-written lines, and a partial line costs the memory a read-modify-write: with the stores under the
+    // visibility tests this kernel took 0.33 ms on the bench frame and 2.8 ms at 50 M, with whole lines 0.25 and 2.4 ms
+    // (`gpurun_out/r02_pp_exp10.txt`) — for MORE bytes written. The records leave as streaming stores (0.46 GB that the
+    // blend reads a few per cent of, much later: 0.357 -> 0.333 ms before this); what the next kernels read at once —
+    // radii, tilesTouched, depth keys, packed rectangles — stays cached.
+    {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        if (!p.cov3D_precomp) {
+            f32x2* dst = reinterpret_cast<f32x2*>(p.cov3Ds + 6 * (size_t)idx);
+            __builtin_nontemporal_store((f32x2){o_c3[0], o_c3[1]}, dst);
+            __builtin_nontemporal_store((f32x2){o_c3[2], o_c3[3]}, dst + 1);
+            __builtin_nontemporal_store((f32x2){o_c3[4], o_c3[5]}, dst + 2);
+        }
+        if (p.rects) __builtin_nontemporal_store((i32x2){o_ex, o_ey}, reinterpret_cast<i32x2*>(p.rects + idx));
+        if (!p.colors_precomp) {
+            float* o = p.rgb + 3 * (size_t)idx;
+            __builtin_nontemporal_store(o_rgb[0], o); __builtin_nontemporal_store(o_rgb[1], o + 1); __builtin_nontemporal_store(o_rgb[2], o + 2);
+        }
+        __builtin_nontemporal_store(o_depth, p.depths + idx);
+        __builtin_nontemporal_store((f32x2){o_pix, o_piy}, reinterpret_cast<f32x2*>(p.means2D + idx));
+        __builtin_nontemporal_store((f32x4){o_co[0], o_co[1], o_co[2], o_co[3]}, reinterpret_cast<f32x4*>(p.conic_opacity + idx));
     }
     p.radii[idx] = out_radius;
     p.tiles_touched[idx] = out_tiles;

@@ -234,26 +234,31 @@ __global__ __launch_bounds__(256) void preprocess_inria_kernel(const InriaParams
     }
     if (!valid) return;
 
-    // ---- stores from here on ---- (the records as streaming stores, as in preprocess.hip)
+    // ---- stores from here on ---- every Gaussian stores every record, zeros where the upstream kernel stores nothing, as
+    // streaming stores: whole lines, no partial writes (preprocess.hip explains; here 0.42 -> 0.33 ms on the bench frame)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if (in_front && !p.cov3D_precomp) {
+    if (!p.cov3D_precomp) {
         f32x2* dst = reinterpret_cast<f32x2*>(p.cov3Ds + 6 * (size_t)idx);
-        __builtin_nontemporal_store((f32x2){c3[0], c3[1]}, dst);
-        __builtin_nontemporal_store((f32x2){c3[2], c3[3]}, dst + 1);
-        __builtin_nontemporal_store((f32x2){c3[4], c3[5]}, dst + 2);
+        __builtin_nontemporal_store((f32x2){in_front ? c3[0] : 0.0f, in_front ? c3[1] : 0.0f}, dst);
+        __builtin_nontemporal_store((f32x2){in_front ? c3[2] : 0.0f, in_front ? c3[3] : 0.0f}, dst + 1);
+        __builtin_nontemporal_store((f32x2){in_front ? c3[4] : 0.0f, in_front ? c3[5] : 0.0f}, dst + 2);
     }
-    if (has_tile) {
-        if (want_sh) {
+    if (want_sh) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) p.clamped[3 * (size_t)idx + c] = neg[c];
-            float* o = p.rgb + 3 * (size_t)idx;
-            __builtin_nontemporal_store(res[0], o); __builtin_nontemporal_store(res[1], o + 1); __builtin_nontemporal_store(res[2], o + 2);
-        }
+        for (int c = 0; c < 3; ++c) p.clamped[3 * (size_t)idx + c] = has_tile && neg[c];
+        float* o = p.rgb + 3 * (size_t)idx;
+        __builtin_nontemporal_store(has_tile ? res[0] : 0.0f, o);
+        __builtin_nontemporal_store(has_tile ? res[1] : 0.0f, o + 1);
+        __builtin_nontemporal_store(has_tile ? res[2] : 0.0f, o + 2);
+    }
+    __builtin_nontemporal_store(has_tile ? pvz : 0.0f, p.depths + idx);
+    __builtin_nontemporal_store((f32x2){has_tile ? pix : 0.0f, has_tile ? piy : 0.0f}, reinterpret_cast<f32x2*>(p.means2D + idx));
+    __builtin_nontemporal_store((f32x4){has_tile ? cc * det_inv : 0.0f, has_tile ? -cb * det_inv : 0.0f, has_tile ? ca * det_inv : 0.0f,
+                                        has_tile ? opacity : 0.0f},
+                                reinterpret_cast<f32x4*>(p.conic_opacity + idx));
+    if (has_tile) {
         const int y0 = clampi(fy0, p.dims.row_begin, p.dims.row_end), y1 = clampi(fy1, p.dims.row_begin, p.dims.row_end);
-        __builtin_nontemporal_store(pvz, p.depths + idx);
-        __builtin_nontemporal_store((f32x2){pix, piy}, reinterpret_cast<f32x2*>(p.means2D + idx));
-        __builtin_nontemporal_store((f32x4){cc * det_inv, -cb * det_inv, ca * det_inv, opacity}, reinterpret_cast<f32x4*>(p.conic_opacity + idx));
         out_radius = ri;
         out_tiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
         view_z = pvz;
