@@ -51,6 +51,7 @@ struct GeoScratch {
     uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
     uint32_t *a_k, *a_v;      // depth-sort ping
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
+    uint32_t *c_r, *a_r, *b_r;  // the packed rectangles of the same Gaussians, moved with the pairs (tile grids up to 255 x 255)
     SweepScratch sweep;       // onesweep status words for the N-sized sort: pass 0 (+ error word, digit histograms)
     SweepScratch sweep_more[3];   // passes 1-3: their own look-back words, so one clear up front covers all four
     char* emit_scratch;       // column-major emission: [chunk][column] table, block partials, column starts
@@ -71,6 +72,9 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.c_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.a_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.b_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
     for (auto& sw : g.sweep_more) { sw = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n); }
     g.emit_scratch = base + off; off += align128(emit_scratch_bytes(n));
@@ -362,7 +366,11 @@ int gsr_forward(gsr_forward_args* a) {
     // Only Gaussians with at least one tile in this call take part from here on (V of N: 52 % on the
     // bench frame, a few per cent per rank when the frame is sharded): their (depth key, index) pairs
     // are compacted in index order — the same kernels count the digits of the four sort passes.
-    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true));
+    // With a packed rectangle per Gaussian (grids up to 255 x 255) the rectangle travels with the index through the depth
+    // passes: both binning plans want it in depth order, and gathering it by index afterwards is a random 4-byte read per
+    // Gaussian (0.93 ms of the 50 M frame).
+    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
+                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
@@ -372,7 +380,8 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
-    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1));
+    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
+                             xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
     // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
@@ -381,10 +390,13 @@ int gsr_forward(gsr_forward_args* a) {
     if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
     const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
-    if (four_passes) GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream));
+    if (four_passes)
+        GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream, nullptr,
+                                 xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     // depth-sorted keys / indices, and the other pair of buffers (free from here on)
     uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k;
     uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v;
+    const uint32_t* const sorted_r = four_passes ? gs.b_r : gs.a_r;      // (xy_plan only)
     uint32_t* const spare_k = four_passes ? gs.a_k : gs.b_k;
     const uint32_t R = (uint32_t)true_total;               // (= pointOffsets[N - 1], GSCuda.cu:772)
     a->num_rendered = R;
@@ -421,7 +433,7 @@ int gsr_forward(gsr_forward_args* a) {
     bool forked = false;
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
-        GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, R, spare_k, gs.block_scratch,
+        GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, R, gs.block_scratch,
                                       bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, img.ranges, inria, stream,
                                       profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr));
         if (profile) {
@@ -469,7 +481,6 @@ int gsr_forward(gsr_forward_args* a) {
         if (forked) GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
-        uint32_t* rect_packed = spare_k;
         SweepScratch bsw = bs.sweep;
         bsw.error_word = g_rb.host_dev + 2;
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bsw, R, (uint32_t)d.grid_y, stream));
@@ -477,7 +488,7 @@ int gsr_forward(gsr_forward_args* a) {
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
         uint32_t* emit_v = d.grid_y > 1 ? bin.values_unsorted : bin.values;
         // the depth-order stage ends and the emission stage starts at an event inside the launcher
-        GSR_STEP(launch_emit_columns(nv, sorted_k, sorted_v, gs.rect_idx, d.grid_x, d.grid_y, rect_packed, gs.emit_scratch, hist_y,
+        GSR_STEP(launch_emit_columns(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, gs.emit_scratch, hist_y,
                                      emit_k, emit_v, stream, profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr,
                                      profile ? g_rb.ev[2 * GSR_STAGE_DUPLICATE] : nullptr));   // :787
         if (profile) {

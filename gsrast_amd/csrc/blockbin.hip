@@ -38,19 +38,15 @@ constexpr int kScanRows = 64;            // table rows per workgroup of the bloc
 inline size_t align128(size_t v) { return (v + 127) / 128 * 128; }
 
 // ---- coarse pass 1: entries per (chunk of 1024 depth-consecutive Gaussians, block) ------------
+// sorted_rect: the visible Gaussians' packed rectangles in depth order (they travel through the depth sort with the indices)
 template <int CHUNK>
-__global__ __launch_bounds__(CHUNK) void coarse_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
-                                                               const uint32_t* __restrict__ sorted_idx,
-                                                               const uint32_t* __restrict__ rect_by_index, int nbx, int nbp,
-                                                               uint32_t* __restrict__ rect_packed,
+__global__ __launch_bounds__(CHUNK) void coarse_count_kernel(int n, const uint32_t* __restrict__ sorted_rect, int nbx, int nbp,
                                                                uint32_t* __restrict__ table) {
     __shared__ uint32_t s_cnt[kMaxBlocks];
     if ((int)threadIdx.x < nbp) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int r = blockIdx.x * CHUNK + threadIdx.x;
-    uint32_t packed = 0;
-    if (r < n && sorted_depth[r] != 0xFFFFFFFFu) packed = rect_by_index[sorted_idx[r]];
-    if (r < n) rect_packed[r] = packed;
+    const uint32_t packed = (r < n) ? sorted_rect[r] : 0u;
     if (packed) {
         const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
         const uint32_t bx0 = x0 / kBW, bx1 = (x0 + w - 1) / kBW, by0 = y0 / kBH, by1 = (y0 + h - 1) / kBH;
@@ -153,7 +149,7 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
     uint32_t* s_pre = s_dyn + (size_t)nb * WP;   // [nb][WP] set bits in the words below
     const int r = blockIdx.x * CHUNK + threadIdx.x;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
-    if (__syncthreads_or(rect != 0u) == 0) return;          // culled tail of the depth order
+    if (__syncthreads_or(rect != 0u) == 0) return;          // (nothing visible in this chunk)
     for (int i = threadIdx.x; i < nb * WP; i += CHUNK) s_mask[i] = 0;
     __syncthreads();
     const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
@@ -716,19 +712,20 @@ BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_
 }
 
 // Everything of the block plan up to (not including) the emission: block lists, unit masks, prefixes and
-// the tile ranges. rect_packed: out, u32[n] in depth order. ent_rd / ent_idx: R-sized scratch for the
-// block lists. ev_coarse_end: optional event recorded after the block lists (stage timing).
-int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
-                         int grid_x, int grid_y, uint32_t r_total, uint32_t* rect_packed, char* geo_scratch, uint64_t* ent_rd,
+// the tile ranges. sorted_depth / sorted_idx / sorted_rect: the n visible Gaussians in depth order (depth bits, index,
+// packed rectangle). ent_rd / ent_idx: R-sized scratch for the block lists. ev_coarse_end: optional event recorded
+// after the block lists (stage timing).
+int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
+                         int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
                          hipEvent_t ev_coarse_end) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
     if (t.chunk == kCoarse)
-        hipLaunchKernelGGL(coarse_count_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_depth, sorted_idx,
-                           rect_by_index, t.nbx, t.nbp, rect_packed, t.table);
+        hipLaunchKernelGGL(coarse_count_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_rect, t.nbx, t.nbp,
+                           t.table);
     else
-        hipLaunchKernelGGL(coarse_count_kernel<kCoarseSmall>, dim3(t.chunks), dim3(kCoarseSmall), 0, stream, n, sorted_depth,
-                           sorted_idx, rect_by_index, t.nbx, t.nbp, rect_packed, t.table);
+        hipLaunchKernelGGL(coarse_count_kernel<kCoarseSmall>, dim3(t.chunks), dim3(kCoarseSmall), 0, stream, n, sorted_rect, t.nbx,
+                           t.nbp, t.table);
     GSR_LAUNCH_CHECK("coarse_count_kernel");
     hipLaunchKernelGGL(blockscan_reduce_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial);
     GSR_LAUNCH_CHECK("blockscan_reduce_kernel");
@@ -740,13 +737,13 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     const size_t mask_bytes = (size_t)t.nb * (t.chunk / 32 + 1) * 4 * 2;
     if (t.chunk == kCoarse) {
         hipLaunchKernelGGL(coarse_emit_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
-                           sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
+                           sorted_idx, sorted_rect, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
     } else {
         if (mask_bytes > 48 * 1024)
             GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel<kCoarseSmall>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
         hipLaunchKernelGGL(coarse_emit_kernel<kCoarseSmall>, dim3(t.chunks), dim3(kCoarseSmall), mask_bytes, stream, n, sorted_depth,
-                           sorted_idx, rect_packed, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
+                           sorted_idx, sorted_rect, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
     }
     GSR_LAUNCH_CHECK("coarse_emit_kernel");
     if (ev_coarse_end) GSR_HIP_TRY(hipEventRecord(ev_coarse_end, stream));

@@ -52,11 +52,10 @@ __device__ __forceinline__ void emit2(uint64_t* __restrict__ keys, uint32_t* __r
 }
 
 // rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
-__global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint32_t* __restrict__ sorted_depth,
-                                                              const uint32_t* __restrict__ sorted_idx,
-                                                              const uint32_t* __restrict__ rect_by_index, int stride_x,
-                                                              int stride_y, uint32_t* __restrict__ rect_packed,
-                                                              uint32_t* __restrict__ table) {
+// rect_packed: the visible Gaussians' rectangles in depth order (they travel through the depth sort with the indices;
+// gathering them by index here cost 0.93 ms on 50 M Gaussians)
+__global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint32_t* __restrict__ rect_packed, int stride_x,
+                                                              int stride_y, uint32_t* __restrict__ table) {
     // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows
     // likewise); one block-wide prefix sum per array then gives the per-column / per-row key counts.
     __shared__ uint32_t lds_hx[257], lds_hy[257];
@@ -66,8 +65,7 @@ __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint3
     if (threadIdx.x == 0) lds_hx[256] = lds_hy[256] = 0;
     __syncthreads();
     const int r = blockIdx.x * kChunk + threadIdx.x;
-    uint32_t packed = 0;
-    if (r < n && sorted_depth[r] != 0xFFFFFFFFu) packed = rect_by_index[sorted_idx[r]];
+    const uint32_t packed = (r < n) ? rect_packed[r] : 0u;
     if (packed) {
         const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
         atomicAdd(&lds_hx[x0], h);
@@ -75,7 +73,6 @@ __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint3
         atomicAdd(&lds_hy[y0], w);
         atomicSub(&lds_hy[y0 + h], w);
     }
-    if (r < n) rect_packed[r] = packed;
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     uint32_t ix = lds_hx[threadIdx.x], iy = lds_hy[threadIdx.x];
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_
     }
     const int r = chunk * kChunk + g;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
-    if (__syncthreads_or(rect != 0u) == 0) return;              // culled tail of the depth order
+    if (__syncthreads_or(rect != 0u) == 0) return;              // (nothing visible in this chunk)
     s_rect[g] = rect;
     s_col[g] = (g < stride) ? table[(size_t)chunk * stride + g] : 0u;
 #pragma unroll
@@ -253,9 +250,9 @@ size_t emit_scratch_bytes(size_t n) {
     return align128(chunks * 512 * 4) + align128(blocks * 512 * 4) + align128(256 * 4);
 }
 
-// rect_packed: out, u32[n] in depth order. hist_y: out, 256 counters (keys per tile row).
-int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
-                        int grid_x, int grid_y, uint32_t* rect_packed, char* scratch, uint32_t* hist_y, uint64_t* keys,
+// sorted_depth / sorted_idx / rect_packed: the n visible Gaussians in depth order. hist_y: out, 256 counters (keys per tile row).
+int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_packed,
+                        int grid_x, int grid_y, char* scratch, uint32_t* hist_y, uint64_t* keys,
                         uint32_t* values, hipStream_t stream, hipEvent_t mark_prep_end, hipEvent_t mark_emit_begin) {
     const int stride_x = emit_stride(grid_x), stride_y = emit_stride(grid_y), stride = stride_x + stride_y;
     const uint32_t chunks = (uint32_t)((n + kChunk - 1) / kChunk);
@@ -264,8 +261,7 @@ int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sor
     uint32_t* partial = reinterpret_cast<uint32_t*>(scratch + align128((size_t)chunks * 512 * 4));
     uint32_t* colbase = reinterpret_cast<uint32_t*>(scratch + align128((size_t)chunks * 512 * 4) + align128((size_t)blocks * 512 * 4));
     GSR_HIP_TRY(hipMemsetAsync(hist_y, 0, 256 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(column_count_kernel, dim3(chunks), dim3(kChunk), 0, stream, n, sorted_depth, sorted_idx, rect_by_index,
-                       stride_x, stride_y, rect_packed, table);
+    hipLaunchKernelGGL(column_count_kernel, dim3(chunks), dim3(kChunk), 0, stream, n, rect_packed, stride_x, stride_y, table);
     GSR_LAUNCH_CHECK("column_count_kernel");
     hipLaunchKernelGGL(colscan_reduce_kernel, dim3(blocks), dim3(stride), 0, stream, table, chunks, stride, partial);
     GSR_LAUNCH_CHECK("colscan_reduce_kernel");

@@ -72,25 +72,30 @@ struct SweepScratch;
 size_t depth_compact_scratch_bytes(size_t n);
 // offsets_ready: `partial` / info[1] already hold the compaction offsets per 4096 keys and the visible count (the scan of
 // tilesTouched produced them on the way: a key is the sentinel exactly where tilesTouched is 0)
+// rect_by_index / out_r (both or neither): the visible Gaussians' packed rectangles, compacted with the pairs; passed on as
+// second_in / a_s / b_s they travel through the passes with the indices and arrive in depth order (gathering them by
+// index afterwards is a random 4-byte read per Gaussian).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
-                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready = false);
+                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready = false,
+                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr);
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
-                    const uint32_t* n_dev = nullptr);
+                    const uint32_t* n_dev = nullptr, const uint32_t* second_in = nullptr, uint32_t* a_s = nullptr,
+                    uint32_t* b_s = nullptr);
 
 // Column-major emission (emit.hip): count, column scan and emission. The two events (may be null)
 // are recorded between the N-sized preparation and the emission kernel, for stage timing.
 size_t emit_scratch_bytes(size_t n);
-int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
-                        int grid_x, int grid_y, uint32_t* rect_packed, char* scratch, uint32_t* hist_y, uint64_t* keys,
+int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
+                        int grid_x, int grid_y, char* scratch, uint32_t* hist_y, uint64_t* keys,
                         uint32_t* values, hipStream_t stream, hipEvent_t mark_prep_end, hipEvent_t mark_emit_begin);
 
 // Block binning (blockbin.hip): the sorted lists written directly by tile-block owners.
 bool blockbin_supported(int grid_x, int grid_y);
 size_t blockbin_geo_bytes(size_t n);
 size_t blockbin_bin_bytes(size_t r);
-int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* rect_by_index,
-                         int grid_x, int grid_y, uint32_t r_total, uint32_t* rect_packed, char* geo_scratch, uint64_t* ent_rd,
+int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
+                         int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
                          hipEvent_t ev_coarse_end);
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,

@@ -156,9 +156,13 @@ struct LookBack {
     }
 };
 
-template <typename KeyT, int BITS>
-__global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+// SECOND: every key carries a second 32-bit value (vals2_in -> vals2_out; the depth order's packed rectangle), staged and
+// written beside the first. It is loaded after the ranking loop: 16 more registers across that loop would leave one
+// workgroup per CU instead of two.
+template <typename KeyT, int BITS, bool SECOND>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            const uint32_t* __restrict__ vals2_in, uint32_t* __restrict__ vals2_out,
                                                             uint32_t n_host, const uint32_t* __restrict__ n_dev, const DigitSpec spec,
                                                             const uint32_t* __restrict__ digit_hist,
                                                             unsigned long long* status, uint32_t* ticket,
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
     __shared__ uint32_t s_tile, s_fail;
     __shared__ KeyT stage_keys[kStageSlots];
     __shared__ uint32_t stage_vals[kStageSlots];
+    __shared__ uint32_t stage_vals2[SECOND ? kStageSlots : 1];
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (threadIdx.x == 0) {
@@ -251,6 +256,19 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
         rd[i] = (d << 16) | (prior + below);
     }
     __syncthreads();
+    // The second values come in now, with the ranking loop behind (see SECOND above): their round trip is hidden
+    // by the digit scan and the look-back.
+    uint32_t val2[SECOND ? kItems : 1];
+    if constexpr (SECOND) {
+        // (the base is opaque to the compiler: the loads are issued HERE, not hoisted to the top of the kernel)
+        uint32_t first = tile_base + (uint32_t)(wave * kWaveSpan + lane);
+        asm volatile("" : "+v"(first));
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t e = first + (uint32_t)(i * kWave);
+            val2[i] = (e < tile_base + valid) ? vals2_in[e] : 0u;
+        }
+    }
 
     // per digit: exclusive offsets across waves (-> the tile's count), publish it, start the
     // look-back, then the exclusive scan across digits (padding sits in the top digit)
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
             if (slot < (uint32_t)kStageSlots) {
                 stage_keys[slot] = key[i];
                 stage_vals[slot] = val[i];
+                if constexpr (SECOND) stage_vals2[slot] = val2[i];
             }
         }
         __syncthreads();
@@ -345,6 +364,7 @@ __global__ __launch_bounds__(kThreads) void onesweep_kernel(const KeyT* __restri
                 if (dst < n) {
                     keys_out[dst] = k;
                     vals_out[dst] = stage_vals[q];
+                    if constexpr (SECOND) vals2_out[dst] = stage_vals2[q];
                 }
             }
         }
@@ -360,7 +380,8 @@ inline int radix_bits_for(uint32_t nbins) {
 template <typename KeyT>
 int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
                 const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
-                bool already_cleared, const uint32_t* n_dev = nullptr) {
+                bool already_cleared, const uint32_t* n_dev = nullptr, const uint32_t* vals2_in = nullptr,
+                uint32_t* vals2_out = nullptr) {
     const int bits = radix_bits_for(spec.nbins);
     if (bits > 8) return GSR_ERR_INVALID_ARG;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
@@ -368,15 +389,25 @@ int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, ui
         const int rc = sweep_clear(sc, n, spec.nbins, stream);
         if (rc != GSR_OK) return rc;
     }
-#define GSR_SWEEP(B)                                                                                              \
-    hipLaunchKernelGGL((onesweep_kernel<KeyT, B>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, \
-                       keys_out, vals_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
-    switch (bits) {
-        case 4: GSR_SWEEP(4); break;
-        case 5: GSR_SWEEP(5); break;
-        case 6: GSR_SWEEP(6); break;
-        case 7: GSR_SWEEP(7); break;
-        default: GSR_SWEEP(8); break;
+#define GSR_SWEEP(B, SECOND)                                                                                          \
+    hipLaunchKernelGGL((onesweep_kernel<KeyT, B, SECOND>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, \
+                       keys_out, vals_out, vals2_in, vals2_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
+    if (vals2_in) {
+        // a second value per key: the depth passes only (u32 keys, 256 bins)
+        if constexpr (sizeof(KeyT) == 4) {
+            if (bits != 8 || !vals2_out) return GSR_ERR_INVALID_ARG;
+            GSR_SWEEP(8, true);
+        } else {
+            return GSR_ERR_INVALID_ARG;
+        }
+    } else {
+        switch (bits) {
+            case 4: GSR_SWEEP(4, false); break;
+            case 5: GSR_SWEEP(5, false); break;
+            case 6: GSR_SWEEP(6, false); break;
+            case 7: GSR_SWEEP(7, false); break;
+            default: GSR_SWEEP(8, false); break;
+        }
     }
 #undef GSR_SWEEP
     GSR_LAUNCH_CHECK("onesweep_kernel");
@@ -424,8 +455,9 @@ int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* k
 
 int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                    const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
-                   bool already_cleared, const uint32_t* n_dev) {
-    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream, already_cleared, n_dev);
+                   bool already_cleared, const uint32_t* n_dev, const uint32_t* vals2_in, uint32_t* vals2_out) {
+    return launch_pass<uint32_t>(keys_in, vals_in, keys_out, vals_out, n, spec, digit_hist, sc, stream, already_cleared, n_dev,
+                                 vals2_in, vals2_out);
 }
 
 template <typename KeyT>
@@ -509,9 +541,13 @@ __global__ __launch_bounds__(1024) void visible_scan_kernel(uint32_t* __restrict
 
 // writes the visible (key, index) pairs in index order and counts the four 8-bit digits of every
 // visible key (the histograms of the four sort passes) on the way
+// rect_by_index / out_r (may be null): the visible Gaussians' packed rectangles are compacted with the pairs — here, in
+// index order, that read is coalesced; they then travel through the depth passes as the keys' second value.
 __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                           const uint32_t* __restrict__ partial,
+                                                                          const uint32_t* __restrict__ rect_by_index,
                                                                           uint32_t* __restrict__ out_k, uint32_t* __restrict__ out_v,
+                                                                          uint32_t* __restrict__ out_r,
                                                                           uint32_t* __restrict__ hist) {
     __shared__ uint32_t lds[4 * 256];
     __shared__ uint32_t s_w[kCompactThreads / kWave];
@@ -523,6 +559,7 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
         const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
         const uint32_t k = (e < n) ? keys[e] : 0xFFFFFFFFu;
         const bool vis = k != 0xFFFFFFFFu;
+        const uint32_t rect = (rect_by_index && vis) ? rect_by_index[e] : 0u;
         const unsigned long long m = __ballot(vis);
         __syncthreads();                                   // s_w of the previous row has been read
         if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
@@ -537,6 +574,7 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
             const uint32_t pos = running + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             out_k[pos] = k;
             out_v[pos] = e;
+            if (out_r) out_r[pos] = rect;
             atomicAdd(&lds[k & 255u], 1u);
             atomicAdd(&lds[256 + ((k >> 8) & 255u)], 1u);
             atomicAdd(&lds[512 + ((k >> 16) & 255u)], 1u);
@@ -565,7 +603,8 @@ size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChu
 // the four sort passes, and (top_digits) the number of distinct top-byte digits: with at most one the
 // fourth pass would move nothing. info[0] = top_digits, info[1] = visible count (device words).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
-                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready) {
+                     const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready,
+                     const uint32_t* rect_by_index, uint32_t* out_r) {
     if (n == 0) return GSR_OK;
     const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
     if (!offsets_ready) {
@@ -574,8 +613,9 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
         hipLaunchKernelGGL(visible_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, chunks, info + 1);
         GSR_LAUNCH_CHECK("visible_scan_kernel");
     }
-    hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, out_k, out_v,
-                       sc4[0].hist);
+    if ((rect_by_index == nullptr) != (out_r == nullptr)) return GSR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
+                       out_k, out_v, out_r, sc4[0].hist);
     GSR_LAUNCH_CHECK("visible_compact_kernel");
     hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info);
     GSR_LAUNCH_CHECK("top_digit_count_kernel");
@@ -585,19 +625,23 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
 // Passes [first, last) of the stable sort of n (key, value) u32 pairs: in -> a -> b -> a -> b. After P
 // passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
 // n_dev (may be null): the true key count on the device, n then being an upper bound that only sizes the grids.
+// second_in / a_s / b_s (all null, or none): a second value per key that takes the same path (in -> a -> b -> ...).
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
-                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream, const uint32_t* n_dev) {
+                    uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream, const uint32_t* n_dev,
+                    const uint32_t* second_in, uint32_t* a_s, uint32_t* b_s) {
     if (n == 0) return GSR_OK;
     for (int p = first; p < last; ++p) {
         const uint32_t* src_k = (p == 0) ? keys_in : ((p % 2 == 1) ? a_k : b_k);
         const uint32_t* src_v = (p == 0) ? vals_in : ((p % 2 == 1) ? a_v : b_v);
         uint32_t* dst_k = (p % 2 == 0) ? a_k : b_k;
         uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
+        const uint32_t* src_s = second_in ? ((p == 0) ? second_in : ((p % 2 == 1) ? a_s : b_s)) : nullptr;
+        uint32_t* dst_s = second_in ? ((p % 2 == 0) ? a_s : b_s) : nullptr;
         DigitSpec spec;
         spec.mode = kDigitBits; spec.shift = 8 * p; spec.nbins = 256; spec.grid_x = 1; spec.inv_grid_x = 1.0f;
         SweepScratch sc = sc4[p];
         sc.error_word = sc4[0].error_word;
-        const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev);
+        const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev, src_s, dst_s);
         if (rc != GSR_OK) return rc;
     }
     return GSR_OK;

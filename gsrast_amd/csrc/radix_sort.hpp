@@ -37,7 +37,8 @@ int sweep_pass_u64(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* k
                    bool already_cleared = false);
 int sweep_pass_u32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, uint32_t n,
                    const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
-                   bool already_cleared = false, const uint32_t* n_dev = nullptr);
+                   bool already_cleared = false, const uint32_t* n_dev = nullptr, const uint32_t* vals2_in = nullptr,
+                   uint32_t* vals2_out = nullptr);      // vals2_*: a second 32-bit value per key (256 bins only)
 int sweep_clear(const SweepScratch& sc, uint32_t n, uint32_t nbins, hipStream_t stream);
 
 // Digit counts of `passes` consecutive 8-bit fields starting at begin_bit (the last one
