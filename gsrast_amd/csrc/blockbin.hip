@@ -150,6 +150,9 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
     const int r = blockIdx.x * CHUNK + threadIdx.x;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
     if (__syncthreads_or(rect != 0u) == 0) return;          // (nothing visible in this chunk)
+    // (loaded up front: in flight while the masks are built)
+    const uint32_t depth = rect ? sorted_depth[r] : 0u, idx = rect ? sorted_idx[r] : 0u;
+    const uint32_t* row = table + (size_t)blockIdx.x * nbp;
     for (int i = threadIdx.x; i < nb * WP; i += CHUNK) s_mask[i] = 0;
     __syncthreads();
     const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
@@ -169,17 +172,17 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
             const uint32_t o = __shfl_up(incl, off, W);
             if ((int)(threadIdx.x & (W - 1)) >= off) incl += o;
         }
-        s_pre[at] = incl - c;
+        // (+ where the chunk's entries of this block start in the block lists: the loop below then reads LDS only —
+        // with the table read inside it every iteration paid a round trip to the L2)
+        s_pre[at] = incl - c + row[i / W];
     }
     __syncthreads();
     if (!rect) return;
-    const uint64_t rd = (uint64_t)rect | ((uint64_t)sorted_depth[r] << 32);
-    const uint32_t idx = sorted_idx[r];
-    const uint32_t* row = table + (size_t)blockIdx.x * nbp;
+    const uint64_t rd = (uint64_t)rect | ((uint64_t)depth << 32);
     for (uint32_t by = by0; by <= by1; ++by)
         for (uint32_t bx = bx0; bx <= bx1; ++bx) {
             const uint32_t b = by * nbx + bx;
-            const uint32_t pos = row[b] + s_pre[b * WP + word] + (uint32_t)__popc(s_mask[b * WP + word] & (bit - 1u));
+            const uint32_t pos = s_pre[b * WP + word] + (uint32_t)__popc(s_mask[b * WP + word] & (bit - 1u));
             ent_rd[pos] = rd;
             ent_idx[pos] = idx;
         }
