@@ -549,47 +549,73 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
                                                                           uint32_t* __restrict__ out_k, uint32_t* __restrict__ out_v,
                                                                           uint32_t* __restrict__ out_r,
                                                                           uint32_t* __restrict__ hist) {
+    constexpr int kCompactWaves = kCompactThreads / kWave;
+    static_assert(kCompactRows * kCompactWaves == kWave, "one wave scans the (row, wave) counts");
     __shared__ uint32_t lds[4 * 256];
-    __shared__ uint32_t s_w[kCompactThreads / kWave];
+    __shared__ uint32_t s_off[kCompactRows * kCompactWaves];       // (row, wave): keys of that row in that wave, then where they go
     for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads) lds[i] = 0;
     const uint32_t base = blockIdx.x * kCompactChunk;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    uint32_t running = partial[blockIdx.x];
+    // All rows are loaded before anything is counted (one round trip), and the output offsets of all (row, wave)
+    // pieces come from ONE 64-lane scan: two barriers per workgroup (a barrier pair per row before: 32).
+    uint32_t k[kCompactRows], rect[kCompactRows];
+#pragma unroll
     for (int r = 0; r < kCompactRows; ++r) {
         const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
-        const uint32_t k = (e < n) ? keys[e] : 0xFFFFFFFFu;
-        const bool vis = k != 0xFFFFFFFFu;
-        const uint32_t rect = (rect_by_index && vis) ? rect_by_index[e] : 0u;
-        const unsigned long long m = __ballot(vis);
-        __syncthreads();                                   // s_w of the previous row has been read
-        if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0, row_total = 0;
+        k[r] = (e < n) ? keys[e] : 0xFFFFFFFFu;
+    }
+    if (rect_by_index) {
+        // (unconditional: the preprocess writes a rectangle word for every Gaussian, 0 for the culled ones)
 #pragma unroll
-        for (int w = 0; w < kCompactThreads / kWave; ++w) {
-            if (w < wave) before += s_w[w];
-            row_total += s_w[w];
+        for (int r = 0; r < kCompactRows; ++r) {
+            const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
+            rect[r] = (e < n) ? rect_by_index[e] : 0u;
         }
+    }
+    unsigned long long m[kCompactRows];
+    uint32_t mine = 0;                                   // lane r: this wave's visible keys in row r
+#pragma unroll
+    for (int r = 0; r < kCompactRows; ++r) {
+        m[r] = __ballot(k[r] != 0xFFFFFFFFu);
+        mine = (lane == r) ? (uint32_t)__popcll(m[r]) : mine;
+    }
+    if (lane < kCompactRows) s_off[lane * kCompactWaves + wave] = mine;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t c = s_off[lane];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        s_off[lane] = partial[blockIdx.x] + incl - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kCompactRows; ++r) {
+        const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
+        const bool vis = k[r] != 0xFFFFFFFFu;
         if (vis) {
-            const uint32_t pos = running + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            out_k[pos] = k;
+            const uint32_t pos = s_off[r * kCompactWaves + wave] +
+                                 __builtin_amdgcn_mbcnt_hi((uint32_t)(m[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[r], 0u));
+            out_k[pos] = k[r];
             out_v[pos] = e;
-            if (out_r) out_r[pos] = rect;
-            atomicAdd(&lds[k & 255u], 1u);
-            atomicAdd(&lds[256 + ((k >> 8) & 255u)], 1u);
-            atomicAdd(&lds[512 + ((k >> 16) & 255u)], 1u);
+            if (out_r) out_r[pos] = rect[r];
+            atomicAdd(&lds[k[r] & 255u], 1u);
+            atomicAdd(&lds[256 + ((k[r] >> 8) & 255u)], 1u);
+            atomicAdd(&lds[512 + ((k[r] >> 16) & 255u)], 1u);
         }
         // The top byte of float bit patterns takes few distinct values: one LDS atomic per distinct value
         // and wave instead of 64 colliding on the same counter.
-        const uint32_t d = k >> 24;
-        unsigned long long todo = m;
+        const uint32_t d = k[r] >> 24;
+        unsigned long long todo = m[r];
         while (todo) {
             const uint32_t v = (uint32_t)__shfl((int)d, __ffsll((long long)todo) - 1, kWave);
             const unsigned long long same = __ballot(vis && d == v) & todo;
             if (lane == __ffsll((long long)same) - 1) atomicAdd(&lds[768 + v], (uint32_t)__popcll(same));
             todo &= ~same;
         }
-        running += row_total;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads)
