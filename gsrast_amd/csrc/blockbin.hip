@@ -131,8 +131,25 @@ __global__ __launch_bounds__(kMaxBlocks) void blockscan_apply_kernel(uint32_t* _
 }
 
 // ---- coarse pass 2: write the block lists ------------------------------------------------------
-// Order inside a chunk: per block a 1024-bit mask of the chunk's Gaussians touching it; the rank of
-// Gaussian g in block b is the number of set bits below g.
+// Order inside a chunk: per block a 1024-bit mask of the chunk's Gaussians touching it; the rank of Gaussian g in
+// block b is the number of set bits below g. The chunk's entries are then written in (block, rank) order, one entry per
+// lane: consecutive lanes write consecutive entries of one block's list, so a wave's stores are a few whole lines.
+// (One lane per Gaussian looping over its blocks — the version before — sent every entry to a different list: two
+// store requests per entry, 24 M per frame, which is what the kernel's 0.12 ms were made of.)
+// The t-th set bit of m (t < popc(m)).
+__device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, uint32_t t) {
+    uint32_t at = 0;
+#pragma unroll
+    for (uint32_t half = 16; half >= 1; half >>= 1) {
+        const uint32_t c = (uint32_t)__popc(m & ((1u << half) - 1u));
+        const bool up = t >= c;
+        t -= up ? c : 0u;
+        at += up ? half : 0u;
+        m = up ? (m >> half) : m;
+    }
+    return at;
+}
+
 template <int CHUNK>
 __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                               const uint32_t* __restrict__ sorted_idx,
@@ -141,18 +158,22 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
                                                               uint64_t* __restrict__ ent_rd, uint32_t* __restrict__ ent_idx) {
     extern __shared__ uint32_t s_dyn[];
     constexpr int W = CHUNK / 32;                // mask words per block
-    // Rows are W + 1 words apart: the lanes of a wave address the SAME word of DIFFERENT blocks (word = lane's
-    // Gaussian >> 5), which at a stride of W = 32 words is one LDS bank for all of them (round 2: 2.7e7 bank-conflict
-    // cycles per launch, a quarter of the kernel's CU time).
-    constexpr int WP = W + 1;
+    constexpr int WP = W + 1;                    // (rows one word apart in the banks)
     uint32_t* s_mask = s_dyn;                    // [nb][WP]
-    uint32_t* s_pre = s_dyn + (size_t)nb * WP;   // [nb][WP] set bits in the words below
+    uint32_t* s_pre = s_mask + (size_t)nb * WP;  // [nb][WP] set bits in the words below; [W] = the block's total
+    uint32_t* s_start = s_pre + (size_t)nb * WP; // [kMaxBlocks] where the block's entries start among the chunk's (~0 past nb)
+    uint32_t* s_row = s_start + kMaxBlocks;      // [nb] where the chunk's entries of the block start in the block lists
+    uint32_t* s_rect = s_row + nbp;              // [CHUNK] what an entry carries
+    uint32_t* s_depth = s_rect + CHUNK;
+    uint32_t* s_idx = s_depth + CHUNK;
+    __shared__ uint32_t s_ws[CHUNK / kWave];
     const int r = blockIdx.x * CHUNK + threadIdx.x;
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
     if (__syncthreads_or(rect != 0u) == 0) return;          // (nothing visible in this chunk)
-    // (loaded up front: in flight while the masks are built)
-    const uint32_t depth = rect ? sorted_depth[r] : 0u, idx = rect ? sorted_idx[r] : 0u;
-    const uint32_t* row = table + (size_t)blockIdx.x * nbp;
+    s_rect[threadIdx.x] = rect;
+    s_depth[threadIdx.x] = rect ? sorted_depth[r] : 0u;
+    s_idx[threadIdx.x] = rect ? sorted_idx[r] : 0u;
+    if ((int)threadIdx.x < nbp) s_row[threadIdx.x] = table[(size_t)blockIdx.x * nbp + threadIdx.x];
     for (int i = threadIdx.x; i < nb * WP; i += CHUNK) s_mask[i] = 0;
     __syncthreads();
     const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
@@ -172,20 +193,35 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
             const uint32_t o = __shfl_up(incl, off, W);
             if ((int)(threadIdx.x & (W - 1)) >= off) incl += o;
         }
-        // (+ where the chunk's entries of this block start in the block lists: the loop below then reads LDS only —
-        // with the table read inside it every iteration paid a round trip to the L2)
-        s_pre[at] = incl - c + row[i / W];
+        s_pre[at] = incl - c;
+        if ((i & (W - 1)) == W - 1) s_pre[(i / W) * WP + W] = incl;
     }
     __syncthreads();
-    if (!rect) return;
-    const uint64_t rd = (uint64_t)rect | ((uint64_t)depth << 32);
-    for (uint32_t by = by0; by <= by1; ++by)
-        for (uint32_t bx = bx0; bx <= bx1; ++bx) {
-            const uint32_t b = by * nbx + bx;
-            const uint32_t pos = s_pre[b * WP + word] + (uint32_t)__popc(s_mask[b * WP + word] & (bit - 1u));
-            ent_rd[pos] = rd;
-            ent_idx[pos] = idx;
-        }
+    // exclusive prefix of the blocks' totals (blocks past nb: ~0, so that the search below needs no bounds)
+    uint32_t chunk_total;
+    {
+        const uint32_t a = ((int)threadIdx.x < nb) ? s_pre[threadIdx.x * WP + W] : 0u;
+        const uint32_t ex = block_exclusive(a, s_ws, &chunk_total);
+        if (threadIdx.x < (uint32_t)kMaxBlocks) s_start[threadIdx.x] = ((int)threadIdx.x < nb) ? ex : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t top = nb > 256 ? 256u : 128u;
+    for (uint32_t j = threadIdx.x; j < chunk_total; j += CHUNK) {
+        // the last block that starts at or before j (blocks without an entry share their successor's start and are skipped)
+        uint32_t b = 0;
+        for (uint32_t step = top; step >= 1; step >>= 1)
+            if (s_start[b + step] <= j) b += step;
+        const uint32_t t = j - s_start[b];
+        const uint32_t* pre = s_pre + b * WP;
+        uint32_t wd = 0;
+#pragma unroll
+        for (uint32_t step = W / 2; step >= 1; step >>= 1)
+            if (pre[wd + step] <= t) wd += step;
+        const uint32_t g = wd * 32u + nth_set_bit(s_mask[b * WP + wd], t - pre[wd]);
+        const uint32_t pos = s_row[b] + t;
+        ent_rd[pos] = (uint64_t)s_rect[g] | ((uint64_t)s_depth[g] << 32);
+        ent_idx[pos] = s_idx[g];
+    }
 }
 
 // ---- units ---------------------------------------------------------------------------------------
@@ -737,8 +773,11 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     hipLaunchKernelGGL(blockscan_apply_kernel, dim3(t.groups), dim3(t.nbp), 0, stream, t.table, t.chunks, t.nbp, t.partial,
                        t.meta.list_start());
     GSR_LAUNCH_CHECK("blockscan_apply_kernel");
-    const size_t mask_bytes = (size_t)t.nb * (t.chunk / 32 + 1) * 4 * 2;
+    const size_t mask_bytes = ((size_t)t.nb * (t.chunk / 32 + 1) * 2 + kMaxBlocks + t.nbp + 3 * (size_t)t.chunk) * 4;
     if (t.chunk == kCoarse) {
+        if (mask_bytes > 48 * 1024)
+            GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel<kCoarse>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
         hipLaunchKernelGGL(coarse_emit_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
                            sorted_idx, sorted_rect, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
     } else {
