@@ -168,12 +168,14 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
     uint32_t* s_idx = s_depth + CHUNK;
     __shared__ uint32_t s_ws[CHUNK / kWave];
     const int r = blockIdx.x * CHUNK + threadIdx.x;
+    // (every load of the chunk is issued before the first wait: one round trip to memory per workgroup, not two)
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
-    if (__syncthreads_or(rect != 0u) == 0) return;          // (nothing visible in this chunk)
+    const uint32_t depth_in = (r < n) ? sorted_depth[r] : 0u, idx_in = (r < n) ? sorted_idx[r] : 0u;
+    const uint32_t row_in = ((int)threadIdx.x < nbp) ? table[(size_t)blockIdx.x * nbp + threadIdx.x] : 0u;
     s_rect[threadIdx.x] = rect;
-    s_depth[threadIdx.x] = rect ? sorted_depth[r] : 0u;
-    s_idx[threadIdx.x] = rect ? sorted_idx[r] : 0u;
-    if ((int)threadIdx.x < nbp) s_row[threadIdx.x] = table[(size_t)blockIdx.x * nbp + threadIdx.x];
+    s_depth[threadIdx.x] = depth_in;
+    s_idx[threadIdx.x] = idx_in;
+    if ((int)threadIdx.x < nbp) s_row[threadIdx.x] = row_in;
     for (int i = threadIdx.x; i < nb * WP; i += CHUNK) s_mask[i] = 0;
     __syncthreads();
     const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;

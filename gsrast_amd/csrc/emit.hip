@@ -7,14 +7,14 @@
 // order the keys of column x are, Gaussian after Gaussian, the h rows of its rectangle, so key
 // (g, x, y) belongs at
 //     start[x] + (rows of all earlier Gaussians covering x) + (y - y0).
-//   column_count_kernel : per chunk of 256 depth-consecutive Gaussians, keys per column
+//   column_count_kernel : per chunk of 512 depth-consecutive Gaussians, keys per column
 //                         (difference arrays, 4 LDS atomics per Gaussian) -> table[chunk][x]
 //   colscan_*           : exclusive prefix of the table down the chunks for every column, plus the
 //                         column starts: table[chunk][x] becomes the output index of the chunk's
 //                         first key in column x (three small launches, all row-coalesced)
 //   emit_chunk_kernel   : resolves the order INSIDE a chunk with per-column bit masks of covering
-//                         Gaussians (+ per-32-Gaussian row sums), then writes every
-//                         (Gaussian, column) run as contiguous 16-byte key / 8-byte value stores.
+//                         Gaussians (+ per-32-Gaussian row sums), then writes the chunk's keys in
+//                         (column, position) order, one key per lane: coalesced runs per column.
 // What reaches the remaining pass (stable on the tile row y) is exactly what a stable x pass over
 // the depth-ordered list would have produced, so the sorted list is bit-identical.
 #include <stdlib.h>
@@ -24,32 +24,9 @@
 namespace gsr {
 namespace {
 
-constexpr int kChunk = 256;        // Gaussians per workgroup
+constexpr int kChunk = 512;        // Gaussians per workgroup
 constexpr int kRowsPerBlock = 256; // table rows per workgroup of the column scan
-constexpr int kSmallRect = 8;   // rectangles up to this many tiles are written by their own lane
-
-// Two consecutive rows of one column run in one go: a 16-byte key store and an 8-byte value store.
-// The destination is only 8-byte (keys) / 4-byte (values) aligned; gfx950 under HSA runs with
-// unaligned vector-memory access enabled, so dword-aligned wide stores are legal.
-struct __attribute__((packed, aligned(8))) KeyPair { uint64_t a, b; };
-struct __attribute__((packed, aligned(4))) ValPair { uint32_t a, b; };
-
-__device__ __forceinline__ void emit1(uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t pos,
-                                      uint32_t tile, uint32_t depth_bits, uint32_t idx) {
-    keys[pos] = ((uint64_t)tile << 32) | (uint64_t)depth_bits;
-    values[pos] = idx;
-}
-__device__ __forceinline__ void emit2(uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint32_t pos,
-                                      uint32_t tile, uint32_t tile_step, uint32_t depth_bits, uint32_t idx) {
-    KeyPair k;
-    k.a = ((uint64_t)tile << 32) | (uint64_t)depth_bits;
-    k.b = ((uint64_t)(tile + tile_step) << 32) | (uint64_t)depth_bits;
-    *reinterpret_cast<KeyPair*>(keys + pos) = k;
-    ValPair v;
-    v.a = idx;
-    v.b = idx;
-    *reinterpret_cast<ValPair*>(values + pos) = v;
-}
+constexpr int kCols = 256;         // tile columns / rows the tables are laid out for (grids up to 255 x 255)
 
 // rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
 // rect_packed: the visible Gaussians' rectangles in depth order (they travel through the depth sort with the indices;
@@ -57,12 +34,13 @@ __device__ __forceinline__ void emit2(uint64_t* __restrict__ keys, uint32_t* __r
 __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint32_t* __restrict__ rect_packed, int stride_x,
                                                               int stride_y, uint32_t* __restrict__ table) {
     // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows
-    // likewise); one block-wide prefix sum per array then gives the per-column / per-row key counts.
-    __shared__ uint32_t lds_hx[257], lds_hy[257];
-    __shared__ uint32_t s_ws[2][4];
-    lds_hx[threadIdx.x] = 0;
-    lds_hy[threadIdx.x] = 0;
-    if (threadIdx.x == 0) lds_hx[256] = lds_hy[256] = 0;
+    // likewise); one prefix sum per array (the first 256 threads) then gives the per-column / per-row key counts.
+    __shared__ uint32_t lds_hx[kCols + 1], lds_hy[kCols + 1];
+    __shared__ uint32_t s_ws[2][kCols / kWave];
+    if (threadIdx.x <= kCols) {
+        lds_hx[threadIdx.x] = 0;
+        lds_hy[threadIdx.x] = 0;
+    }
     __syncthreads();
     const int r = blockIdx.x * kChunk + threadIdx.x;
     const uint32_t packed = (r < n) ? rect_packed[r] : 0u;
@@ -75,14 +53,16 @@ __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint3
     }
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    uint32_t ix = lds_hx[threadIdx.x], iy = lds_hy[threadIdx.x];
+    const bool scans = threadIdx.x < kCols;
+    uint32_t ix = scans ? lds_hx[threadIdx.x] : 0u, iy = scans ? lds_hy[threadIdx.x] : 0u;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
         const uint32_t ox = __shfl_up(ix, off, kWave), oy = __shfl_up(iy, off, kWave);
         if (lane >= off) { ix += ox; iy += oy; }
     }
-    if (lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
+    if (scans && lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
     __syncthreads();
+    if (!scans) return;
     for (int ww = 0; ww < wave; ++ww) { ix += s_ws[0][ww]; iy += s_ws[1][ww]; }
     // one table row per chunk: [keys per tile column | keys per tile row]. The row counts are summed
     // down the chunks by the column scan below (its totals are the digit histogram of the tile-row
@@ -148,93 +128,116 @@ __global__ __launch_bounds__(256) void colscan_apply_kernel(uint32_t* __restrict
 }
 
 // ---- emission ----------------------------------------------------------------------------------
+// The keys of a chunk leave in (column, position) order, one key per lane: consecutive lanes write consecutive keys of
+// one column's run, so a wave's stores are a few whole lines. (One lane per Gaussian walking its own tiles — the
+// version before — sent every key to a different place: two store requests per key, 250 M on the 50 M frame, which
+// is what its 1.2 ms were made of.)
+//   masks : per column, which of the chunk's Gaussians cover it (bit g of word g / 32) and, per word, the rows they
+//           add there; prefix over the words -> where a word's keys start in the column's run of this chunk
+//   keys  : key j of the chunk -> its column (search in the columns' starts), the word (search in the word prefix), the
+//           Gaussian (walk over the word's set bits, subtracting heights) and the row inside its rectangle
 __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                             const uint32_t* __restrict__ sorted_idx,
                                                             const uint32_t* __restrict__ rect_packed,
-                                                            const uint32_t* __restrict__ table, int stride, int grid_x,
+                                                            const uint32_t* __restrict__ table, int stride, int stride_x, int grid_x,
                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
-    __shared__ uint32_t s_rect[kChunk];
-    __shared__ uint32_t s_col[256];             // output index of the chunk's first key in column x
-    __shared__ uint32_t s_mask[256][8];         // per column: which of the 256 Gaussians cover it
-    __shared__ uint32_t s_wsum[256][8];         // per column and 32-Gaussian word: rows contributed
-    __shared__ uint32_t s_tmp[4][256];          // per wave: run starts of the rectangle being expanded
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    constexpr int W = kChunk / 32;                       // mask words per column
+    // [word][column]: the lanes of the build address one word of different columns, those of the prefix one column each
+    __shared__ uint32_t s_mask[W][kCols];
+    __shared__ uint32_t s_wpre[W + 1][kCols];           // rows added by the words below; [W] = the column's keys in this chunk
+    __shared__ uint32_t s_rect[kChunk], s_depth[kChunk], s_idx[kChunk];
+    __shared__ uint32_t s_cstart[kCols];                 // where the column's keys start among the chunk's
+    __shared__ uint32_t s_col[kCols];                    // output index of the chunk's first key in column x
+    __shared__ uint32_t s_ws[kChunk / kWave];
     const int g = threadIdx.x;
-    // Which chunk: workgroup b runs on XCD b % 8. Consecutive chunks write adjacent pieces of every column's run (a few
-    // keys each when the splats are small), so 32 consecutive chunks go to ONE XCD: the pieces of a line then meet in
-    // that XCD's L2 and leave as whole lines instead of as one partial write per chunk.
+    // Which chunk: workgroup b runs on XCD b % 8. Consecutive chunks write adjacent pieces of every column's run, so 32
+    // consecutive chunks go to ONE XCD: the pieces of a line then meet in that XCD's L2 and leave as whole lines.
     int chunk = (int)blockIdx.x;
     {
-        constexpr int kPer = 32, kGroupChunks = 8 * kPer;          // (8 / 32 / 128 chunks in a row: 1.24 / 1.20 / 1.19 ms at 50 M, 1.48 before)
+        constexpr int kPer = 32, kGroupChunks = 8 * kPer;
         const int group0 = chunk / kGroupChunks * kGroupChunks;
         if (group0 + kGroupChunks <= (int)gridDim.x) chunk = group0 + ((chunk - group0) % 8) * kPer + (chunk - group0) / 8;
     }
     const int r = chunk * kChunk + g;
+    // (every load of the chunk is issued before the first wait: one round trip to memory per workgroup, not two)
     const uint32_t rect = (r < n) ? rect_packed[r] : 0u;
-    if (__syncthreads_or(rect != 0u) == 0) return;              // (nothing visible in this chunk)
+    const uint32_t depth_in = (r < n) ? sorted_depth[r] : 0u, idx_in = (r < n) ? sorted_idx[r] : 0u;
+    const uint32_t col_in = (g < stride_x) ? table[(size_t)chunk * stride + g] : 0u;
     s_rect[g] = rect;
-    s_col[g] = (g < stride) ? table[(size_t)chunk * stride + g] : 0u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        s_mask[g][k] = 0;
-        s_wsum[g][k] = 0;
+    s_depth[g] = depth_in;
+    s_idx[g] = idx_in;
+    if (g < kCols) s_col[g] = col_in;
+    // (only the columns of this grid: stride_x of them, a multiple of 64; 16 bytes per lane and store)
+    for (int i = g; i < W * (stride_x / 4); i += kChunk) {
+        const int k = i / (stride_x / 4), q = i - k * (stride_x / 4);
+        reinterpret_cast<uint4*>(&s_mask[k][0])[q] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4*>(&s_wpre[k][0])[q] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
-    const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
+    const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, h = rect >> 24;
     for (uint32_t c = 0; c < w; ++c) {
-        atomicOr(&s_mask[x0 + c][g >> 5], 1u << (g & 31));
-        atomicAdd(&s_wsum[x0 + c][g >> 5], h);
+        atomicOr(&s_mask[g >> 5][x0 + c], 1u << (g & 31));
+        atomicAdd(&s_wpre[g >> 5][x0 + c], h);
     }
     __syncthreads();
-    // rows of the chunk's earlier Gaussians in column x = whole 32-Gaussian words + the set bits
-    // below g in its own word
-    auto run_start = [&](uint32_t gg, uint32_t x) -> uint32_t {
-        uint32_t s = s_col[x];
-        const uint32_t word = gg >> 5;
-        for (uint32_t k = 0; k < word; ++k) s += s_wsum[x][k];
-        uint32_t m = s_mask[x][word] & ((1u << (gg & 31)) - 1u);
-        while (m) {
-            const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
-            m &= m - 1u;
-            s += s_rect[(word << 5) + b] >> 24;
+    // per column: the words' row counts -> exclusive prefix, total in [W]
+    uint32_t col_total = 0;
+    if (g < stride_x) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const uint32_t v = s_wpre[k][g];
+            s_wpre[k][g] = col_total;
+            col_total += v;
         }
-        return s;
-    };
-    const uint32_t cnt = w * h;
-    const uint32_t depth = cnt ? sorted_depth[r] : 0u, idx = cnt ? sorted_idx[r] : 0u;
-    // small rectangles: the owning lane walks its few tiles itself
-    if (cnt > 0 && cnt <= (uint32_t)kSmallRect) {
-        for (uint32_t c = 0; c < w; ++c) {
-            const uint32_t base = run_start((uint32_t)g, x0 + c);
-            for (uint32_t yy = 0; yy < h; ++yy)
-                emit1(keys, values, base + yy, __umul24(y0 + yy, (uint32_t)grid_x) + x0 + c, depth, idx);
-        }
+        s_wpre[W][g] = col_total;
     }
-    // large rectangles: one at a time; first the lanes resolve the run start of every column, then
-    // the 64 lanes walk the rectangle in pairs of rows (pair k -> column k / hp, rows 2 (k % hp), +1)
-    unsigned long long big = __ballot(cnt > (uint32_t)kSmallRect);
-    uint32_t* tmp = s_tmp[wave];
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t sx0 = __shfl(x0, src, kWave), sw = __shfl(w, src, kWave), sy0 = __shfl(y0, src, kWave);
-        const uint32_t sh = __shfl(h, src, kWave), sdepth = __shfl(depth, src, kWave), sidx = __shfl(idx, src, kWave);
-        const uint32_t sg = (uint32_t)(wave << 6) + (uint32_t)src;
-        for (uint32_t c = (uint32_t)lane; c < sw; c += kWave) tmp[c] = run_start(sg, sx0 + c);
-        // (wave-private LDS: the writes above are ordered before the reads below inside the wave)
-        const uint32_t hp = (sh + 1u) >> 1, npairs = sw * hp;
-        const float inv_hp = 1.0f / (float)hp;
-        for (uint32_t k = (uint32_t)lane; k < npairs; k += kWave) {
-            uint32_t c = (uint32_t)((float)k * inv_hp);             // k < 2^16: off by at most one
-            int j = (int)k - (int)__umul24(c, hp);
-            if (j < 0) { --c; j += (int)hp; }
-            if (j >= (int)hp) { ++c; j -= (int)hp; }
-            const uint32_t yy = 2u * (uint32_t)j;
-            const uint32_t pos = tmp[c] + yy;
-            const uint32_t tile = __umul24(sy0 + yy, (uint32_t)grid_x) + sx0 + c;
-            if (yy + 1u < sh) emit2(keys, values, pos, tile, (uint32_t)grid_x, sdepth, sidx);
-            else emit1(keys, values, pos, tile, sdepth, sidx);
+    uint32_t chunk_total;
+    {
+        // exclusive prefix of the columns' totals (non-decreasing; a column without keys shares its successor's start, and
+        // everything behind the last key starts at chunk_total: never at or before a j < chunk_total)
+        const int lane = g & (kWave - 1), wave = g / kWave;
+        uint32_t incl = col_total;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
         }
+        if (lane == kWave - 1) s_ws[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, tot = 0;
+        for (int ww = 0; ww < kChunk / kWave; ++ww) {
+            if (ww < wave) base += s_ws[ww];
+            tot += s_ws[ww];
+        }
+        chunk_total = tot;
+        if (g < kCols) s_cstart[g] = base + incl - col_total;      // (columns past stride_x: col_total = 0, start = chunk_total)
+    }
+    __syncthreads();
+    const uint32_t top = stride_x > 128 ? 128u : (stride_x > 64 ? 64u : 32u);
+    for (uint32_t j = (uint32_t)g; j < chunk_total; j += kChunk) {
+        // the last column that starts at or before j (of columns sharing a start, the last one is the one with keys)
+        uint32_t x = 0;
+        for (uint32_t step = top; step >= 1; step >>= 1)
+            if (s_cstart[x + step] <= j) x += step;
+        const uint32_t t = j - s_cstart[x];
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t step = W / 2; step >= 1; step >>= 1)
+            if (s_wpre[k + step][x] <= t) k += step;
+        // inside the word: Gaussian after Gaussian (set bits, ascending), each with the rows of its rectangle
+        uint32_t rem = t - s_wpre[k][x], m = s_mask[k][x], gg = 0, gr = 0;
+        for (;;) {
+            gg = (k << 5) + (uint32_t)__ffs((int)m) - 1u;
+            gr = s_rect[gg];
+            const uint32_t gh = gr >> 24;
+            m &= m - 1u;
+            if (rem < gh || m == 0u) break;
+            rem -= gh;
+        }
+        const uint32_t tile = __umul24(((gr >> 16) & 0xFFu) + rem, (uint32_t)grid_x) + x;
+        const uint32_t pos = s_col[x] + t;
+        keys[pos] = ((uint64_t)tile << 32) | (uint64_t)s_depth[gg];
+        values[pos] = s_idx[gg];
     }
 }
 
@@ -272,7 +275,7 @@ int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sor
     if (mark_prep_end) GSR_HIP_TRY(hipEventRecord(mark_prep_end, stream));
     if (mark_emit_begin) GSR_HIP_TRY(hipEventRecord(mark_emit_begin, stream));
     hipLaunchKernelGGL(emit_chunk_kernel, dim3(chunks), dim3(kChunk), 0, stream, n, sorted_depth, sorted_idx, rect_packed, table,
-                       stride, grid_x, keys, values);
+                       stride, stride_x, grid_x, keys, values);
     GSR_LAUNCH_CHECK("emit_chunk_kernel");
     return GSR_OK;
 }
