@@ -245,7 +245,8 @@ class Runner:
                 mine[b0:b1] = per_tile[b0:b1]
                 exch.rebalance(mine, floor_cost=0.02 * float(per_tile[b0:b1].mean() if b1 > b0 else 0.0) + 1.0)
         rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None, **kw)
-        out = {"plan": rast.last_plan, "lists_written": rast.last_lists_written, "records_staged": rast.last_records_staged,
+        out = {"plan": rast.last_plan, "lists_written": rast.last_lists_written, "blend_from_lists": rast.last_blend_from_lists,
+               "records_staged": rast.last_records_staged,
                "num_rendered": rast.last_num_rendered}
         geo = rast.map_geometry_state()
         out["visible_band"] = int((geo["tilesTouched"] != 0).sum().item())
@@ -469,7 +470,7 @@ def main() -> int:
         dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"), key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
                      "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)",
-                     "blend": "blend_blocks_kernel" if blocks else "blend_wave_kernel",
+                     "blend": "blend_blocks_kernel" if blocks and not m["blend_from_lists"] else "blend_wave_kernel",
                      "duplicate": "block_emit_kernel (sorted lists written directly)" if blocks else "emit_chunk_kernel",
                      "preprocess": "preprocess_inria_kernel" if inria else "preprocess_kernel", "ranges": "tile_ranges_search_kernel"}
 
@@ -513,11 +514,12 @@ def main() -> int:
                        "minstances_per_s": round(m["num_rendered_total"] / (ms_per_step * 1e-3) / 1e6, 2),
                        "semantics": args.semantics + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)"),
                        "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "rccl_ranks": world if distributed else 0,
-                       "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"],
+                       "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
-                                  "duplicate": "block_emit_kernel (the sorted keys / values)", "blend": "blend_blocks_kernel"} if blocks else
+                                  "duplicate": "block_emit_kernel (the sorted keys / values)",
+                                  "blend": "blend_wave_kernel (from the sorted lists)" if m["blend_from_lists"] else "blend_blocks_kernel"} if blocks else
                                  {"depth_order": "visible-key compaction + depth sort + column counts / scan", "duplicate": "emit_chunk_kernel",
                                   "sort_pass2": "onesweep pass on the tile row", "blend": "blend_wave_kernel"}),
             "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {m['prof_steps']} "
@@ -546,6 +548,7 @@ def brief(e, n_splats, what):
     return {"what": what, "ms_per_step": round(e["ms_per_step"], 4), "fps": round(1e3 / e["ms_per_step"], 2),
             "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
             "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],
+            "blend_from_sorted_lists": e["blend_from_lists"],
             "sorted_lists_written": e["lists_written"], "stage_ms": {k: round(v, 4) for k, v in e["stage_ms"].items() if v > 0}}
 
 

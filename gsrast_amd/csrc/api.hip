@@ -425,12 +425,15 @@ int gsr_forward(gsr_forward_args* a) {
     // one onesweep pass on the tile row. The block plan pays per (Gaussian, block) entry, so scenes
     // of tiny splats (few tiles per Gaussian) stay on the sort plan unless a flag forces one.
     bool use_blocks = xy_plan && blockbin_supported(d.grid_x, d.grid_y) && !(a->flags & GSR_FLAG_PLAN_SORT);
-    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 4ull * (uint64_t)n;   // measured: 3.5 % slower at R/N = 2.5 (50 M tiny splats), 2x faster at 46
+    // The block plan pays per (Gaussian, block) entry and per unit, the sort plan 36 bytes per instance: what decides is
+    // the instances per VISIBLE Gaussian. Measured (binning without the blend, sort / blocks): R/V = 2.7 (50 M tiny splats)
+    // 5.6 / 5.9 ms, 5.3 (the bench scene from far away) 0.98 / 1.00 ms, 7.5: 2.08 / 1.81 ms, 11: 2.76 / 1.58 ms, 88: 2x.
+    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 6ull * (uint64_t)nv;
     a->plan_used = use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC);
     // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
     if (!use_blocks)
         GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
-    bool forked = false;
+    bool forked = false, blend_from_lists = false;
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, R, gs.block_scratch,
@@ -448,6 +451,12 @@ int gsr_forward(gsr_forward_args* a) {
         // gsr_forward's work is complete: 5 % shorter frames, but each of the two kernels runs ~20 % longer
         // while they share the chip, so per-kernel times are no longer those of the kernels alone.
         const bool serial = !(a->flags & GSR_FLAG_OVERLAP_EMIT) || (a->flags & GSR_FLAG_NO_SORTED_LISTS);
+        // Which lists feed the blend. Out of the block lists a tile walks every unit of its block and picks its entries
+        // by mask: as good as the sorted list where a Gaussian covers most tiles of its blocks, but with small splats a
+        // tile owns a few of a unit's 2048 entries and pays a round trip to memory per unit for them (the bench scene
+        // from outside the cloud, R/V = 23: 0.65 against 0.45 ms; from far away, R/V = 5: 1.98 against 0.65 ms; bench
+        // frame, R/V = 88: equal). With the sorted lists written anyway, sparse frames blend from them.
+        blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) && (uint64_t)R < 48ull * (uint64_t)nv;
         hipStream_t emit_stream = stream;
         if (!serial) {
             GSR_STEP(g_rb.ensure_side());
@@ -462,7 +471,10 @@ int gsr_forward(gsr_forward_args* a) {
         g_rb.feed = block_feed(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
         g_rb.feed.acc = reinterpret_cast<float*>(bin.keys_unsorted);
         g_rb.feed.acc_floats = 2ull * (unsigned long long)R;
-        g_rb.feed_for = bin.values;
+        // (not after a blend from the sorted lists: BlockMeta::walked, which bounds the per-entry sums, is the block-fed
+        // blend's by-product; gsr_backward then takes the sorted lists for every tile)
+        g_rb.feed_for = blend_from_lists ? nullptr : bin.values;
+        if (blend_from_lists) a->plan_used |= GSR_PLAN_BLEND_FROM_LISTS;
         // GSR_FLAG_NO_SORTED_LISTS: this plan's blend reads the block lists, and no caller of the reference reads
         // BinningState (GSGaussians.cpp:214-219 maps GeometryState only): a forward-only caller may skip the 12 R
         // bytes of sorted keys / values altogether. keys / values are then left unwritten.
@@ -531,7 +543,7 @@ int gsr_forward(gsr_forward_args* a) {
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     GSR_BEGIN(GSR_STAGE_BLEND);
-    if (use_blocks)
+    if (use_blocks && !blend_from_lists)
         GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
                                      colors, geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color,
                                      count_staged ? g_rb.staged_dev : nullptr, t_cutoff, stream));

@@ -80,6 +80,7 @@ class SplatRasterizer:
         self.last_num_rendered = 0
         self.last_records_staged = 0
         self.last_plan = "none"
+        self.last_blend_from_lists = False
         self.last_stage_ms: dict[str, float] = {}
         # view (16) | proj (16) | cam_pos (3): one device buffer, uploaded with one async copy from pinned memory
         self._cam_dev = torch.zeros(35, dtype=torch.float32, device=self.device)
@@ -166,6 +167,8 @@ class SplatRasterizer:
         self.last_records_staged = int(a.records_staged)
         self.last_plan = _capi.PLAN_NAMES[int(a.plan_used) & 0xFF]
         self.last_lists_written = not (int(a.plan_used) & _capi.GSR_PLAN_LISTS_SKIPPED)
+        # block plan only: did the blend read the sorted lists (sparse frames) instead of the block lists
+        self.last_blend_from_lists = bool(int(a.plan_used) & _capi.GSR_PLAN_BLEND_FROM_LISTS)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()

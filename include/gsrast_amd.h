@@ -107,7 +107,7 @@ enum {
  * profile is unpinned (no upstream source in the reference tree). */
 #define GSR_FLAG_SEMANTICS_INRIA 0x4u
 /* Binning plan (both produce bit-identical sorted keys / values / ranges; default: chosen per frame
- * from numRendered / numGaussians). PLAN_SORT: column-major key emission + one onesweep radix pass;
+ * from numRendered per visible Gaussian: the block plan from 6 up). PLAN_SORT: column-major key emission + one onesweep radix pass;
  * keysUnsorted / valuesUnsorted then hold the reference's pairs in (tile column, depth) order.
  * PLAN_BLOCKS: the sorted lists are written directly by tile-block owners, no R-sized sort;
  * keysUnsorted / valuesUnsorted then hold that plan's block lists (scratch, as sortingSpace is). */
@@ -116,8 +116,8 @@ enum {
 /* Block plan only: run the emission of the sorted lists on a second stream beside the blend (which reads the
  * block lists and does not need them). Same results; the call's work is complete, as always, when `stream` is. */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
-/* Forward-only callers: under the block plan the blend is fed from the block lists and never reads the sorted
- * keys / values, and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
+/* Forward-only callers: under the block plan the blend can be fed from the block lists without reading the sorted
+ * keys / values (it is by default on frames of 48 or more instances per visible Gaussian), and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
  * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
  * UNWRITTEN, plan_used carries GSR_PLAN_LISTS_SKIPPED, and a gsr_backward call that follows (same thread and
  * device, chunks untouched, `point_list` = that unwritten values array) walks the tile lists out of the block lists.
@@ -125,7 +125,9 @@ enum {
  * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
 #define GSR_FLAG_NO_SORTED_LISTS 0x40u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
-       GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */ };
+       GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
+       GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer
+                                            than 48 instances per visible Gaussian), not the block lists */ };
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
  * gscuda::forward (GSCuda.cuh:103-126); the rest are extensions with neutral defaults (0). */

@@ -240,6 +240,34 @@ def test_forward_only_calls_may_skip_the_sorted_lists():
     r.backward(torch.ones((3, 1080, 1920)))                                        # and backward works again
 
 
+def test_plan_and_blend_feed_follow_the_instances_per_visible_gaussian():
+    """The default choices (csrc/api.hip): the block plan from 6 instances per VISIBLE Gaussian up; under it the blend
+    reads the sorted lists on sparse frames (fewer than 48 per visible Gaussian) and the block lists on dense ones.
+    Whatever is chosen, pixels, finalT, nContrib, ranges, R and R_f are those of every other choice."""
+    import torch
+    from gsrast_amd import camera, scenes
+    scene = scenes.garden_like_scene(400_000, seed=47)
+    r = _rast(1920, 1080, background=(0.1, 0.0, 0.2))
+    r.configure_from_scene(scene)
+    seen = set()
+    for z in (-5.0, -14.0, -30.0, -50.0):
+        cam = camera.default_camera(1920, 1080, near=0.05, far=120.0, position=(0.0, 0.0, z))
+        img = r.draw(cam, count_staged=True).clone()
+        R, staged, plan, from_lists = r.last_num_rendered, r.last_records_staged, r.last_plan, r.last_blend_from_lists
+        V = int((r.map_geometry_state()["tilesTouched"] != 0).sum().item())
+        assert plan == ("blocks" if R >= 6 * V else "sort"), (z, R, V, plan)
+        assert from_lists == (plan == "blocks" and R < 48 * V), (z, R, V, from_lists)
+        seen.add((plan, from_lists))
+        st = {k: v.clone() for k, v in r.map_image_state().items()}
+        for kw in (dict(plan="sort"), dict(plan="blocks"), dict(plan="blocks", sorted_lists=False)):
+            other = r.draw(cam, count_staged=True, **kw)
+            assert torch.equal(other, img), (z, kw)
+            assert r.last_num_rendered == R and r.last_records_staged == staged, (z, kw)
+            for k, v in r.map_image_state().items():
+                assert torch.equal(v, st[k]), (z, kw, k)
+    assert len(seen) == 3, seen          # the poses cover: sort plan, block plan fed from the sorted lists, block plan fed from the block lists
+
+
 def test_nan_positions_of_either_sign_match_the_oracle():
     """A NaN position passes the reference's frustum test (every comparison is false, GSCuda.cu:306-309) and dies
     at the rectangle (an int conversion of NaN gives an empty one): nothing of it may reach the lists. (A visible key
