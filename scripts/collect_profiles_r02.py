@@ -32,7 +32,8 @@ def write_trace(name, cmd):
         print("missing trace", name)
         return {}
     line = bench_line(f"{SRC}/trace_{name}.log")
-    rows = list(csv.DictReader(open(f)))
+    # (the scene generator's torch kernels — 50 M scene built on the device — are not the library's)
+    rows = [r for r in csv.DictReader(open(f)) if "at::native" not in r["Name"] and not r["Name"].startswith("void at::")]
     with open(f"{DST}/r02_{name}_kernel_stats.txt", "w") as o:
         o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {cmd}\n# bench line of the same run:\n{json.dumps(line)}\n")
         o.write("# kernel  calls  average / min / max microseconds  share of device time\n")
@@ -62,6 +63,8 @@ def main():
     write_trace("head", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras   (the headline frame)")
     write_trace("outside", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --pose 0,0,-14")
     write_trace("bound", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --opacity-scale 0.1")
+    write_trace("stress50M", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --scene stress --splats 50000000")
+    write_trace("4k", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --width 3840 --height 2160")
     write_trace("backward_nolists", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --backward --no-sorted-lists")
     with open(f"{DST}/r02_pmc.txt", "w") as o:
         o.write("# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras [frame]\n"
@@ -104,8 +107,11 @@ def main():
                               "SQ_ACTIVE_INST_ANY": b.get("SQ_ACTIVE_INST_ANY"), "clock_ghz": 2.4,
                               "source": "profiles/r02_pmc.txt, set head_sq"}
     for name in ("bound_sq", "outside_sq"):
-        v = pmc_values(name).get("blend_blocks_kernel", {})
+        pv = pmc_values(name)
+        # (sparse frames blend from the sorted lists: blend_wave_kernel)
+        v = pv.get("blend_blocks_kernel") or pv.get("blend_wave_kernel") or {}
         if v:
+            v = dict(v, kernel="blend_blocks_kernel" if "blend_blocks_kernel" in pv else "blend_wave_kernel")
             out[f"blend_insts_{name.split('_')[0]}"] = v
     json.dump(out, open(f"{DST}/pmc_traffic_r02.json", "w"), indent=1)
     for name in ("bench_default", "bench_backward", "bench_backward_outside", "bench_backward_nolists", "bench_backward_nolists_inria_sh3", "bench_4k", "bench_overlap", "bench_stress50M",

@@ -29,6 +29,8 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_d
 trace head $HEAD
 trace outside $SHORT --pose 0,0,-14
 trace bound $SHORT --opacity-scale 0.1
+trace stress50M $SHORT --scene stress --splats 50000000
+trace 4k $SHORT --width 3840 --height 2160
 # 3. PMC passes, headline frame
 pmc head_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $SHORT
 pmc head_fetch "FETCH_SIZE" $SHORT
