@@ -52,7 +52,7 @@ def _run(scene, cam, bg=(0.0, 0.0, 0.0), use_rects=True, **kw):
     return r, img
 
 
-def _compare_all(r, img, exp, n):
+def _compare_all(r, img, exp, n, expect_plan=None, max_bad_pixels=0):
     g = {k: v.cpu().numpy() for k, v in r.map_geometry_state().items()}
     assert np.array_equal(g["radii"], exp["radii"])
     assert np.array_equal(g["tilesTouched"].view(np.uint32), exp["tilesTouched"])
@@ -70,7 +70,7 @@ def _compare_all(r, img, exp, n):
         # depth alone on grids wider than 255 tiles. (The block plan writes the sorted lists
         # directly and keeps its block lists in the two "unsorted" arrays: nothing to compare.)
         gx, gy = (r.width + 15) // 16, (r.height + 15) // 16
-        assert r.last_plan == ("generic" if (gx > 255 or gy > 255) else PLAN)
+        assert r.last_plan == (expect_plan or ("generic" if (gx > 255 or gy > 255) else PLAN))
         ku, vu = b["keys_unsorted"].view(np.uint64), b["values_unsorted"].view(np.uint32)
         if r.last_plan != "blocks":
             o_g, o_e = np.lexsort((vu, ku)), np.lexsort((exp["values_unsorted"], exp["keys_unsorted"]))
@@ -91,8 +91,10 @@ def _compare_all(r, img, exp, n):
     im = {k: v.cpu().numpy() for k, v in r.map_image_state().items()}
     assert np.array_equal(im["ranges"].view(np.uint32), exp["ranges"])
     max_err, n_bad, _ = image_report(img, exp["out_color"], TOL)
-    assert max_err <= TOL, f"image max abs err {max_err}, {n_bad} pixels over {TOL}"
-    assert np.abs(im["finalT"] - exp["finalT"]).max() <= TOL
+    # (max_bad_pixels, frames of millions of pixels only: the hardware exponential against glibc's can flip a hard
+    # threshold — alpha >= 1/255, T < 0.001 — for a pixel that sits on it, which moves it by up to ~4e-3)
+    assert n_bad <= max_bad_pixels and max_err <= (TOL if max_bad_pixels == 0 else 5e-3), f"image max abs err {max_err}, {n_bad} pixels over {TOL}"
+    assert int((np.abs(im["finalT"] - exp["finalT"]) > TOL).sum()) <= max_bad_pixels
     flips = int((im["nContrib"].view(np.uint32) != exp["nContrib"]).sum())
     assert flips <= max(2, exp["nContrib"].size // 20000), f"{flips} nContrib mismatches"
     assert r.last_records_staged == exp["records_staged"]
@@ -136,6 +138,36 @@ def test_grid_wider_than_255_tiles_uses_generic_digit_passes():
     assert exp["num_rendered"] > 1000
     r, img = _run(scene, cam, (0.0, 0.1, 0.2))
     _compare_all(r, img, exp, 4000)
+
+
+@pytest.mark.parametrize("w,h,n,seed,xs", [(2500, 200, 6000, 13, 8.0), (3000, 330, 9000, 17, 9.5)])
+def test_grids_of_129_to_192_tile_columns(w, h, n, seed, xs):
+    """157 / 188 tile columns: the sort plan's column tables are laid out for 192 columns (its per-key column search
+    starts at 128), the block plan has 20 / 24 block columns and partial blocks on both edges."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.garden_like_scene(n, seed=seed)
+    scene["means3D"][:, :3] *= 0.2
+    scene["means3D"][:, 0] *= xs
+    cam = camera.default_camera(w, h, near=0.05, far=50.0)
+    exp = cpu_oracle.forward(scene, cam, (0.2, 0.1, 0.0))
+    assert exp["num_rendered"] > 5000
+    r, img = _run(scene, cam, (0.2, 0.1, 0.0))
+    _compare_all(r, img, exp, n)
+
+
+def test_more_than_512_tile_blocks_fall_back_to_the_sort_plan():
+    """4000 x 2400 -> 250 x 150 tiles = 32 x 19 = 608 blocks of 8 x 8 tiles: more than the block plan's tables hold
+    (kMaxBlocks = 512), so the sort plan runs whatever the flag says — with 250 tile columns in its 256-column tables."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.garden_like_scene(12000, seed=23)
+    scene["means3D"][:, :3] *= 0.25
+    cam = camera.default_camera(4000, 2400, near=0.05, far=50.0)
+    exp = cpu_oracle.forward(scene, cam, (0.0, 0.0, 0.0))
+    assert exp["num_rendered"] > 100000
+    r, img = _run(scene, cam, (0.0, 0.0, 0.0))
+    _compare_all(r, img, exp, 12000, expect_plan="sort", max_bad_pixels=10)
 
 
 def test_single_tile_row_and_single_tile_grids():
