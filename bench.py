@@ -18,7 +18,7 @@ row bands are exchanged inside the step (strong scaling: same frame, N GPUs); BA
 Workload at N=1: BASELINE config 2 — the Mip-NeRF360 garden .ply is not available offline, so the "garden-like"
 synthetic scene of SURVEY.md §8d stands in (same splat count, labelled so), at the reference's default pose. Extra keys
 at N=1 (measured after, and outside, the timed region of the headline): the same scene from a pose outside the cloud,
-a blend-bound variant (opacities x 0.1) and the forward-only mode without the sorted lists.
+and from far away, a blend-bound variant (opacities x 0.1) and the forward-only mode without the sorted lists.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -427,6 +427,10 @@ def main() -> int:
             cam_out = camera.default_camera(W, H, near=near, far=far, position=(0.0, 0.0, -14.0))
             e = run.measure(cam_out, **short, **draw_kw)
             extras["pose_outside"] = brief(e, n_splats, "eye (0,0,-14): the whole cloud in front of the camera, small splats, deep lists")
+            # (a') from far away: few instances per visible Gaussian (R/V = 5), the regime of the sort plan
+            cam_far = camera.default_camera(W, H, near=near, far=far, position=(0.0, 0.0, -30.0))
+            e = run.measure(cam_far, **short, **draw_kw)
+            extras["pose_far"] = brief(e, n_splats, "eye (0,0,-30): the cloud covers a part of the screen, one or two tiles per splat (sort plan)")
             # (b) forward-only callers: GSR_FLAG_NO_SORTED_LISTS on the headline frame
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["no_sorted_lists"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_SORTED_LISTS (block plan: the 12 R bytes of sorted keys / values are not written)")
