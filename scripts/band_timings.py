@@ -1,10 +1,10 @@
 """What one rank of a sharded 1080p frame does: per-band frame time and stage times (single GPU, one band at a time)."""
-import sys, os
+import sys, os  # noqa
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, time, bench
 from gsrast_amd import camera, sharding
 from gsrast_amd.rasterizer import SplatRasterizer
-sc, near, far, pos, label = bench.make_scene("garden_like", 5_834_784)
+sc, near, far, pos, label = bench.make_scene("garden_like", 5_834_784, torch.device("cuda", 0))
 cam = camera.default_camera(1920, 1080, near=near, far=far, position=pos)
 r = SplatRasterizer(1920, 1080); r.configure_from_scene(sc)
 print("#", label, "1920x1080; bands = uniform split of the 68 tile rows; times in ms")
