@@ -46,7 +46,7 @@ struct GeoScratch {
     uint32_t* depth_key;      // u32[N] depth bits or ~0 (written by preprocess)
     uint32_t* rect_idx;       // u32[N] packed band-clipped rectangle in index order (written by preprocess)
     uint32_t* sort_info;      // [0] distinct top-byte digits of the visible depth keys, [1] visible Gaussians V,
-                              // [2..3] u64: sum of tilesTouched without the u32 wrap-around
+                              // [2..3] u64: sum of tilesTouched without the u32 wrap-around, [4] tiles with a list
     uint32_t* vis_partial;    // per 4096-key chunk: visible keys before it (compaction)
     uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
     uint32_t *a_k, *a_v;      // depth-sort ping
@@ -438,7 +438,7 @@ int gsr_forward(gsr_forward_args* a) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, R, gs.block_scratch,
                                       bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, img.ranges, inria, stream,
-                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr));
+                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr, gs.sort_info + 4));
         if (profile) {
             // depth order + block lists | unit masks + prefixes + ranges (recorded as "sort_pass1") | emission
             g_rb.ev_alias_begin(GSR_STAGE_SORT_PASS1, GSR_STAGE_DEPTH_ORDER);
@@ -537,7 +537,7 @@ int gsr_forward(gsr_forward_args* a) {
     // :800-801 — under the block plan the ranges are the tile starts it has already computed
     if (!use_blocks) {
         GSR_BEGIN(GSR_STAGE_RANGES);
-        GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, inria, stream));
+        GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, inria, stream, gs.sort_info + 4));
         GSR_END(GSR_STAGE_RANGES);
     }
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
@@ -550,7 +550,7 @@ int gsr_forward(gsr_forward_args* a) {
     else
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                              t_cutoff, stream));                                                    // :804-810
+                              t_cutoff, stream, gs.sort_info + 4, R));                               // :804-810
     GSR_END(GSR_STAGE_BLEND);
     if (forked) GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));      // the sorted lists are complete too
 

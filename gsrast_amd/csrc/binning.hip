@@ -125,12 +125,14 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int n, const uint32_t* _
 // key of tile t and of tile t + 1 by two interleaved binary searches (2 x ~log2 R dependent loads).
 // Tiles that own no key get (0, 0) (the reference's memset) and the R == 1 quirk is kept: the lone tile is
 // never closed there, because the "last element closes its tile" test sits inside the else branch.
+// nonempty (may be null; zeroed by the caller's stream before this launch): += the tiles that got a list — the blend
+// decides from it whether the frame's tiles can fill the chip with one wave each (blend.hip).
 __global__ __launch_bounds__(256) void tile_ranges_search_kernel(const uint64_t* __restrict__ keys, uint32_t n,
                                                                  uint2* __restrict__ ranges, uint32_t num_tiles,
-                                                                 bool close_single) {
+                                                                 bool close_single, uint32_t* __restrict__ nonempty) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= num_tiles) return;
-    uint32_t lo_a = 0, hi_a = n, lo_b = 0, hi_b = n;      // lower bounds of tile t (a) and t + 1 (b)
+    const bool live = t < num_tiles;
+    uint32_t lo_a = 0, hi_a = live ? n : 0u, lo_b = 0, hi_b = live ? n : 0u;      // lower bounds of tile t (a) and t + 1 (b)
     while (lo_a < hi_a || lo_b < hi_b) {
         const uint32_t mid_a = lo_a + ((hi_a - lo_a) >> 1), mid_b = lo_b + ((hi_b - lo_b) >> 1);
         const uint32_t ka = (lo_a < hi_a) ? (uint32_t)(keys[mid_a] >> 32) : 0u;
@@ -139,8 +141,12 @@ __global__ __launch_bounds__(256) void tile_ranges_search_kernel(const uint64_t*
         if (lo_b < hi_b) { if (kb < t + 1) lo_b = mid_b + 1; else hi_b = mid_b; }
     }
     uint2 r = make_uint2(0u, 0u);
-    if (lo_b > lo_a && (n > 1 || close_single)) r = make_uint2(lo_a, lo_b);
-    ranges[t] = r;
+    if (live && lo_b > lo_a && (n > 1 || close_single)) r = make_uint2(lo_a, lo_b);
+    if (live) ranges[t] = r;
+    if (nonempty) {
+        const unsigned long long m = __ballot(r.y > r.x);
+        if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(nonempty, (uint32_t)__popcll(m));
+    }
 }
 
 }  // namespace
@@ -164,14 +170,15 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
     return GSR_OK;
 }
 
-int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream) {
+int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream,
+                       uint32_t* nonempty) {
     if (n == 0) {
         GSR_HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, stream));
         return GSR_OK;
     }
     if (n >= 0xFFFFFFFFull) return GSR_ERR_TOO_LARGE;
     hipLaunchKernelGGL(tile_ranges_search_kernel, dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, stream, keys,
-                       (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles, close_single);
+                       (uint32_t)n, reinterpret_cast<uint2*>(ranges), (uint32_t)num_tiles, close_single, nonempty);
     GSR_LAUNCH_CHECK("tile_ranges_search_kernel");
     return GSR_OK;
 }

@@ -31,7 +31,22 @@ struct BlendParams {
     float t_cutoff;                // transmittance below which a pixel is finished (0.001 gscuda, 1e-4 upstream)
     FrameDims dims;
     int num_tiles;                 // tiles in [row_begin,row_end)
+    const uint32_t* nonempty;      // tiles of the frame that have a list (device word), or null: never four waves per tile
+    int base_workgroups;           // workgroups of one wave per tile; the launch holds four times as many when nonempty is given
+    uint32_t num_rendered;         // R of the call (the lists' total length)
 };
+
+// One wave per tile leaves most of the chip idle when few tiles have a list, and the frame lasts as long as the slowest
+// of them. Four waves then share a tile: one 16 x 4 strip each, every wave walking the whole list but keeping, at
+// staging, only what can reach ITS strip. That repeats the walk four times and divides the compositing by up to four,
+// so it pays where the chip has room for the repeated walk (few tiles), or where the walk is short and the compositing
+// is the work (a scene seen from far away: short lists of splats smaller than a tile — eye (0,0,-50) on the bench
+// scene, 3 712 tiles with a list, 210 entries each on average: blend 0.84 -> 0.34 ms). With thousands of deep lists
+// the repeated walk costs more than the shorter chains save (full-screen frames with four waves per tile: 0.46 -> 1.27
+// ms from outside the cloud, 0.66 -> 1.01 ms from (0,0,-30): `gpurun_out/s12`).
+constexpr uint32_t kStripTilesAny = 1536;        // tiles with a list up to which four waves share a tile whatever the lists
+constexpr uint32_t kStripTilesShort = 4096;      // ... and up to which they do when the lists are short:
+constexpr uint32_t kStripMeanList = 1024;        // entries per tile with a list, on average
 
 // ---- one wave per tile, four pixels per lane ------------------------------------------------
 // Lane l owns pixels (x = l & 15, y = (l >> 4) + 4 k), k = 0..3, so slot k of the wave is the
@@ -47,13 +62,22 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
 
-    const int tile_local = tile_of_workgroup((int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    // workgroups [k * base, (k + 1) * base) are strip k of the tiles: the three extra sets leave at once unless the frame
+    // has few tiles with a list (they are the END of the launch, and a tile's four waves run on one XCD)
+    const int strip = (int)blockIdx.x / p.base_workgroups;
+    bool strips = false;
+    if (p.nonempty != nullptr) {
+        const uint32_t ne = *p.nonempty;
+        strips = ne <= kStripTilesAny || (ne <= kStripTilesShort && (unsigned long long)p.num_rendered <= (unsigned long long)kStripMeanList * ne);
+    }
+    if (strip != 0 && !strips) return;
+    const int tile_local = tile_of_workgroup((int)blockIdx.x - strip * p.base_workgroups, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
     if (tile_local < 0) return;
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
     const int lane = threadIdx.x;
     TileLanes s;
-    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height);
+    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height, strips ? strip : -1);
     const uint2 range = p.ranges[tile];
     const uint32_t total = range.y - range.x;          // unsigned wrap as in the reference
     unsigned long long staged = 0;
@@ -62,6 +86,10 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     TileFeed feed;
     feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
     feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
+    if (strips) {
+        feed.box.y_lo = (float)(ty * kTile + 4 * strip);
+        feed.box.y_hi = (float)min(ty * kTile + 4 * strip + 3, p.dims.height - 1);
+    }
     feed.total = total; feed.t_cutoff = p.t_cutoff;
     // batch k = list positions [64 k, 64 k + 64); ids are fetched two batches ahead, records one batch ahead
     auto next_batch = [&](uint32_t pos) {
@@ -113,8 +141,10 @@ int launch_footprint_test(int n, const float* xy, const float* conic_opacity, co
 int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
-                 unsigned long long* staged_counter, float t_cutoff, hipStream_t stream) {
+                 unsigned long long* staged_counter, float t_cutoff, hipStream_t stream, const uint32_t* nonempty_tiles,
+                 uint32_t num_rendered) {
     BlendParams p;
+    p.num_rendered = num_rendered;
     p.ranges = reinterpret_cast<const uint2*>(ranges);
     p.point_list = point_list;
     p.means2D = reinterpret_cast<const float2*>(means2D);
@@ -129,7 +159,10 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     p.dims = d;
     p.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
     if (p.num_tiles <= 0) return GSR_OK;
-    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)patch_workgroups(d.grid_x, d.row_end - d.row_begin)), dim3(kWave), 0, stream, p);
+    // (not when the staged records are counted: that count is per tile, the reference's "whole tile done" test)
+    p.nonempty = staged_counter ? nullptr : nonempty_tiles;
+    p.base_workgroups = patch_workgroups(d.grid_x, d.row_end - d.row_begin);
+    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups * (p.nonempty ? 4 : 1))), dim3(kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;
 }

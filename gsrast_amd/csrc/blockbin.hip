@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(BlockMeta meta, int n
 // `close_single` (the upstream behaviour) is asked for.
 __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __restrict__ tile_count, uint32_t tiles,
                                                           uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
-                                                          uint32_t r_total, bool close_single) {
+                                                          uint32_t r_total, bool close_single, uint32_t* __restrict__ nonempty) {
     __shared__ uint32_t s_ws[16];
     const uint32_t per = (tiles + 1023) / 1024;
     const uint32_t a = min(tiles, threadIdx.x * per), z = min(tiles, a + per);
@@ -382,14 +382,26 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
     uint32_t running = incl - s;
     for (int w = 0; w < wave; ++w) running += s_ws[w];
     const bool closed = r_total > 1u || close_single;
+    int with_list = 0;
 #pragma unroll 8
     for (uint32_t t = a; t < z; ++t) {
         const uint32_t c = tile_count[t];
         tile_start[t] = running;
         ranges[t] = (c != 0u && closed) ? make_uint2(running, running + c) : make_uint2(0u, 0u);
+        with_list += (c != 0u && closed) ? 1 : 0;
         running += c;
     }
     if (threadIdx.x == 1023) tile_start[tiles] = running;
+    // the tiles that got a list (the blend from the sorted lists asks whether they can fill the chip, blend.hip)
+    __shared__ int s_with[16];
+    for (int off = 32; off > 0; off >>= 1) with_list += __shfl_xor(with_list, off, kWave);
+    if (lane == 0) s_with[wave] = with_list;
+    __syncthreads();
+    if (threadIdx.x == 0 && nonempty) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_with[w];
+        *nonempty = (uint32_t)tot;
+    }
 }
 
 // ---- emission ------------------------------------------------------------------------------------
@@ -759,7 +771,7 @@ BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
                          int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
-                         hipEvent_t ev_coarse_end) {
+                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
     if (t.chunk == kCoarse)
         hipLaunchKernelGGL(coarse_count_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_rect, t.nbx, t.nbp,
@@ -799,7 +811,7 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     hipLaunchKernelGGL(block_prefix_kernel, dim3(t.nb), dim3(256), 0, stream, t.meta, t.nbx, grid_x, grid_y, t.cnt, t.tile_count);
     GSR_LAUNCH_CHECK("block_prefix_kernel");
     hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(1024), 0, stream, t.tile_count, t.tiles, t.tile_start,
-                       reinterpret_cast<uint2*>(ranges), r_total, close_single);
+                       reinterpret_cast<uint2*>(ranges), r_total, close_single, nonempty_tiles);
     GSR_LAUNCH_CHECK("tile_start_kernel");
     return GSR_OK;
 }

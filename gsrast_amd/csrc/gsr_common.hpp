@@ -97,7 +97,7 @@ size_t blockbin_bin_bytes(size_t r);
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
                          int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
-                         hipEvent_t ev_coarse_end);
+                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles = nullptr);
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
                       const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream);
 int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
@@ -105,12 +105,15 @@ int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_s
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                         unsigned long long* staged_counter, float t_cutoff, hipStream_t stream);
 
-int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream);
+// nonempty (may be null): device word, zero before the launch; receives the number of tiles that got a list
+int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream,
+                       uint32_t* nonempty = nullptr);
 
 int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* point_list,
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
-                 unsigned long long* staged_counter, float t_cutoff, hipStream_t stream);
+                 unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
+                 const uint32_t* nonempty_tiles = nullptr, uint32_t num_rendered = 0);      // (both: see blend.hip, four waves per tile)
 
 int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,
                           uint8_t* misses, hipStream_t stream);

@@ -485,9 +485,13 @@ namespace {
 // How many distinct digits the top byte of the visible keys takes (one thread per digit; culled Gaussians'
 // 0xFFFFFFFF sentinels are compacted away before the histogram, so digit 255 is a real depth — the top byte
 // of a negative NaN, which passes the reference's frustum test — and counts like any other).
+// (out[4]: the frame's count of tiles with a list, accumulated later by the tile-range kernel, starts at zero here)
 __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __restrict__ hist_top, uint32_t* __restrict__ out) {
     const int c = __syncthreads_count(hist_top[threadIdx.x] != 0u);
-    if (threadIdx.x == 0) *out = (uint32_t)c;
+    if (threadIdx.x == 0) {
+        out[0] = (uint32_t)c;
+        out[4] = 0u;
+    }
 }
 
 // ---- visible keys first: stable compaction of the keys that are not the 0xFFFFFFFF sentinel --------
@@ -627,7 +631,8 @@ size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChu
 
 // Depth keys of the visible Gaussians first (stable: index order), their count, the digit histograms of
 // the four sort passes, and (top_digits) the number of distinct top-byte digits: with at most one the
-// fourth pass would move nothing. info[0] = top_digits, info[1] = visible count (device words).
+// fourth pass would move nothing. info[0] = top_digits, info[1] = visible count (device words); info[4] is zeroed
+// (the frame's non-empty-tile counter; info must hold at least five words).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready,
                      const uint32_t* rect_by_index, uint32_t* out_r) {

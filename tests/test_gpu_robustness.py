@@ -265,6 +265,12 @@ def test_plan_and_blend_feed_follow_the_instances_per_visible_gaussian():
             assert r.last_num_rendered == R and r.last_records_staged == staged, (z, kw)
             for k, v in r.map_image_state().items():
                 assert torch.equal(v, st[k]), (z, kw, k)
+            # without the staged-record count the blend from the sorted lists may give a tile four waves (one 16 x 4 strip
+            # each) when few tiles have a list — the far poses here: same pixels, finalT, nContrib
+            other = r.draw(cam, **kw)
+            assert torch.equal(other, img), (z, kw, "uncounted")
+            for k, v in r.map_image_state().items():
+                assert torch.equal(v, st[k]), (z, kw, k, "uncounted")
     assert len(seen) == 3, seen          # the poses cover: sort plan, block plan fed from the sorted lists, block plan fed from the block lists
 
 
