@@ -8,7 +8,10 @@
 // written front to back by whoever owns the tile. Owners are wavefronts, one lane per tile of an
 // 8 x 8 tile block:
 //   coarse_count / blockscan_* / coarse_emit : the depth-ordered list is split, stably, into one
-//       list per tile block (entries = rectangle, depth bits, index; 12 B, E <= R of them)
+//       list per tile block (entries = rectangle, depth bits, index; 12 B, E <= R of them); a
+//       chunk's entries leave in (block, rank) order, one per lane: whole lines per block
+//   blend_blocks : ... on frames of large splats (48 or more instances per visible Gaussian, or
+//       when the sorted lists are not written); sparser frames blend from the sorted lists (blend.hip)
 //   unit_masks   : a unit = 2048 consecutive entries of one block list; its coverage bit masks
 //       (entries x tile columns / rows, transposed with v_writelane) and, from their bit counts,
 //       the keys per (unit, tile)
