@@ -67,6 +67,9 @@ def parse_args():
                    help="GSR_FLAG_OVERLAP_EMIT: block plan's emission on a second stream beside the blend (shorter frames, "
                         "but per-kernel times are then those of kernels sharing the chip)")
     p.add_argument("--no-sorted-lists", action="store_true", help="GSR_FLAG_NO_SORTED_LISTS for the headline frame (forward-only callers)")
+    p.add_argument("--colors-precomp", action="store_true",
+                   help="pass the colours as the reference's colorsPrecomp argument (GSCuda.cuh:111), computed once per scene by "
+                        "gsr_colors_from_dc: the preprocess then reads no SH and writes no geomState.rgb (gscuda semantics)")
     p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: a free one)")
     p.add_argument("--dry-run", action="store_true",
@@ -223,7 +226,7 @@ class Runner:
         if exch:
             exch.gather(frame)
             torch.cuda.current_stream(self.device).synchronize()
-            self.capi.check(rast.lib.gsr_poll_async_error(), "gsr_forward (device side)")
+            rast.poll_async_error()
         return frame
 
     def sync_all(self):
@@ -295,7 +298,7 @@ class Runner:
         return out
 
 
-def alg_bytes(m, N, W, H, grid_x, sh_floats_read):
+def alg_bytes(m, N, W, H, grid_x, sh_floats_read, colors_precomp=False):
     """ALGORITHMIC bytes per launch on THIS rank (SURVEY.md §8d / BASELINE.md §2). N splats, V visible, R instances,
     R_f records staged by the blend, P pixels, T tiles of this rank's band."""
     rows = m["tile_rows"]
@@ -304,7 +307,8 @@ def alg_bytes(m, N, W, H, grid_x, sh_floats_read):
     V, R, r_f = m["visible_band"], m["num_rendered"], m["records_staged"]
     blocks = m["plan"] == "blocks"
     return {
-        "preprocess": N * (52 + 4 * sh_floats_read + 8) + V * 72,
+        # (colorsPrecomp: neither the SH read nor the 12-byte rgb record of a visible Gaussian)
+        "preprocess": N * (52 + (0 if colors_precomp else 4 * sh_floats_read) + 8) + V * (60 if colors_precomp else 72),
         "scan": 8 * N,
         # sort plan: the emission kernel of SURVEY.md §8d. block plan: block_emit_kernel writes the
         # SORTED pairs once (12 B each); its block-list reads (12 B per entry, E <= R) are not counted.
@@ -413,12 +417,12 @@ def main() -> int:
         assert not distributed, "--backward is a single-GPU configuration"
         run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
     draw_kw = dict(plan=args.plan, overlap_emit=args.overlap, semantics=args.semantics, sh_degree=args.sh_degree,
-                   sorted_lists=not args.no_sorted_lists)
+                   sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp)
     m = run.measure(cam, args.steps, args.warmup, **draw_kw)
 
     default_frame = (args.scene == "garden_like" and args.splats == DEFAULT_SPLATS and (W, H) == (1920, 1080) and not args.pose
                      and args.opacity_scale == 1.0 and not inria and not args.backward and args.plan == "auto"
-                     and not args.overlap and not args.no_sorted_lists)
+                     and not args.overlap and not args.no_sorted_lists and not args.colors_precomp)
     extras = {}
     if not args.no_extras and default_frame:
         short = dict(steps=max(5, min(args.steps, 15)), warmup=3)
@@ -434,6 +438,15 @@ def main() -> int:
             # (b) forward-only callers: GSR_FLAG_NO_SORTED_LISTS on the headline frame
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["no_sorted_lists"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_SORTED_LISTS (block plan: the 12 R bytes of sorted keys / values are not written)")
+            # (b') the caller-side route the reference's signature offers around the 192-byte-stride DC read: colorsPrecomp
+            e = run.measure(cam, **short, **{**draw_kw, "colors_precomp": True})
+            b = brief(e, n_splats, "headline frame with the colours passed as colorsPrecomp (GSCuda.cuh:111; computed once per scene, "
+                                   "0.5 + 0.4 DC is view-independent): same pixels bit for bit, the preprocess reads no SH and writes no rgb")
+            pb = alg_bytes(e, n_splats, W, H, run.grid_x, 3, colors_precomp=True)["preprocess"]
+            pms = e["stage_ms"].get("preprocess", 0.0)
+            b["preprocess"] = {"ms": round(pms, 4), "alg_bytes": int(pb), "gbs": round(pb / max(pms, 1e-9) / 1e6, 1),
+                               "frac_hbm": round(pb / max(pms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+            extras["colors_precomp"] = b
             # (c) blend-bound variant: opacities x 0.1, so pixels saturate late and the blend stages most of R
             saved = run.rast.opacities
             run.rast.opacities = (saved * 0.1).contiguous()
@@ -469,7 +482,7 @@ def main() -> int:
         ms_per_step = m["ms_per_step"]
         stage_ms = dict(m["stage_ms"])
         blocks = m["plan"] == "blocks"
-        alg = alg_bytes(m, n_splats, W, H, grid_x, 48 if full_sh else 3)
+        alg = alg_bytes(m, n_splats, W, H, grid_x, 48 if full_sh else 3, colors_precomp=args.colors_precomp)
         kernels = kernel_table(m, alg)
         dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"), key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
@@ -516,7 +529,8 @@ def main() -> int:
                        "width": W, "height": H, "splats": n_splats, "visible": m["visible"], "num_rendered": m["num_rendered_total"],
                        "records_staged": m["records_staged_total"],
                        "minstances_per_s": round(m["num_rendered_total"] / (ms_per_step * 1e-3) / 1e6, 2),
-                       "semantics": args.semantics + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)"),
+                       "semantics": args.semantics + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)")
+                                    + (", colours passed as colorsPrecomp" if args.colors_precomp else ""),
                        "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "rccl_ranks": world if distributed else 0,
                        "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "bands": m["bands"], "per_rank": m["per_rank"]},

@@ -54,6 +54,25 @@ class BinningState(C.Structure):
                 ("values", C.c_void_p), ("sorting_size", C.c_size_t), ("sorting_space", C.c_void_p)]
 
 
+GSR_RECEIPT_MAGIC = 0x31525347
+GSR_LISTS_SKIPPED_STAMP = 0xFFFFFFFF
+
+
+class ForwardReceipt(C.Structure):
+    """gsr_forward_receipt: plain data, copied by value (ctypes copies nested structures on assignment)."""
+    _fields_ = [("magic", C.c_uint32), ("plan_used", C.c_uint32),
+                ("num_gaussians", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
+                ("num_rendered", C.c_uint32), ("num_visible", C.c_uint32), ("serial", C.c_uint32),
+                ("geometry_chunk", C.c_void_p), ("image_chunk", C.c_void_p), ("binning_chunk", C.c_void_p),
+                ("async_words", C.c_void_p)]
+
+    def copy(self) -> "ForwardReceipt":
+        r = ForwardReceipt()
+        C.memmove(C.byref(r), C.byref(self), C.sizeof(ForwardReceipt))
+        return r
+
+
 class ForwardArgs(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("flags", C.c_uint32),
@@ -72,6 +91,7 @@ class ForwardArgs(C.Structure):
         ("num_rendered", C.c_uint32), ("records_staged", C.c_uint64),
         ("stage_ms", C.c_float * GSR_NUM_STAGES),
         ("plan_used", C.c_uint32),
+        ("receipt", ForwardReceipt),
     ]
 
 
@@ -96,6 +116,7 @@ class BackwardArgs(C.Structure):
         ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
         ("stage_ms", C.c_float * 2),
         ("cam_pos", C.c_void_p), ("shs", C.c_void_p), ("clamped", C.c_void_p), ("sh_dims", C.c_int32),
+        ("receipt", ForwardReceipt),
     ]
 
 
@@ -115,7 +136,7 @@ SIGNATURES = {
     "gsr_last_error": (C.c_int, []),
     "gsr_error_string": (C.c_char_p, [C.c_int]),
     "gsr_last_hip_error": (C.c_char_p, []),
-    "gsr_poll_async_error": (C.c_int, []),
+    "gsr_poll_async_error": (C.c_int, [C.POINTER(ForwardReceipt)]),
     "gsr_higher_msb": (C.c_uint32, [C.c_uint32]),
     "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),
     "gsr_inclusive_scan_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -125,6 +146,7 @@ SIGNATURES = {
     "gsr_ply_parse_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "gsr_ply_activate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "gsr_colors_from_dc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_footprint_misses_tile": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsr_ply_activate_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]),

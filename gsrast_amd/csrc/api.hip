@@ -103,14 +103,17 @@ BinScratch carve_bin_scratch(char* base, size_t r) {
 }
 
 // Pinned landing zone for the numRendered read-back plus the events / side stream of a call: one per host
-// thread AND device (events and streams belong to the device that was current when they were created).
+// thread AND device (events and streams belong to the device that was current when they were created). These are
+// resources, not state: nothing a later call needs to know about an earlier one is kept here — that travels in the
+// gsr_forward_receipt, and lives in the caller's chunks.
+constexpr uint32_t kAsyncSlots = 64;       // error-word slots handed out in turn, one per gsr_forward call
+constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned block
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
-    uint32_t* host = nullptr;          // [0] unused, [1] / [2] onesweep error words (written by the kernels themselves), [3] top digits, [4] V,
-                                       // [5..6] u64 un-wrapped instance count, [8..9] staged count
-    const void* lists_skipped = nullptr;   // `values` of the last call made with GSR_FLAG_NO_SORTED_LISTS under the block plan
-    const void* feed_for = nullptr;        // `values` of the last call that ran the block plan ...
-    BlockFeed feed = {};                   // ... and where that call left its block lists (gsr_backward reads tile lists there)
+    uint32_t* host = nullptr;          // [3] top digits, [4] V, [5..6] u64 un-wrapped instance count, [8..9] staged count;
+                                       // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
+                                       // written by the kernels themselves), serial of the owning call, 0}
+    uint32_t serial = 0;               // calls made so far by this thread on this device
     unsigned long long* staged_dev = nullptr;
     unsigned long long* staged_host = nullptr;
     hipEvent_t ev[2 * GSR_NUM_STAGES] = {};   // [2s] start, [2s+1] end of stage s
@@ -131,7 +134,9 @@ struct Readback {
     }
     int ensure() {
         if (!host) {
-            GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocMapped));
+            const size_t bytes = sizeof(uint32_t) * (kAsyncBase + 4 * kAsyncSlots);
+            GSR_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&host), bytes, hipHostMallocMapped));
+            memset(host, 0, bytes);
             GSR_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), host, 0));
             staged_host = reinterpret_cast<unsigned long long*>(host + 8);
         }
@@ -151,9 +156,8 @@ struct Readback {
     }
 };
 static thread_local std::map<int, Readback> g_rb_by_device;
-static thread_local Readback* g_rb_last = nullptr;      // the state of this thread's most recent gsr_forward call
 
-// The calling thread's state for the CURRENT device.
+// The calling thread's resources for the CURRENT device.
 int current_readback(Readback*& out) {
     int dev = 0;
     GSR_HIP_TRY(hipGetDevice(&dev));
@@ -163,13 +167,40 @@ int current_readback(Readback*& out) {
 
 }  // namespace
 
-bool forward_skipped_sorted_lists(const void* point_list) {
-    return g_rb_last && g_rb_last->lists_skipped && g_rb_last->lists_skipped == point_list;
-}
-bool forward_left_block_feed(const void* point_list, BlockFeed* out) {
-    if (!(g_rb_last && g_rb_last->feed_for && g_rb_last->feed_for == point_list)) return false;
-    *out = g_rb_last->feed;
-    return true;
+// What a gsr_backward call may read of the forward call that issued `r` (see gsr_backward_args.receipt): derived from
+// the receipt and the chunk layouts alone — no state of this library is consulted, so any host thread may ask, after any
+// number of other calls, as long as the chunks are as that call left them.
+int lists_of_receipt(const gsr_forward_receipt& r, int n, int width, int height, int row_begin, int row_end,
+                     const void* point_list, BlockFeed* feed, bool* from_blocks, bool* lists_written) {
+    *from_blocks = false;
+    *lists_written = true;
+    if (r.magic != GSR_RECEIPT_MAGIC) return GSR_ERR_INVALID_ARG;
+    if (r.num_gaussians != n || r.width != width || r.height != height || r.tile_row_begin != row_begin ||
+        r.tile_row_end != row_end || !r.geometry_chunk || !r.image_chunk)
+        return GSR_ERR_INVALID_ARG;
+    if (r.num_rendered == 0) return GSR_OK;                     // (no binning chunk, no lists: the caller zeroes its outputs)
+    if (!r.binning_chunk) return GSR_ERR_INVALID_ARG;
+    gsr_binning_state bin;
+    gsr_binning_from_chunk(r.binning_chunk, r.num_rendered, &bin);
+    if (point_list != bin.values) return GSR_ERR_INVALID_ARG;
+    *lists_written = !(r.plan_used & GSR_PLAN_LISTS_SKIPPED);
+    // (not after a blend from the sorted lists: BlockMeta::walked, which bounds the per-entry sums, is the block-fed
+    // blend's by-product; the backward then takes the sorted lists for every tile)
+    if ((r.plan_used & 0xFFu) == GSR_PLAN_BLOCKS && !(r.plan_used & GSR_PLAN_BLEND_FROM_LISTS)) {
+        gsr_geometry_state geom;
+        gsr_geometry_from_chunk(r.geometry_chunk, n, &geom);
+        const GeoScratch gs = carve_geo_scratch(geom.scanning_space, (size_t)n);
+        const int grid_x = (width + kTile - 1) / kTile, grid_y = (height + kTile - 1) / kTile;
+        // the block lists (read by nothing else once the forward call is complete) and, for the per-entry gradient sums,
+        // the 8 R bytes of keysUnsorted: the (rectangle | depth) halves of the block-list entries there are dead after
+        // the unit masks and the emission
+        *feed = block_feed((int)r.num_visible, grid_x, grid_y, r.num_rendered, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
+        feed->acc = reinterpret_cast<float*>(bin.keys_unsorted);
+        feed->acc_floats = 2ull * (unsigned long long)r.num_rendered;
+        *from_blocks = true;
+    }
+    if (!*from_blocks && !*lists_written) return GSR_ERR_INVALID_ARG;
+    return GSR_OK;
 }
 
 }  // namespace gsr
@@ -257,6 +288,13 @@ int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const ui
     return fail(launch_sort_pairs(keys_in, keys_out, values_in, values_out, n, begin_bit, end_bit, temp, (hipStream_t)stream));
 }
 
+int gsr_colors_from_dc(int n, const float* shs, float* colors, void* stream) {
+    g_hip_error[0] = 0;
+    if (n <= 0) return fail(GSR_OK);
+    if (!shs || !colors) return fail(GSR_ERR_INVALID_ARG);
+    return fail(launch_colors_from_dc(n, shs, colors, (hipStream_t)stream));
+}
+
 int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_opacity, const int32_t* tile_xy, int width,
                               int height, uint8_t* misses, void* stream) {
     g_hip_error[0] = 0;
@@ -264,8 +302,11 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
     return fail(launch_footprint_test(n, means2D, conic_opacity, tile_xy, width, height, misses, (hipStream_t)stream));
 }
 
-int gsr_poll_async_error(void) {
-    if (g_rb_last && g_rb_last->host && (g_rb_last->host[1] || g_rb_last->host[2])) return fail(GSR_ERR_INTERNAL);
+int gsr_poll_async_error(const gsr_forward_receipt* r) {
+    if (!r || r->magic != GSR_RECEIPT_MAGIC || !r->async_words) return fail(GSR_ERR_INVALID_ARG);
+    const volatile uint32_t* w = r->async_words;
+    if (w[2] != r->serial) return GSR_OK;                 // the slot has a new owner: nothing is known about that call any more
+    if (w[0] || w[1]) return fail(GSR_ERR_INTERNAL);
     return GSR_OK;
 }
 
@@ -276,6 +317,7 @@ int gsr_forward(gsr_forward_args* a) {
     a->records_staged = 0;
     a->plan_used = 0;
     memset(a->stage_ms, 0, sizeof(a->stage_ms));
+    memset(&a->receipt, 0, sizeof(a->receipt));
     const int n = a->num_gaussians;
     if (n <= 0 || a->width <= 0 || a->height <= 0 || !a->geometry_alloc || !a->binning_alloc || !a->image_alloc ||
         !a->background || !a->means3D || !a->opacities || !a->view_matrix || !a->proj_matrix || !a->out_color ||
@@ -294,9 +336,6 @@ int gsr_forward(gsr_forward_args* a) {
     Readback* rbp = nullptr;
     if ((rc = current_readback(rbp)) != GSR_OK) return fail(rc);
     Readback& g_rb = *rbp;
-    g_rb_last = rbp;
-    g_rb.lists_skipped = nullptr;
-    g_rb.feed_for = nullptr;
     if ((rc = g_rb.ensure()) != GSR_OK) return fail(rc);
     if (profile && (rc = g_rb.ensure_events()) != GSR_OK) return fail(rc);
     if (count_staged && (rc = g_rb.ensure_staged()) != GSR_OK) return fail(rc);
@@ -335,7 +374,27 @@ int gsr_forward(gsr_forward_args* a) {
 #define GSR_STEP(call) do { rc = (call); if (rc != GSR_OK) return fail(rc); } while (0)
 
     const GeoScratch gs = carve_geo_scratch(geom.scanning_space, (size_t)n);
-    g_rb.host[1] = g_rb.host[2] = 0;
+    // This call's error words: the next of the slots (the call that owned it 64 calls ago is long complete: the host
+    // has waited for every call's read-back since). Zeroed here, written only by a kernel whose bounded look-back spin
+    // gave up, read by gsr_poll_async_error through the receipt.
+    const uint32_t serial = ++g_rb.serial;
+    const uint32_t slot_at = kAsyncBase + 4u * (serial % kAsyncSlots);
+    g_rb.host[slot_at] = g_rb.host[slot_at + 1] = g_rb.host[slot_at + 3] = 0;
+    g_rb.host[slot_at + 2] = serial;
+    uint32_t* const err_n = g_rb.host_dev + slot_at;          // N-sized depth sort
+    uint32_t* const err_r = g_rb.host_dev + slot_at + 1;      // R-sized sort (sort plan, generic plan)
+    // what the caller takes away from this call (complete once GSR_OK is certain)
+    auto issue_receipt = [&](uint32_t nv, char* bin_chunk_or_null) {
+        gsr_forward_receipt& rc_ = a->receipt;
+        rc_.plan_used = a->plan_used;
+        rc_.num_gaussians = n; rc_.width = a->width; rc_.height = a->height;
+        rc_.tile_row_begin = d.row_begin; rc_.tile_row_end = d.row_end;
+        rc_.num_rendered = a->num_rendered; rc_.num_visible = nv;
+        rc_.serial = serial;
+        rc_.geometry_chunk = geo_chunk; rc_.image_chunk = img_chunk; rc_.binning_chunk = bin_chunk_or_null;
+        rc_.async_words = g_rb.host + slot_at;
+        rc_.magic = GSR_RECEIPT_MAGIC;
+    };
     for (bool& r : g_rb.recorded) r = false;
     for (int s = 0; s < GSR_NUM_STAGES; ++s) g_rb.begin_of[s] = 2 * s;
 
@@ -362,7 +421,7 @@ int gsr_forward(gsr_forward_args* a) {
     SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
     // "a bounded look-back spin gave up" is written by the kernel straight into the pinned host words (it never
     // happens on a healthy device; a copy at the end of every frame for it cost 5 us of stream time)
-    for (auto& f : four) f.error_word = g_rb.host_dev + 1;
+    for (auto& f : four) f.error_word = err_n;
     // Only Gaussians with at least one tile in this call take part from here on (V of N: 52 % on the
     // bench frame, a few per cent per rank when the frame is sharded): their (depth key, index) pairs
     // are compacted in index order — the same kernels count the digits of the four sort passes.
@@ -402,6 +461,7 @@ int gsr_forward(gsr_forward_args* a) {
     a->num_rendered = R;
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
     if (R == 0) {
+        issue_receipt((uint32_t)nv, nullptr);
         if (!inria) return fail(GSR_OK);                                                    // :775-778
         // upstream still runs the tile loop: every pixel gets the background
         GSR_HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
@@ -438,7 +498,8 @@ int gsr_forward(gsr_forward_args* a) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, R, gs.block_scratch,
                                       bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, img.ranges, inria, stream,
-                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr, gs.sort_info + 4));
+                                      profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr, gs.sort_info + 4,
+                                      (a->flags & GSR_FLAG_NO_SORTED_LISTS) ? bin.values : nullptr));
         if (profile) {
             // depth order + block lists | unit masks + prefixes + ranges (recorded as "sort_pass1") | emission
             g_rb.ev_alias_begin(GSR_STAGE_SORT_PASS1, GSR_STAGE_DEPTH_ORDER);
@@ -465,22 +526,14 @@ int gsr_forward(gsr_forward_args* a) {
             emit_stream = g_rb.side;
             forked = true;
         }
-        // What a gsr_backward call after this one may use: the block lists (read by nothing else once this call is
-        // complete) and, for its per-entry gradient sums, the 8 R bytes of keysUnsorted — the (rectangle | depth) halves
-        // of the block-list entries there are dead after the unit masks and the emission.
-        g_rb.feed = block_feed(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space);
-        g_rb.feed.acc = reinterpret_cast<float*>(bin.keys_unsorted);
-        g_rb.feed.acc_floats = 2ull * (unsigned long long)R;
-        // (not after a blend from the sorted lists: BlockMeta::walked, which bounds the per-entry sums, is the block-fed
-        // blend's by-product; gsr_backward then takes the sorted lists for every tile)
-        g_rb.feed_for = blend_from_lists ? nullptr : bin.values;
+        // (What a gsr_backward call after this one may use — the block lists and, for its per-entry gradient sums, the
+        // bytes of keysUnsorted — it works out from the receipt: lists_of_receipt.)
         if (blend_from_lists) a->plan_used |= GSR_PLAN_BLEND_FROM_LISTS;
         // GSR_FLAG_NO_SORTED_LISTS: this plan's blend reads the block lists, and no caller of the reference reads
         // BinningState (GSGaussians.cpp:214-219 maps GeometryState only): a forward-only caller may skip the 12 R
         // bytes of sorted keys / values altogether. keys / values are then left unwritten.
         if (a->flags & GSR_FLAG_NO_SORTED_LISTS) {
-            g_rb.lists_skipped = bin.values;
-            a->plan_used |= GSR_PLAN_LISTS_SKIPPED;
+            a->plan_used |= GSR_PLAN_LISTS_SKIPPED;        // (values[0] = GSR_LISTS_SKIPPED_STAMP: written with the tile ranges)
         } else {
             if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
             GSR_STEP(launch_block_emit(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
@@ -494,7 +547,7 @@ int gsr_forward(gsr_forward_args* a) {
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
         SweepScratch bsw = bs.sweep;
-        bsw.error_word = g_rb.host_dev + 2;
+        bsw.error_word = err_r;
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bsw, R, (uint32_t)d.grid_y, stream));
         // one pass: with a single tile row the column-major list is already the sorted list
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
@@ -531,7 +584,7 @@ int gsr_forward(gsr_forward_args* a) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
         GSR_BEGIN(GSR_STAGE_SORT_PASS2);
         GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, 32, end_bit,
-                                   bin.sorting_space, stream, g_rb.host_dev + 2));
+                                   bin.sorting_space, stream, err_r));
         GSR_END(GSR_STAGE_SORT_PASS2);
     }
     // :800-801 — under the block plan the ranges are the tile starts it has already computed
@@ -572,6 +625,7 @@ int gsr_forward(gsr_forward_args* a) {
 #undef GSR_BEGIN
 #undef GSR_END
 #undef GSR_STEP
+    issue_receipt((uint32_t)nv, bin_chunk);
     return fail(GSR_OK);
 }
 

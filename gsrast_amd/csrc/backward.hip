@@ -708,7 +708,18 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     }
 }
 
-static thread_local hipEvent_t g_bw_ev[3] = {nullptr, nullptr, nullptr};
+// Events of one profiled call: created on the device that is current for THIS call, destroyed when it returns.
+struct CallEvents {
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int create() {
+        for (auto& e : ev) GSR_HIP_TRY(hipEventCreate(&e));
+        return GSR_OK;
+    }
+    ~CallEvents() {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
 
 }  // namespace
 }  // namespace gsr
@@ -720,7 +731,7 @@ static int backward_impl(gsr_backward_args* a) {
     a->stage_ms[0] = a->stage_ms[1] = 0.0f;
     const int n = a->num_gaussians;
     if (n <= 0 || a->width <= 0 || a->height <= 0 || !a->background || !a->means2D || !a->conic_opacity || !a->colors ||
-        !a->ranges || !a->point_list || !a->n_contrib || !a->final_t || !a->dL_dout_color || !a->dL_dmean2D ||
+        !a->ranges || !a->n_contrib || !a->final_t || !a->dL_dout_color || !a->dL_dmean2D ||
         !a->dL_dconic_opacity || !a->dL_dcolors)
         return GSR_ERR_INVALID_ARG;
     if (a->dL_dcov3D && (!a->cov3D || !a->means3D || !a->view_matrix || !a->radii)) return GSR_ERR_INVALID_ARG;
@@ -730,16 +741,14 @@ static int backward_impl(gsr_backward_args* a) {
     const bool inria = (a->flags & GSR_FLAG_SEMANTICS_INRIA) != 0;
     // the upstream profile's chain needs what its colour was computed from
     if (inria && a->dL_dshs && (!a->shs || !a->cam_pos || !a->clamped || !a->means3D)) return GSR_ERR_INVALID_ARG;
-    // The forward call ran the block plan: its block lists serve the tiles of shallow blocks (per-entry gradient sums,
-    // see block_acc_fits) and, if it left the sorted lists unwritten (GSR_FLAG_NO_SORTED_LISTS), all tiles.
-    BlockFeed feed = {};
-    const bool from_blocks = forward_left_block_feed(a->point_list, &feed);
-    const bool lists_written = !forward_skipped_sorted_lists(a->point_list);
-    if (!from_blocks && !lists_written) return GSR_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)a->stream;
     const bool profile = (a->flags & GSR_FLAG_PROFILE) != 0;
-    if (profile && !g_bw_ev[0])
-        for (auto& e : g_bw_ev) GSR_HIP_TRY(hipEventCreate(&e));
+    CallEvents g_bw;
+    hipEvent_t* const g_bw_ev = g_bw.ev;
+    if (profile) {
+        const int rc = g_bw.create();
+        if (rc != GSR_OK) return rc;
+    }
 
     FrameDims d;
     d.width = a->width; d.height = a->height;
@@ -749,9 +758,39 @@ static int backward_impl(gsr_backward_args* a) {
         if (a->tile_row_begin < 0 || a->tile_row_end > d.grid_y || a->tile_row_begin > a->tile_row_end) return GSR_ERR_INVALID_ARG;
         d.row_begin = a->tile_row_begin; d.row_end = a->tile_row_end;
     }
+    // Which lists the forward call left (see gsr_backward_args.receipt). With a receipt: from the receipt and the chunk
+    // layouts — where that call ran the block plan, its block lists serve the tiles of shallow blocks (per-entry gradient
+    // sums, see block_acc_fits) and, if it left the sorted lists unwritten (GSR_FLAG_NO_SORTED_LISTS), all tiles. Without
+    // one only the reference's contract can hold (sorted lists in point_list), and whether it does is read off
+    // point_list[0]: a call that skipped the lists left GSR_LISTS_SKIPPED_STAMP there.
+    BlockFeed feed = {};
+    bool from_blocks = false, lists_written = true;
+    const bool have_receipt = a->receipt.magic != 0;        // (any other magic than the library's: refused below)
+    bool nothing_rendered = false;
+    if (have_receipt) {
+        const int rc = lists_of_receipt(a->receipt, n, a->width, a->height, d.row_begin, d.row_end, a->point_list, &feed,
+                                        &from_blocks, &lists_written);
+        if (rc != GSR_OK) return rc;
+        nothing_rendered = a->receipt.num_rendered == 0;
+    } else {
+        if (!a->point_list) return GSR_ERR_INVALID_ARG;
+        uint32_t first = 0;
+        GSR_HIP_TRY(hipMemcpyAsync(&first, a->point_list, sizeof(first), hipMemcpyDeviceToHost, stream));
+        GSR_HIP_TRY(hipStreamSynchronize(stream));
+        if (first == GSR_LISTS_SKIPPED_STAMP) return GSR_ERR_INVALID_ARG;
+    }
     GSR_HIP_TRY(hipMemsetAsync(a->dL_dmean2D, 0, sizeof(float) * 2 * (size_t)n, stream));
     GSR_HIP_TRY(hipMemsetAsync(a->dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)n, stream));
     GSR_HIP_TRY(hipMemsetAsync(a->dL_dcolors, 0, sizeof(float) * 3 * (size_t)n, stream));
+    if (nothing_rendered) {
+        // R == 0: no Gaussian reached a pixel (the forward call left even the tile ranges unwritten, GSCuda.cu:775-778)
+        if (a->dL_dcov3D) GSR_HIP_TRY(hipMemsetAsync(a->dL_dcov3D, 0, sizeof(float) * 6 * (size_t)n, stream));
+        if (a->dL_dshs) GSR_HIP_TRY(hipMemsetAsync(a->dL_dshs, 0, sizeof(float) * 48 * (size_t)n, stream));
+        if (a->dL_dmeans3D) GSR_HIP_TRY(hipMemsetAsync(a->dL_dmeans3D, 0, sizeof(float) * 4 * (size_t)n, stream));
+        if (a->dL_dscales) GSR_HIP_TRY(hipMemsetAsync(a->dL_dscales, 0, sizeof(float) * 4 * (size_t)n, stream));
+        if (a->dL_drotations) GSR_HIP_TRY(hipMemsetAsync(a->dL_drotations, 0, sizeof(float) * 4 * (size_t)n, stream));
+        return GSR_OK;
+    }
     if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[0], stream));
     RenderBackwardParams r;
     r.ranges = reinterpret_cast<const uint2*>(a->ranges);

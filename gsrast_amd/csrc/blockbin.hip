@@ -366,8 +366,11 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(BlockMeta meta, int n
 // `close_single` (the upstream behaviour) is asked for.
 __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __restrict__ tile_count, uint32_t tiles,
                                                           uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
-                                                          uint32_t r_total, bool close_single, uint32_t* __restrict__ nonempty) {
+                                                          uint32_t r_total, bool close_single, uint32_t* __restrict__ nonempty,
+                                                          uint32_t* __restrict__ skipped_stamp) {
     __shared__ uint32_t s_ws[16];
+    // GSR_FLAG_NO_SORTED_LISTS: the sorted values stay unwritten; their first word says so (include/gsrast_amd.h)
+    if (threadIdx.x == 0 && skipped_stamp) *skipped_stamp = GSR_LISTS_SKIPPED_STAMP;
     const uint32_t per = (tiles + 1023) / 1024;
     const uint32_t a = min(tiles, threadIdx.x * per), z = min(tiles, a + per);
     uint32_t s = 0;
@@ -774,7 +777,7 @@ BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
                          int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
-                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles) {
+                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles, uint32_t* skipped_stamp) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
     if (t.chunk == kCoarse)
         hipLaunchKernelGGL(coarse_count_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_rect, t.nbx, t.nbp,
@@ -814,7 +817,7 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     hipLaunchKernelGGL(block_prefix_kernel, dim3(t.nb), dim3(256), 0, stream, t.meta, t.nbx, grid_x, grid_y, t.cnt, t.tile_count);
     GSR_LAUNCH_CHECK("block_prefix_kernel");
     hipLaunchKernelGGL(tile_start_kernel, dim3(1), dim3(1024), 0, stream, t.tile_count, t.tiles, t.tile_start,
-                       reinterpret_cast<uint2*>(ranges), r_total, close_single, nonempty_tiles);
+                       reinterpret_cast<uint2*>(ranges), r_total, close_single, nonempty_tiles, skipped_stamp);
     GSR_LAUNCH_CHECK("tile_start_kernel");
     return GSR_OK;
 }

@@ -41,9 +41,11 @@ struct BlockFeed {
 };
 BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch);
 
-// The feed of the calling thread's most recent gsr_forward call, if that call ran the block plan and `point_list` is
-// the values array of its binning chunk (written or, with GSR_FLAG_NO_SORTED_LISTS, not).
-bool forward_left_block_feed(const void* point_list, BlockFeed* out);
+// Which lists the forward call that issued `r` left for a backward call with these sizes / rows / point_list (api.hip):
+// *lists_written — the sorted lists are in point_list; *from_blocks — it ran the block plan and blended from the block
+// lists: *feed says where they are. GSR_ERR_INVALID_ARG if the receipt does not fit the arguments or promises no list.
+int lists_of_receipt(const gsr_forward_receipt& r, int n, int width, int height, int row_begin, int row_end,
+                     const void* point_list, BlockFeed* feed, bool* from_blocks, bool* lists_written);
 
 // inclusive prefix sum over lanes 0..31 (and, separately, 32..63): row_shr 1, 2, 4, 8 + row_bcast:15
 __device__ __forceinline__ uint32_t prefix32_inclusive(uint32_t v) {

@@ -34,10 +34,6 @@ int record_error(int code);
         }                                                   \
     } while (0)
 
-// True if `point_list` is the `values` array of this thread's last gsr_forward call and that call skipped the
-// sorted lists (GSR_FLAG_NO_SORTED_LISTS): gsr_backward refuses such a state.
-bool forward_skipped_sorted_lists(const void* point_list);
-
 struct FrameDims {
     int width, height;
     int grid_x, grid_y;            // tile grid of the whole image
@@ -47,6 +43,8 @@ struct FrameDims {
 // ---- stage launchers (each asynchronous on `stream`) ----
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
                       uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
+
+int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t stream);
 
 int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
                             uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
@@ -97,7 +95,7 @@ size_t blockbin_bin_bytes(size_t r);
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
                          int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
-                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles = nullptr);
+                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles = nullptr, uint32_t* skipped_stamp = nullptr);
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
                       const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream);
 int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,

@@ -261,7 +261,25 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     if (p.rect_packed) p.rect_packed[idx] = out_rect;
 }
 
+// colour = 0.5 + 0.4 DC (GSCuda.cu:362-366), the same two float32 operations as the preprocess kernel above (this file
+// is compiled without contraction): the colours a caller precomputes with it are bit-equal to geomState.rgb.
+__global__ __launch_bounds__(256) void colors_from_dc_kernel(int n, const float* __restrict__ shs, float* __restrict__ colors) {
+    // lane = one float of the output; the three floats of a Gaussian sit at a 192-byte stride in the input (a one-time
+    // pass per scene: one 128-byte line per Gaussian is what the input layout costs)
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= 3 * (size_t)n) return;
+    const size_t g = f / 3;
+    colors[f] = 0.5f + 0.4f * shs[48 * g + (f - 3 * g)];
+}
+
 }  // namespace
+
+int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t stream) {
+    const size_t floats = 3 * (size_t)n;
+    hipLaunchKernelGGL(colors_from_dc_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, stream, n, shs, colors);
+    GSR_LAUNCH_CHECK("colors_from_dc_kernel");
+    return GSR_OK;
+}
 
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
                       uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream) {

@@ -694,7 +694,7 @@ int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_
     uint64_t* tmp_k = reinterpret_cast<uint64_t*>(temp);
     uint32_t* tmp_v = reinterpret_cast<uint32_t*>(temp + align_up(n * sizeof(uint64_t), 128));
     SweepScratch sc = carve_sweep_scratch(temp + align_up(n * sizeof(uint64_t), 128) + align_up(n * sizeof(uint32_t), 128), n);
-    if (error_word) sc.error_word = error_word;          // (the caller's word, cleared by the caller; may be host memory)
+    if (error_word) sc.error_word = error_word;          // (the caller's word: gsr_forward hands in this call's slot of pinned host memory, zeroed at the top of the call)
     else GSR_HIP_TRY(hipMemsetAsync(sc.error_word, 0, sizeof(uint32_t), stream));
     int rc = histogram_bits_u64(keys_in, n, begin_bit, end_bit, sc.hist, stream);
     if (rc != GSR_OK) return rc;

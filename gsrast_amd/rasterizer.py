@@ -81,6 +81,8 @@ class SplatRasterizer:
         self.last_records_staged = 0
         self.last_plan = "none"
         self.last_blend_from_lists = False
+        self.last_lists_written = True
+        self.last_receipt: _capi.ForwardReceipt | None = None      # of the last draw(): what backward() / poll take
         self.last_stage_ms: dict[str, float] = {}
         # view (16) | proj (16) | cam_pos (3): one device buffer, uploaded with one async copy from pinned memory
         self._cam_dev = torch.zeros(35, dtype=torch.float32, device=self.device)
@@ -99,6 +101,7 @@ class SplatRasterizer:
         assert self.means3D.shape == (self.num_gaussians, 4) and self.scales.shape == (self.num_gaussians, 4)
         assert self.rotations.shape == (self.num_gaussians, 4) and self.shs.shape == (self.num_gaussians, 48)
         self.use_rects = use_rects
+        self._colors_dc = None                       # colours precomputed from the DC triples, on first use
         self.rects = (torch.zeros((self.num_gaussians, 2), dtype=torch.int32, device=self.device)
                       if use_rects else None)
 
@@ -120,7 +123,7 @@ class SplatRasterizer:
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
              sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
-             overlap_emit: bool = False, sorted_lists: bool = True) -> torch.Tensor:
+             overlap_emit: bool = False, sorted_lists: bool = True, colors_precomp: bool = False) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
@@ -128,7 +131,10 @@ class SplatRasterizer:
         plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan.
         overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: emission on a second stream beside the blend).
         sorted_lists=False: GSR_FLAG_NO_SORTED_LISTS (forward-only callers; last_lists_written tells whether the
-        binning chunk holds the sorted keys / values of this call)."""
+        binning chunk holds the sorted keys / values of this call).
+        colors_precomp: pass the scene's colours as the reference's `colorsPrecomp` argument (GSCuda.cuh:111) — computed once
+        per scene by gsr_colors_from_dc, bit-equal to what the preprocess writes to geomState.rgb per frame (gscuda semantics
+        only: there the colour does not depend on the view)."""
         if cam is not None:
             self.set_camera(cam)
         a = _capi.ForwardArgs()
@@ -145,7 +151,8 @@ class SplatRasterizer:
         a.background = self.background.data_ptr()
         a.width, a.height = self.width, self.height
         a.means3D, a.shs = self.means3D.data_ptr(), self.shs.data_ptr()
-        a.colors_precomp = None
+        a.colors_precomp = self.precomputed_colors().data_ptr() if colors_precomp else None
+        assert not (colors_precomp and inria), "upstream colour depends on the view direction"
         a.opacities, a.scales = self.opacities.data_ptr(), self.scales.data_ptr()
         a.scale_modifier = scale_modifier
         a.rotations = self.rotations.data_ptr()
@@ -163,6 +170,8 @@ class SplatRasterizer:
         with torch.cuda.device(self.device):
             rc = self.lib.gsr_forward(C.byref(a))
         _capi.check(rc, "gsr_forward")
+        self.last_receipt = a.receipt.copy()
+        self.last_colors_precomp = bool(colors_precomp)
         self.last_num_rendered = int(a.num_rendered)
         self.last_records_staged = int(a.records_staged)
         self.last_plan = _capi.PLAN_NAMES[int(a.plan_used) & 0xFF]
@@ -172,8 +181,24 @@ class SplatRasterizer:
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()
-            _capi.check(self.lib.gsr_poll_async_error(), "gsr_forward (device side)")
+            self.poll_async_error()
         return self.out_color
+
+    def precomputed_colors(self) -> torch.Tensor:
+        """vec3[N] = 0.5 + 0.4 DC (gsr_colors_from_dc), computed on first use and kept for the scene."""
+        if self._colors_dc is None:
+            c = torch.empty((self.num_gaussians, 3), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = self.lib.gsr_colors_from_dc(self.num_gaussians, self.shs.data_ptr(), c.data_ptr(),
+                                                 torch.cuda.current_stream(self.device).cuda_stream)
+            _capi.check(rc, "gsr_colors_from_dc")
+            self._colors_dc = c
+        return self._colors_dc
+
+    def poll_async_error(self, receipt: "_capi.ForwardReceipt | None" = None) -> None:
+        """After the stream of a draw() has been synchronised: raises if a device-side wait of that call gave up."""
+        r = receipt if receipt is not None else self.last_receipt
+        _capi.check(self.lib.gsr_poll_async_error(C.byref(r)), "gsr_forward (device side)")
 
     # -- point-splat path (gscuda::forwardPoints, GSCuda.cu:110-155) -----------------------------
     def draw_points(self, cam: Camera | None = None, sync: bool = True) -> torch.Tensor:
@@ -212,9 +237,11 @@ class SplatRasterizer:
     # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
     def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
                  tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0, semantics: str = "gscuda",
-                 sh_degree: int = 3) -> dict:
+                 sh_degree: int = 3, receipt: "_capi.ForwardReceipt | None | bool" = None) -> dict:
         """Gradients of sum(dL_dout * out_color) of the LAST draw() through gsr_backward; `semantics` / `sh_degree`
-        must be those of that draw(). Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3]
+        must be those of that draw(). receipt: the gsr_forward_receipt of the draw() this is the backward of (default:
+        this object's last draw(); any host thread may call); False = none, the reference's contract only (sorted lists
+        in the binning chunk — refused after a draw(sorted_lists=False)). Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3]
         and, with with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (gscuda: the DC triple only; inria: every coefficient
         up to sh_degree), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
         The tensors are owned by this object and overwritten by the next call."""
@@ -225,10 +252,14 @@ class SplatRasterizer:
         gst, ist, bst = _capi.GeometryState(), _capi.ImageState(), _capi.BinningState()
         self.lib.gsr_geometry_from_chunk(self.geom.base(), n, C.byref(gst))
         self.lib.gsr_image_from_chunk(self.image.base(), self.width * self.height, C.byref(ist))
-        self.lib.gsr_binning_from_chunk(self.binning.base(), self.last_num_rendered, C.byref(bst))
-        # output buffers are allocated once per scene and reused (dL_dshs is 48 floats per Gaussian of which
-        # only the DC triple is ever written: it is zero-filled once, not per call)
-        cache = getattr(self, "_bw_out", None)
+        rcpt = self.last_receipt if receipt is None else (None if receipt is False else receipt)
+        num_rendered = int(rcpt.num_rendered) if rcpt is not None else self.last_num_rendered
+        self.lib.gsr_binning_from_chunk(self.binning.base(), num_rendered, C.byref(bst))
+        # output buffers are allocated once per scene and semantics and reused. dL_dshs is 48 floats per Gaussian; the
+        # gscuda chain writes floats 0..15 of every Gaussian, the inria chain all 48: the buffer is zero-filled once, and
+        # kept per semantics so that a gscuda call never returns what an inria call left in floats 16..47.
+        caches = self.__dict__.setdefault("_bw_out_by_semantics", {})
+        cache = caches.get(semantics)
         if cache is None or cache["dL_dmean2D"].shape[0] != n or ("dL_dcov3D" in cache) != with_cov3D:
             cache = {"dL_dmean2D": torch.empty((n, 2), dtype=torch.float32, device=dev),
                      "dL_dconic_opacity": torch.empty((n, 4), dtype=torch.float32, device=dev),
@@ -238,7 +269,7 @@ class SplatRasterizer:
                 cache["dL_dshs"] = torch.zeros((n, 48), dtype=torch.float32, device=dev)
                 for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
                     cache[k] = torch.empty((n, 4), dtype=torch.float32, device=dev)
-            self._bw_out = cache
+            caches[semantics] = cache
         out = cache
         a = _capi.BackwardArgs()
         a.struct_size = C.sizeof(_capi.BackwardArgs)
@@ -247,7 +278,8 @@ class SplatRasterizer:
             a.cam_pos, a.shs, a.clamped, a.sh_dims = self._cam_pos.data_ptr(), self.shs.data_ptr(), gst.clamped, int(sh_degree)
         a.num_gaussians, a.width, a.height = n, self.width, self.height
         a.background = self.background.data_ptr()
-        a.means2D, a.conic_opacity, a.colors, a.cov3D = gst.means2D, gst.conic_opacity, gst.rgb, gst.cov3D
+        a.means2D, a.conic_opacity, a.cov3D = gst.means2D, gst.conic_opacity, gst.cov3D
+        a.colors = self._colors_dc.data_ptr() if getattr(self, "last_colors_precomp", False) else gst.rgb
         a.radii = gst.internal_radii
         a.ranges, a.n_contrib, a.final_t = ist.ranges, ist.n_contrib, ist.accum_alpha
         a.point_list = bst.values
@@ -266,6 +298,8 @@ class SplatRasterizer:
         a.stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_rows is not None:
             a.tile_row_begin, a.tile_row_end = int(tile_rows[0]), int(tile_rows[1])
+        if rcpt is not None:
+            a.receipt = rcpt
         with torch.cuda.device(dev):
             rc = self.lib.gsr_backward(C.byref(a))
         _capi.check(rc, "gsr_backward")

@@ -97,6 +97,11 @@ int main(int argc, char** argv) {
             fprintf(stderr, "gscuda::forward failed: %s (%s)\n", gsr_error_string(gscuda::lastError()), gsr_last_hip_error());
             return 1;
         }
+        // (after the sync inside CHECK_HIP_ERROR: the device-side half of the sticky-error poll)
+        if (gscuda::pollAsyncError() != GSR_OK) {
+            fprintf(stderr, "gscuda::forward: a device-side wait gave up, frame %d is invalid\n", i);
+            return 1;
+        }
     }
     // What the Inspector does: re-derive GeometryState pointers from the caller-owned chunk.
     char* chunk = reinterpret_cast<char*>(geomPtr);

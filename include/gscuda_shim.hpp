@@ -11,8 +11,10 @@
 // error after a device sync, apps/gsrast/CudaBuffer.hpp:8-12) is kept: forward() returns
 // nothing and gscuda::lastError() reports the code of the last call.
 //
-// glm is not required: vec2/vec3/vec4/uvec2 below are layout-compatible PODs used only as
-// pointer element types.
+// The state structs' pointer element types are glm's where glm is installed — the reference declares
+// glm::vec2* / vec4* / vec3* / uvec2* (AuxBuffer.cuh:46-49,57), so a caller that assigns geomState.means2D to a
+// glm::vec2* compiles unchanged — and layout-compatible PODs of the same names where it is not (this image has no glm).
+// Define GSCUDA_SHIM_NO_GLM to get the PODs regardless.
 #pragma once
 
 #include <cstddef>
@@ -22,12 +24,30 @@
 
 #include "gsrast_amd.h"
 
+#if !defined(GSCUDA_SHIM_NO_GLM) && defined(__has_include)
+#if __has_include(<glm/glm.hpp>)
+#include <glm/glm.hpp>
+#define GSCUDA_SHIM_HAS_GLM 1
+#endif
+#endif
+
 namespace gscuda {
 
+#ifdef GSCUDA_SHIM_HAS_GLM
+using vec2 = glm::vec2;
+using vec3 = glm::vec3;
+using vec4 = glm::vec4;
+using uvec2 = glm::uvec2;
+#else
 struct vec2 { float x, y; };
 struct vec3 { float x, y, z; };
 struct vec4 { float x, y, z, w; };
 struct uvec2 { uint32_t x, y; };
+#endif
+// the strides the library writes (AuxBuffer.cu:52-59: vec2 8, vec3 12, vec4 16 bytes; a glm built with forced
+// alignment of vec3 / vec4 would not fit)
+static_assert(sizeof(vec2) == 8 && sizeof(vec3) == 12 && sizeof(vec4) == 16 && sizeof(uvec2) == 8,
+              "gscuda_shim: vector types must be tightly packed");
 
 namespace detail {
 inline char* trampoline(void* user, size_t bytes) {
@@ -37,9 +57,21 @@ inline int& last_error_slot() {
     static thread_local int e = GSR_OK;
     return e;
 }
+inline gsr_forward_receipt& last_receipt_slot() {
+    static thread_local gsr_forward_receipt r{};
+    return r;
+}
 }  // namespace detail
 
 inline int lastError() { return detail::last_error_slot(); }
+// The receipt of the calling thread's last forward() (include/gsrast_amd.h): what gsr_backward and the poll below take.
+inline const gsr_forward_receipt& lastReceipt() { return detail::last_receipt_slot(); }
+// After the caller's device sync (the reference's CHECK_CUDA_ERROR, CudaBuffer.hpp:8-12): did a device-side wait of that
+// forward() give up. GSR_OK also when the last forward() failed on the host (lastError() says how) or drew nothing.
+inline int pollAsyncError() {
+    const gsr_forward_receipt& r = detail::last_receipt_slot();
+    return r.magic == GSR_RECEIPT_MAGIC ? gsr_poll_async_error(&r) : GSR_OK;
+}
 
 template <typename T>
 size_t required(int num) {
@@ -124,6 +156,37 @@ struct BinningState {
 
 }  // namespace gs
 
+namespace detail {
+// The reference's parameter list (GSCuda.cuh:103-126 = :19-42) filed into the C struct, field for field.
+inline gsr_forward_args marshal(std::function<char*(size_t)>& geometryBuffer, std::function<char*(size_t)>& binningBuffer,
+                                std::function<char*(size_t)>& imageBuffer, int numGaussians, int shDims, int M,
+                                const float* background, int width, int height, const float* means3D, const float* shs,
+                                const float* colorsPrecomp, const float* opacities, const float* scales, float scaleModifier,
+                                const float* rotations, const float* cov3DPrecomp, const float* viewMatrix,
+                                const float* projMatrix, const float* camPos, float tanFOVx, float tanFOVy, bool prefiltered,
+                                float* outColor, int* radii, int* rects, float* boxMin, float* boxMax) {
+    gsr_forward_args a{};
+    a.struct_size = sizeof(a);
+    a.geometry_alloc = trampoline; a.geometry_user = &geometryBuffer;
+    a.binning_alloc = trampoline;  a.binning_user = &binningBuffer;
+    a.image_alloc = trampoline;    a.image_user = &imageBuffer;
+    a.num_gaussians = numGaussians; a.sh_dims = shDims; a.M = M;
+    a.background = background;
+    a.width = width; a.height = height;
+    a.means3D = means3D; a.shs = shs; a.colors_precomp = colorsPrecomp;
+    a.opacities = opacities; a.scales = scales; a.scale_modifier = scaleModifier;
+    a.rotations = rotations; a.cov3D_precomp = cov3DPrecomp;
+    a.view_matrix = viewMatrix; a.proj_matrix = projMatrix; a.cam_pos = camPos;
+    a.tan_fovx = tanFOVx; a.tan_fovy = tanFOVy;
+    a.prefiltered = prefiltered ? 1 : 0;
+    a.out_color = outColor;
+    a.radii = radii; a.rects = rects;
+    a.box_min = boxMin; a.box_max = boxMax;
+    a.stream = nullptr;                       // the reference runs on the default stream
+    return a;
+}
+}  // namespace detail
+
 // Same parameter list, order and meaning as the reference declaration.
 inline void forward(std::function<char*(size_t)> geometryBuffer,
                     std::function<char*(size_t)> binningBuffer,
@@ -149,25 +212,12 @@ inline void forward(std::function<char*(size_t)> geometryBuffer,
                     int* rects,
                     float* boxMin,
                     float* boxMax) {
-    gsr_forward_args a{};
-    a.struct_size = sizeof(a);
-    a.geometry_alloc = detail::trampoline; a.geometry_user = &geometryBuffer;
-    a.binning_alloc = detail::trampoline;  a.binning_user = &binningBuffer;
-    a.image_alloc = detail::trampoline;    a.image_user = &imageBuffer;
-    a.num_gaussians = numGaussians; a.sh_dims = shDims; a.M = M;
-    a.background = background;
-    a.width = width; a.height = height;
-    a.means3D = means3D; a.shs = shs; a.colors_precomp = colorsPrecomp;
-    a.opacities = opacities; a.scales = scales; a.scale_modifier = scaleModifier;
-    a.rotations = rotations; a.cov3D_precomp = cov3DPrecomp;
-    a.view_matrix = viewMatrix; a.proj_matrix = projMatrix; a.cam_pos = camPos;
-    a.tan_fovx = tanFOVx; a.tan_fovy = tanFOVy;
-    a.prefiltered = prefiltered ? 1 : 0;
-    a.out_color = outColor;
-    a.radii = radii; a.rects = rects;
-    a.box_min = boxMin; a.box_max = boxMax;
-    a.stream = nullptr;                       // the reference runs on the default stream
+    gsr_forward_args a = detail::marshal(geometryBuffer, binningBuffer, imageBuffer, numGaussians, shDims, M, background, width,
+                                         height, means3D, shs, colorsPrecomp, opacities, scales, scaleModifier, rotations,
+                                         cov3DPrecomp, viewMatrix, projMatrix, camPos, tanFOVx, tanFOVy, prefiltered, outColor,
+                                         radii, rects, boxMin, boxMax);
     detail::last_error_slot() = gsr_forward(&a);
+    detail::last_receipt_slot() = a.receipt;
 }
 
 // gscuda::forwardPoints (GSCuda.cuh:19-42): same parameter list as forward; means3D has a stride of
@@ -196,24 +246,10 @@ inline void forwardPoints(std::function<char*(size_t)> geometryBuffer,
                           int* rects,
                           float* boxMin,
                           float* boxMax) {
-    gsr_forward_args a{};
-    a.struct_size = sizeof(a);
-    a.geometry_alloc = detail::trampoline; a.geometry_user = &geometryBuffer;
-    a.binning_alloc = detail::trampoline;  a.binning_user = &binningBuffer;
-    a.image_alloc = detail::trampoline;    a.image_user = &imageBuffer;
-    a.num_gaussians = numGaussians; a.sh_dims = shDims; a.M = M;
-    a.background = background;
-    a.width = width; a.height = height;
-    a.means3D = means3D; a.shs = shs; a.colors_precomp = colorsPrecomp;
-    a.opacities = opacities; a.scales = scales; a.scale_modifier = scaleModifier;
-    a.rotations = rotations; a.cov3D_precomp = cov3DPrecomp;
-    a.view_matrix = viewMatrix; a.proj_matrix = projMatrix; a.cam_pos = camPos;
-    a.tan_fovx = tanFOVx; a.tan_fovy = tanFOVy;
-    a.prefiltered = prefiltered ? 1 : 0;
-    a.out_color = outColor;
-    a.radii = radii; a.rects = rects;
-    a.box_min = boxMin; a.box_max = boxMax;
-    a.stream = nullptr;
+    gsr_forward_args a = detail::marshal(geometryBuffer, binningBuffer, imageBuffer, numGaussians, shDims, M, background, width,
+                                         height, means3D, shs, colorsPrecomp, opacities, scales, scaleModifier, rotations,
+                                         cov3DPrecomp, viewMatrix, projMatrix, camPos, tanFOVx, tanFOVy, prefiltered, outColor,
+                                         radii, rects, boxMin, boxMax);
     detail::last_error_slot() = gsr_forward_points(&a);
 }
 

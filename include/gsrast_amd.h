@@ -119,8 +119,8 @@ enum {
 /* Forward-only callers: under the block plan the blend can be fed from the block lists without reading the sorted
  * keys / values (it is by default on frames of 48 or more instances per visible Gaussian), and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
  * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
- * UNWRITTEN, plan_used carries GSR_PLAN_LISTS_SKIPPED, and a gsr_backward call that follows (same thread and
- * device, chunks untouched, `point_list` = that unwritten values array) walks the tile lists out of the block lists.
+ * UNWRITTEN except for values[0] = GSR_LISTS_SKIPPED_STAMP, plan_used carries GSR_PLAN_LISTS_SKIPPED, and a gsr_backward
+ * call that is given this call's receipt (any thread; chunks untouched) walks the tile lists out of the block lists.
  * Pixels, ranges, finalT, nContrib and numRendered are unchanged. Ignored under the other plans, whose blend
  * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
 #define GSR_FLAG_NO_SORTED_LISTS 0x40u
@@ -128,6 +128,31 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
        GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer
                                             than 48 instances per visible Gaussian), not the block lists */ };
+
+/* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
+ * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this
+ * library — the receipt only says which chunks those were, how many instances (R) and visible Gaussians (V) the call
+ * found and which binning plan left which lists there. It is plain data: copy it, hand it to another host thread, keep
+ * several (one per rasterizer). It describes the chunks as that call left them, so it is valid until the next
+ * gsr_forward call that is given the same chunks. */
+#define GSR_RECEIPT_MAGIC 0x31525347u   /* "GSR1" */
+/* First word of BinningState.values after a call that left the sorted lists unwritten (GSR_FLAG_NO_SORTED_LISTS took
+ * effect): no Gaussian index, so a gsr_backward call WITHOUT a receipt can tell that there is no list to walk. */
+#define GSR_LISTS_SKIPPED_STAMP 0xFFFFFFFFu
+typedef struct gsr_forward_receipt {
+    uint32_t magic;                /* GSR_RECEIPT_MAGIC once gsr_forward has returned GSR_OK, else 0 */
+    uint32_t plan_used;            /* as gsr_forward_args.plan_used */
+    int32_t  num_gaussians, width, height;
+    int32_t  tile_row_begin, tile_row_end;   /* the tile rows the call processed (0, ceil(H/16) for the whole frame) */
+    uint32_t num_rendered;         /* R */
+    uint32_t num_visible;          /* V: Gaussians with at least one tile in this call */
+    uint32_t serial;               /* which call of its host thread and device */
+    char*    geometry_chunk;       /* what the three allocator callbacks returned (binning: NULL if R == 0) */
+    char*    image_chunk;
+    char*    binning_chunk;
+    const volatile uint32_t* async_words;   /* host memory (pinned, never freed): {N-sized sort gave up, R-sized sort gave up,
+                                               serial of the call that owns the words, 0} — see gsr_poll_async_error */
+} gsr_forward_receipt;
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
  * gscuda::forward (GSCuda.cuh:103-126); the rest are extensions with neutral defaults (0). */
@@ -171,6 +196,7 @@ typedef struct gsr_forward_args {
     uint64_t records_staged;       /* R_f, only with GSR_FLAG_COUNT_STAGED                 */
     float stage_ms[GSR_NUM_STAGES];/* only with GSR_FLAG_PROFILE                           */
     uint32_t plan_used;            /* GSR_PLAN_* of this call (0 if R == 0), | GSR_PLAN_LISTS_SKIPPED */
+    gsr_forward_receipt receipt;   /* hand it to gsr_backward / gsr_poll_async_error (magic = 0 unless GSR_OK is returned) */
 } gsr_forward_args;
 
 /* The forward pass. Calls geometry_alloc(required_geometry(N)), then
@@ -186,10 +212,13 @@ const char* gsr_error_string(int code);
 /* Text of the HIP error behind the last GSR_ERR_HIP ("" if none). */
 const char* gsr_last_hip_error(void);
 
-/* After the caller has synchronised the stream of the last gsr_forward call: GSR_OK, or
- * GSR_ERR_INTERNAL if a radix-sort look-back wait expired during that call (the frame is
- * then invalid). Mirrors the reference caller polling the sticky error after its sync. */
-int gsr_poll_async_error(void);
+/* After the caller has synchronised the stream of the gsr_forward call that issued `receipt`: GSR_OK, or
+ * GSR_ERR_INTERNAL if a radix-sort look-back wait expired during that call (the frame is then invalid). Mirrors the
+ * reference caller polling the sticky error after its sync (CudaBuffer.hpp:8-12). Any thread may ask. The words a call
+ * reports into are one of 64 slots per host thread and device, handed out in turn: asked about a call that lies more
+ * than 63 calls back the answer is GSR_OK (its slot has a new owner; nothing is known any more). NULL or a receipt
+ * without the magic: GSR_ERR_INVALID_ARG. */
+int gsr_poll_async_error(const gsr_forward_receipt* receipt);
 
 /* getHigherMsb (GSCuda.cu:481-502): bits of the tile id that take part in the sort. */
 uint32_t gsr_higher_msb(uint32_t n);
@@ -204,6 +233,12 @@ int gsr_inclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, char* te
 size_t gsr_sort_temp_bytes(size_t n);
 int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
                            uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, void* stream);
+
+/* The colours of the reference's semantics, once per scene: colors[3 i + c] = 0.5f + 0.4f * shs[48 i + c] (GSCuda.cu:362-366;
+ * the colour does not depend on the view). Passed as `colors_precomp` (GSCuda.cuh:111; the blend then reads them instead of
+ * geomState.rgb, GSCuda.cu:803) they spare every frame the 12-byte read at a 192-byte stride — one 128-byte line per visible
+ * Gaussian — and the 12 N bytes of geomState.rgb: same pixels bit for bit. Device pointers; asynchronous on stream. */
+int gsr_colors_from_dc(int n, const float* shs, float* colors, void* stream);
 
 /* The blend's footprint test (csrc/blend_core.hpp), record by record: misses[i] = 1 iff the library would drop record i
  * (centre means2D[i], conic + opacity conic_opacity[i]) when it stages the list of tile tile_xy[i] = (tx, ty) of a
@@ -248,10 +283,7 @@ typedef struct gsr_backward_args {
     const uint32_t* ranges;        /* image chunk */
     const uint32_t* n_contrib;
     const float* final_t;          /* accum_alpha */
-    const uint32_t* point_list;    /* binning chunk: values. When this is the values array of the thread's most recent
-                                      gsr_forward call and that call ran the block plan, the block lists it left in its
-                                      chunks are used too (all tiles if GSR_FLAG_NO_SORTED_LISTS left `values` unwritten,
-                                      else the tiles with short lists), and keysUnsorted serves as scratch */
+    const uint32_t* point_list;    /* binning chunk: values (with a receipt: must be the values array of ITS binning chunk) */
     /* inputs of the forward call that the covariance chain needs again (only with dL_dcov3D) */
     const float* means3D;
     const float* view_matrix;
@@ -279,6 +311,15 @@ typedef struct gsr_backward_args {
     const float* shs;              /* device f32[48 N], [16][3] per Gaussian */
     const uint8_t* clamped;        /* geometry chunk: bool[3 N], colour channel was clamped at zero */
     int32_t sh_dims;               /* SH degree the forward call evaluated (0..3) */
+    /* ---- which forward call this is the backward of ---- */
+    gsr_forward_receipt receipt;   /* gsr_forward_args.receipt of that call, by value. With it the block lists that call left
+                                      in its chunks are used where it ran the block plan (all tiles if GSR_FLAG_NO_SORTED_LISTS
+                                      left `values` unwritten, else the tiles of shallow blocks, keysUnsorted serving as
+                                      scratch for per-entry sums), and R == 0 gives all-zero gradients. All zero (no receipt):
+                                      the reference's contract only — the sorted lists must be in point_list; the call then
+                                      reads point_list[0] back (one stream sync) and refuses GSR_LISTS_SKIPPED_STAMP with
+                                      GSR_ERR_INVALID_ARG. A receipt that does not fit the other arguments (sizes, rows,
+                                      point_list): GSR_ERR_INVALID_ARG. */
 } gsr_backward_args;
 int gsr_backward(gsr_backward_args* args);
 

@@ -40,8 +40,7 @@ torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps
 ok = bool(((out[0][1:] >> 32) >= (out[0][:-1] >> 32)).all())
 gbs = n * (8 + 24 * passes) / (ms * 1e-3) / 1e9
-print(f"keys={mode} tag={os.environ.get('GSR_LIB_TAG','')} n={n} passes={passes} {ms:.3f} ms  {gbs:.0f} GB/s algorithmic  sorted={ok} "
-      f"err={_capi.lib().gsr_poll_async_error()}")
+print(f"keys={mode} tag={os.environ.get('GSR_LIB_TAG','')} n={n} passes={passes} {ms:.3f} ms  {gbs:.0f} GB/s algorithmic  sorted={ok}")
 
 if os.environ.get("GSR_SHOW_STAMPS"):
     # diagnostic build: 128-byte per-tile slots behind the status words (see radix_sort.hip)

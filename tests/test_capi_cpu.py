@@ -100,3 +100,86 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         _capi.lib()
+
+
+def _compile_and_run(tmp_path, source: str, flags=(), cxx=False):
+    import subprocess
+    src = tmp_path / ("probe.cpp" if cxx else "probe.c")
+    src.write_text(source)
+    exe = tmp_path / "probe"
+    cmd = (["g++", "-std=c++17"] if cxx else ["gcc", "-std=c11"]) + ["-I", os.path.join(ROOT, "include"), *flags, str(src), "-o", str(exe)]
+    subprocess.check_call(cmd)
+    return subprocess.check_output([str(exe)], text=True)
+
+
+def test_ctypes_structs_have_the_headers_layout(tmp_path):
+    """The header is compiled as C and asked for sizes / offsets; the ctypes mirrors must agree field for field (a
+    silent mismatch would shift every pointer behind it)."""
+    probes = {"gsr_forward_args": (_capi.ForwardArgs, ["flags", "num_gaussians", "out_color", "stream", "num_rendered",
+                                                        "records_staged", "stage_ms", "plan_used", "receipt"]),
+              "gsr_backward_args": (_capi.BackwardArgs, ["point_list", "dL_dout_color", "dL_drotations", "stage_ms", "sh_dims",
+                                                          "receipt"]),
+              "gsr_forward_receipt": (_capi.ForwardReceipt, ["plan_used", "tile_row_end", "num_visible", "serial",
+                                                             "geometry_chunk", "binning_chunk", "async_words"])}
+    lines = []
+    for cname, (_, fields) in probes.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    out = _compile_and_run(tmp_path, '#include <stdio.h>\n#include <stddef.h>\n#include "gsrast_amd.h"\nint main(void){' + "".join(lines) + "return 0;}")
+    got = dict(line.split() for line in out.strip().splitlines())
+    for cname, (ctype, fields) in probes.items():
+        assert int(got[cname]) == C.sizeof(ctype), cname
+        for f in fields:
+            assert int(got[f"{cname}.{f}"]) == getattr(ctype, f).offset, f"{cname}.{f}"
+
+
+def test_poll_async_error_wants_a_receipt():
+    L = _capi.lib()
+    assert L.gsr_poll_async_error(None) == _capi.GSR_ERR_INVALID_ARG
+    assert L.gsr_poll_async_error(C.byref(_capi.ForwardReceipt())) == _capi.GSR_ERR_INVALID_ARG
+    # a receipt whose slot has a new owner (other serial) says nothing: GSR_OK; the owner's words are reported
+    words = (C.c_uint32 * 4)(1, 0, 7, 0)
+    r = _capi.ForwardReceipt()
+    r.magic, r.serial, r.async_words = _capi.GSR_RECEIPT_MAGIC, 6, C.addressof(words)
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_OK
+    r.serial = 7
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_ERR_INTERNAL
+    words[0] = 0
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_OK
+
+
+@pytest.mark.parametrize("with_glm", [False, True])
+def test_shim_state_pointers_are_glm_typed_when_glm_exists(tmp_path, with_glm):
+    """AuxBuffer.cuh:46-49,57 declare glm::vec2* / vec4* / vec3* / uvec2*: with glm on the include path the shim's structs
+    carry exactly those types (a caller's `glm::vec2* p = geomState.means2D;` compiles), without it PODs of the same layout.
+    This image has no glm; tests/doubles/glm is a stand-in with glm's default layout, for this compile test only."""
+    flags = ["-I", os.path.join(ROOT, "tests", "doubles")] if with_glm else []
+    body = """
+#include <cstdio>
+#include <type_traits>
+#include "gscuda_shim.hpp"
+int main() {
+    char* chunk = nullptr;
+    gscuda::gs::GeometryState g = gscuda::gs::GeometryState::fromChunk(chunk, 10);
+    chunk = nullptr;
+    gscuda::gs::ImageState im = gscuda::gs::ImageState::fromChunk(chunk, 64);
+#ifdef GSCUDA_SHIM_HAS_GLM
+    glm::vec2* m = g.means2D; glm::vec4* c = g.conicOpacity; glm::vec3* rgb = g.rgb; glm::uvec2* r = im.ranges;
+    static_assert(std::is_same<gscuda::vec3, glm::vec3>::value, "alias");
+    std::printf("glm %d\\n", (int)(m != nullptr && c != nullptr && rgb != nullptr) + (int)(r == nullptr));
+#else
+    gscuda::vec2* m = g.means2D; (void)m; (void)im;
+    std::printf("pod 0\\n");
+#endif
+    return gscuda::required<gscuda::gs::GeometryState>(10) == gsr_required_geometry(10) ? 0 : 1;
+}
+"""
+    import subprocess
+    src = tmp_path / "shim_probe.cpp"
+    src.write_text(body)
+    exe = tmp_path / "shim_probe"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), *flags, str(src), "-o", str(exe),
+                           _capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(_capi.LIB_PATH), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.split()[0] == ("glm" if with_glm else "pod")

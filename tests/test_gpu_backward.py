@@ -229,3 +229,141 @@ def test_backward_from_the_block_lists_corner_cases():
         r.draw(cam, plan="blocks", tile_rows=(7, 19), sorted_lists=lists)
         out = r.backward(dl, with_cov3D=False, tile_rows=(7, 19))
         _assert_same_sums(out, ref, noise, f"band, sorted lists {lists}")
+
+
+def _receipt_scene():
+    from gsrast_amd import camera, scenes
+    W, H = 400, 272
+    return (W, H, scenes.garden_like_scene(60_000, seed=47), camera.default_camera(W, H, near=0.05, far=80.0),
+            camera.default_camera(W, H, near=0.05, far=80.0, position=(0.5, 0.2, -7.0)))
+
+
+_RECEIPT_MODES = {"sorted": dict(plan="sort"), "blocks": dict(plan="blocks"),
+                  "blocks, no sorted lists": dict(plan="blocks", sorted_lists=False)}
+
+
+@pytest.mark.parametrize("mode", list(_RECEIPT_MODES))
+def test_backward_follows_the_receipt_not_the_last_call(mode):
+    """What gsr_backward reads is decided by the gsr_forward_receipt it is handed and by the caller-owned chunks, not by
+    anything the library remembers of its last call (round 2: thread-local last-call state; a backward issued from another
+    host thread — what torch.autograd does — or after a second rasterizer's forward walked unwritten lists and returned
+    GSR_OK). Here: forward on thread A / backward on thread B; forward A, forward B, backward A; each must give the sums of
+    the plain same-thread sequence."""
+    import threading
+    import torch
+    from gsrast_amd.rasterizer import SplatRasterizer
+    W, H, scene, cam_a, cam_b = _receipt_scene()
+    kw = _RECEIPT_MODES[mode]
+    dl = torch.from_numpy(np.random.default_rng(5).normal(size=(3, H, W)).astype(np.float32)).cuda()
+    ra, rb = SplatRasterizer(W, H, background=(0.1, 0.2, 0.3)), SplatRasterizer(W, H, background=(0.1, 0.2, 0.3))
+    ra.configure_from_scene(scene)
+    rb.configure_from_scene(scene)
+    # reference: forward + backward of A, nothing in between, one thread
+    ra.draw(cam_a, **kw)
+    assert ra.last_num_rendered > 0 and ra.last_lists_written == kw.get("sorted_lists", True)
+    ref = _base_sums(ra, dl)
+    noise = {k: float((_base_sums(ra, dl)[k] - v).abs().max()) for k, v in ref.items()}
+
+    # (1) forward here, backward on another host thread (its own thread-local state in the library: none of A's)
+    ra.draw(cam_a, **kw)
+    box = {}
+
+    def worker():
+        try:
+            box["sums"] = _base_sums(ra, dl)
+            ra.poll_async_error()                      # any thread may ask about a call
+        except Exception as e:                         # noqa: BLE001
+            box["error"] = e
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert "error" not in box, box.get("error")
+    _assert_same_sums(box["sums"], ref, noise, mode + ": backward on another thread")
+
+    # (2) a second rasterizer's forward (other camera, other plan) between A's forward and A's backward
+    ra.draw(cam_a, **kw)
+    receipt_a = ra.last_receipt
+    rb.draw(cam_b, plan="blocks" if kw["plan"] == "sort" else "sort")
+    rb.draw(cam_b, plan="blocks", sorted_lists=False)
+    out = ra.backward(dl, with_cov3D=False, receipt=receipt_a)
+    _assert_same_sums(out, ref, noise, mode + ": another rasterizer's forward in between")
+    # ... and B's own backward is B's
+    rb.draw(cam_b, plan="sort")
+    ref_b = _base_sums(rb, dl)
+    rb.draw(cam_b, **kw)
+    ra.draw(cam_a, plan="sort")
+    out_b = rb.backward(dl, with_cov3D=False)
+    noise_b = {k: 1e-30 for k in ref_b}
+    _assert_same_sums(out_b, ref_b, noise_b, mode + ": B after A's forward")
+
+
+def test_backward_without_a_fitting_receipt_is_refused_never_garbage():
+    import ctypes as C
+    import torch
+    from gsrast_amd import _capi
+    from gsrast_amd.rasterizer import SplatRasterizer
+    W, H, scene, cam_a, cam_b = _receipt_scene()
+    dl = torch.from_numpy(np.random.default_rng(6).normal(size=(3, H, W)).astype(np.float32)).cuda()
+    ra, rb = SplatRasterizer(W, H), SplatRasterizer(W, H)
+    ra.configure_from_scene(scene)
+    rb.configure_from_scene(scene)
+    ra.draw(cam_a, plan="sort")
+    ref = _base_sums(ra, dl)
+    noise = {k: float((_base_sums(ra, dl)[k] - v).abs().max()) for k, v in ref.items()}
+    # no receipt, sorted lists in place (the reference's contract): served, from the sorted lists
+    for plan in ("sort", "blocks"):
+        ra.draw(cam_a, plan=plan)
+        _assert_same_sums(ra.backward(dl, with_cov3D=False, receipt=False), ref, noise, f"no receipt after a {plan}-plan call")
+    # no receipt, lists skipped: the stamp in values[0] says so
+    ra.draw(cam_a, plan="blocks", sorted_lists=False)
+    assert int(ra.map_binning_state()["values"][0].item()) & 0xFFFFFFFF == _capi.GSR_LISTS_SKIPPED_STAMP
+    with pytest.raises(_capi.GsrError) as e:
+        ra.backward(dl, with_cov3D=False, receipt=False)
+    assert e.value.code == _capi.GSR_ERR_INVALID_ARG
+    # ... and with the receipt the same state is served
+    _assert_same_sums(ra.backward(dl, with_cov3D=False), ref, noise, "receipt after a call without sorted lists")
+    # a receipt of another rasterizer's call (other chunks), of another size, of another band, a forged magic
+    rb.draw(cam_b, plan="blocks", sorted_lists=False)
+    with pytest.raises(_capi.GsrError) as e:
+        ra.backward(dl, with_cov3D=False, receipt=rb.last_receipt)
+    assert e.value.code == _capi.GSR_ERR_INVALID_ARG
+    for field, value in (("width", W + 16), ("num_gaussians", 5), ("tile_row_end", 3), ("magic", 0x12345678)):
+        bad = ra.last_receipt.copy()
+        setattr(bad, field, value)
+        with pytest.raises(_capi.GsrError) as e:
+            ra.backward(dl, with_cov3D=False, receipt=bad)
+        assert e.value.code == _capi.GSR_ERR_INVALID_ARG, field
+    # polling: NULL and a receipt without the magic are refused; a valid one is answered from any call distance
+    L = _capi.lib()
+    assert L.gsr_poll_async_error(None) == _capi.GSR_ERR_INVALID_ARG
+    assert L.gsr_poll_async_error(C.byref(_capi.ForwardReceipt())) == _capi.GSR_ERR_INVALID_ARG
+    old = ra.last_receipt.copy()
+    for _ in range(70):                               # more calls than there are error-word slots
+        ra.draw(cam_a, plan="blocks", sync=False)
+    torch.cuda.synchronize()
+    assert L.gsr_poll_async_error(C.byref(old)) == _capi.GSR_OK
+    assert L.gsr_poll_async_error(C.byref(ra.last_receipt)) == _capi.GSR_OK
+    assert ra.last_receipt.serial >= old.serial + 70       # (the serial counts every call of this thread on this device)
+
+
+def test_backward_of_a_frame_without_instances_is_all_zero():
+    """R == 0: the forward call leaves even the tile ranges unwritten (GSCuda.cu:775-778); with its receipt gsr_backward
+    returns zero gradients instead of walking whatever an earlier frame left in the chunks."""
+    import torch
+    from gsrast_amd import camera
+    from gsrast_amd.rasterizer import SplatRasterizer
+    from helpers import single_gaussian_scene
+    W, H = 128, 96
+    r = SplatRasterizer(W, H)
+    r.configure_from_scene(single_gaussian_scene(n=40, scale=0.3))
+    cam = camera.default_camera(W, H, near=0.05, far=50.0)
+    r.draw(cam)
+    assert r.last_num_rendered > 0
+    dl = torch.ones((3, H, W), device="cuda")
+    assert float(r.backward(dl)["dL_dcolors"].abs().sum()) > 0
+    away = camera.default_camera(W, H, near=0.05, far=50.0, position=(0.0, 0.0, 5.0))   # the scene is behind this camera
+    r.draw(away)
+    assert r.last_num_rendered == 0 and r.last_receipt.magic != 0 and not r.last_receipt.binning_chunk
+    out = r.backward(dl)
+    for k, v in out.items():
+        assert float(v.abs().sum()) == 0.0, k

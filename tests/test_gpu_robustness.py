@@ -142,6 +142,43 @@ def test_precomputed_colors_and_cov3d_paths():
     assert torch.equal(r2.map_image_state()["finalT"], r.map_image_state()["finalT"])
 
 
+def test_colors_precomputed_once_per_scene_give_the_same_frame_bit_for_bit():
+    """The reference's colour is view-independent (0.5 + 0.4 DC, GSCuda.cu:362-366), so a caller may compute it once
+    (gsr_colors_from_dc) and pass it as colorsPrecomp (GSCuda.cuh:111, :803): bit-equal to geomState.rgb of the `shs` call
+    for every visible Gaussian, same pixels / finalT / nContrib / lists, same gradients — under every plan."""
+    import torch
+    from gsrast_amd import camera, scenes
+    scene = scenes.garden_like_scene(50_000, seed=52)
+    scene["means3D"][:, :3] *= 0.3
+    W, H = 640, 368
+    cam = camera.default_camera(W, H, near=0.05, far=60.0)
+    r = _rast(W, H, background=(0.05, 0.1, 0.2))
+    r.configure_from_scene(scene)
+    dl = torch.from_numpy(np.random.default_rng(3).normal(size=(3, H, W)).astype(np.float32)).cuda()
+    for plan, lists in (("sort", True), ("blocks", True), ("blocks", False)):
+        ref = r.draw(cam, plan=plan, sorted_lists=lists).clone()
+        assert r.last_num_rendered > 0
+        g = r.map_geometry_state()
+        vis = g["radii"] > 0
+        rgb = g["rgb"].clone()
+        im = {k: v.clone() for k, v in r.map_image_state().items()}
+        keys = r.map_binning_state()["keys"].clone() if lists else None
+        grads = {k: v.clone() for k, v in r.backward(dl).items()}
+        g["rgb"].fill_(float("nan"))                         # the precomp call must neither write nor read geomState.rgb
+        got = r.draw(cam, plan=plan, sorted_lists=lists, colors_precomp=True)
+        assert torch.equal(r.precomputed_colors()[vis], rgb[vis]), plan
+        assert torch.equal(got, ref), plan
+        assert bool(torch.isnan(r.map_geometry_state()["rgb"]).all())
+        for k, v in r.map_image_state().items():
+            assert torch.equal(v, im[k]), (plan, k)
+        if lists:
+            assert torch.equal(r.map_binning_state()["keys"], keys)
+        out = r.backward(dl)
+        for k, v in grads.items():
+            scale = float(v.abs().max()) + 1e-30
+            assert float((out[k] - v).abs().max()) <= 2e-4 * scale, (plan, k)
+
+
 def test_overlapped_emission_on_a_non_default_stream_with_bands_and_upstream_semantics():
     """GSR_FLAG_OVERLAP_EMIT forks to the library's own side stream and joins the caller's stream again: the
     results must be those of the serial call whatever stream the caller uses, for band-limited calls and for
