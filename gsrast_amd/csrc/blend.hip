@@ -58,9 +58,7 @@ constexpr uint32_t kStripMeanList = 1024;        // entries per tile with a list
 // reference (256) only survives as the granularity of the "whole tile done" test and of the
 // staged-record count R_f, which therefore stay identical to the reference's.
 __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
-    __shared__ float2 s_xy[kWave];
-    __shared__ float4 s_co[kWave];
-    __shared__ float4 s_rgb[kWave];
+    __shared__ StagedRecords s_staged;
 
     // workgroups [k * base, (k + 1) * base) are strip k of the tiles: the three extra sets leave at once unless the frame
     // has few tiles with a list (they are the END of the launch, and a tile's four waves run on one XCD)
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     for (uint32_t pos = 2 * kWave; b0.valid && !all_done; pos += kWave) {
         fetch_records(b1, feed);
         RecordBatch b2 = next_batch(pos);
-        all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, b0, staged);
+        all_done = stage_and_composite(s, feed, s_staged, b0, staged);
         b0 = b1;
         b1 = b2;
     }

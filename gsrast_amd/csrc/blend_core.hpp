@@ -87,6 +87,14 @@ __device__ __forceinline__ void tile_lanes_init(TileLanes& s, int tx, int ty, in
         s.done[k] = s.inside[k] ? 0u : 1u;
         s.T[k] = 1.0f; s.cr[k] = s.cg[k] = s.cb[k] = 0.0f; s.last[k] = 0;
     }
+#if GSR_BLEND_FAST
+    // a finished pixel's row coordinate is NaN: its power is NaN and fails the candidate range test without a test of its own
+    const float qnan = __builtin_nanf("");
+    if (s.done[0]) s.fy01.x = qnan;
+    if (s.done[1]) s.fy01.y = qnan;
+    if (s.done[2]) s.fy23.x = qnan;
+    if (s.done[3]) s.fy23.y = qnan;
+#endif
 }
 
 __device__ __forceinline__ bool tile_lanes_all_done(const TileLanes& s) {
@@ -99,8 +107,104 @@ __device__ __forceinline__ bool tile_lanes_all_done(const TileLanes& s) {
 // and lane; the per-row terms run as packed f32 pairs (v_pk_mul_f32 / v_pk_add_f32: two IEEE single
 // operations per issue, same rounding as the scalar form, no fused multiply-add). Returns true as soon as
 // every pixel of the tile is finished.
+#ifndef GSR_BLEND_FAST
+#define GSR_BLEND_FAST 1
+#endif
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kFilterSlack = 0.25f;      // in units of the power: covers terms up to 4e6 in magnitude (see composite_staged)
+#if GSR_BLEND_FAST
+// A cheap FILTER in front of the reference's arithmetic. Of the records a tile stages, most reach only a part of its four
+// 16 x 4 strips, and finding that out cost as much as compositing: the reference's power (GSCuda.cu:634) for all four
+// pixels of a lane, 18 issues, and twelve compares. The filter evaluates the power a second way: the staged conic is
+// pre-scaled (stage_and_composite), q = (-0.5 log2(e) A, -log2(e) B, -0.5 log2(e) C, opacity), so that
+//   log2(e) * power = q.x dx^2 + dy (q.z dy + q.y dx)
+// is four scalar operations for the dx terms and three packed ones per pair of rows (a subtract, two v_pk_fma_f32); a
+// finished pixel has a NaN row coordinate (tile_lanes_init), so the range test "floor <= power <= 0" is the whole
+// candidate test, two compares per pixel whose results stay lane masks in scalar registers. Its floor has a margin
+// (kPowerFloor is 1.9 % below -ln 255) and a record fails it only if every lane is outside [floor, 0], so it decides
+// nothing the reference's tests decide: for the pairs of strips that have a candidate the power is evaluated again in the
+// reference's operation order (unfused; raw conic from s_raw), and alpha, the 1/255 test, T and the cut-off test follow
+// from THAT — T and every decision are bit for bit what they were. (Feeding alpha from the fused evaluation was built
+// first: 25 % faster still, but alpha then differs by 1e-7 relative, T drifts by 1e-6 to 1e-5 over a deep list, and a
+// pixel whose T (1 - alpha) lands that close to the cut-off stops one record earlier or later: 59 to 109 pixels of the
+// 8.3 M of the 4K parity frame beyond 1e-4 instead of fewer than 20, `gpurun_out/r3e`, `r3f`.) Only the colour sums
+// take a fused form, three multiply-adds on alpha T — they feed no test, and move the pixel by a few 1e-8.
 __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
-                                                 uint32_t chunk, float t_cutoff) {
+                                                 const float4* s_raw, uint32_t chunk, float t_cutoff) {
+    const float qnan = __builtin_nanf("");
+    constexpr float kAlphaMin = 1.0f / 255.0f;
+    for (uint32_t j = 0; j < chunk; ++j) {
+        const float2 xy = s_xy[j];
+        const float4 q = s_co[j];
+        const float dx = xy.x - s.fx;
+        const float h0 = (q.x * dx) * dx;
+        const float g = q.y * dx;
+        f32x2 gy; gy.x = xy.y; gy.y = xy.y;
+        f32x2 gg; gg.x = g; gg.y = g;
+        f32x2 hh; hh.x = h0; hh.y = h0;
+        f32x2 cz; cz.x = q.z; cz.y = q.z;
+        const f32x2 dy01 = gy - s.fy01, dy23 = gy - s.fy23;
+        const f32x2 fw01 = __builtin_elementwise_fma(dy01, __builtin_elementwise_fma(cz, dy01, gg), hh);
+        const f32x2 fw23 = __builtin_elementwise_fma(dy23, __builtin_elementwise_fma(cz, dy23, gg), hh);
+        const float filter[4] = {fw01.x, fw01.y, fw23.x, fw23.y};
+        // exp(power) >= 1/255 needs power >= -ln(255) = -5.5413; below kPowerFloor it fails for every opacity <= 1 (wave-uniform
+        // test). The filter's window is wider than the reference's tests at both ends by kFilterSlack: the two evaluations
+        // of the power differ by rounding, 6e-8 of the largest of three terms that may cancel — for a needle-shaped splat seen
+        // along its axis those terms reach 1e6 while the power is -1 — and a pixel the reference would accept must never be
+        // filtered out. The reference's own "power > 0" and "alpha < 1/255" tests follow below, on its own arithmetic.
+        const float floor2 = q.w > 1.0f ? -__builtin_inff() : (kPowerFloor - kFilterSlack) * kLog2e;
+        unsigned long long cand[4];       // lane masks (every lane of the wave is active here); false for a finished pixel: NaN
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cand[k] = __ballot(filter[k] <= kFilterSlack * kLog2e) & __ballot(filter[k] >= floor2);
+        if ((cand[0] | cand[1] | cand[2] | cand[3]) == 0ull) continue;
+        const float4 col = s_rgb[j];
+        const float4 raw = s_raw[j];
+        const uint32_t contributor = __float_as_uint(col.w);
+        // the reference's operation order from here on (this file is compiled without contraction)
+        const float t1 = (raw.x * dx) * dx, bdx = raw.y * dx;
+        unsigned long long newly_done = 0ull;
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            if ((cand[2 * pair] | cand[2 * pair + 1]) == 0ull) continue;
+            // (finished pixels: their dy is NaN, and so is their power — they are no candidates)
+            const f32x2 dy = pair == 0 ? dy01 : dy23;
+            const f32x2 pw = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * pair + h;
+                if (cand[k] == 0ull) continue;                // nobody in this strip sees the record
+                const float power = h == 0 ? pw.x : pw.y;
+                const float alpha = fminf(0.99f, raw.w * __expf(power));
+                const unsigned long long live = cand[k] & ~__ballot(power > 0.0f) & ~__ballot(alpha < kAlphaMin);
+                const float test = s.T[k] * (1.0f - alpha);
+                const unsigned long long stop = live & __ballot(test < t_cutoff);
+                if (__builtin_amdgcn_inverse_ballot_w64(live & ~stop)) {
+                    const float w = alpha * s.T[k];
+                    s.cr[k] = __builtin_fmaf(col.x, w, s.cr[k]);
+                    s.cg[k] = __builtin_fmaf(col.y, w, s.cg[k]);
+                    s.cb[k] = __builtin_fmaf(col.z, w, s.cb[k]);
+                    s.T[k] = test;
+                    s.last[k] = contributor;
+                }
+                if (stop != 0ull) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(stop)) {
+                        s.done[k] = 1u;
+                        if (k == 0) s.fy01.x = qnan;
+                        if (k == 1) s.fy01.y = qnan;
+                        if (k == 2) s.fy23.x = qnan;
+                        if (k == 3) s.fy23.y = qnan;
+                    }
+                    newly_done |= stop;
+                }
+            }
+        }
+        if (newly_done != 0ull && tile_lanes_all_done(s)) return true;
+    }
+    return false;
+}
+#else
+__device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
+                                                 const float4*, uint32_t chunk, float t_cutoff) {
     for (uint32_t j = 0; j < chunk; ++j) {
         const float2 xy = s_xy[j];
         const float4 co = s_co[j];
@@ -146,6 +250,7 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
     }
     return false;
 }
+#endif
 
 // Stages the records of one batch of up to 64 list entries and composites them. Lane l holds entry l of the batch
 // (`present`: the lane has an entry; `id`: its Gaussian; `number`: its 1-based position in the tile's list).
@@ -184,8 +289,20 @@ __device__ __forceinline__ void fetch_records(RecordBatch& b, const TileFeed& f)
     if (b.valid && b.present()) { b.xy = f.means2D[b.id]; b.co = f.conic_opacity[b.id]; }
 }
 
-__device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, float2* s_xy, float4* s_co, float4* s_rgb,
+// One wave's staging area in LDS (wave-private: no barrier): the survivors of a batch, compacted.
+struct StagedRecords {
+    float2 xy[kWave];
+    float4 co[kWave];              // conic as the compositing loop wants it (pre-scaled), opacity
+    float4 rgb[kWave];             // colour, and (as bits) the record's 1-based position in the tile's list
+    float4 raw[kWave];             // conic + opacity as fetched: the reference-order evaluation of the lanes near a threshold
+};
+
+__device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, StagedRecords& st,
                                                     const RecordBatch& b, unsigned long long& staged) {
+    float2* const s_xy = st.xy;
+    float4* const s_co = st.co;
+    float4* const s_rgb = st.rgb;
+    float4* const s_raw = st.raw;
     const bool present = b.present();
     const uint32_t rank = b.rank(), pos = b.pos, count = b.count();
     const bool keep = present && !record_misses_tile(b.xy, b.co, f.box);
@@ -195,7 +312,12 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
         const float* c = f.colors + 3 * (size_t)b.id;
         s_xy[slot] = b.xy;
+#if GSR_BLEND_FAST
+        s_co[slot] = make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, b.co.w);
+        s_raw[slot] = b.co;
+#else
         s_co[slot] = b.co;
+#endif
         s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
     }
     // wave-private LDS: the writes above and the reads of composite_staged are ordered inside the wave
@@ -205,12 +327,12 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
     if (boundary < pos + count) {
         // records in front of the boundary first; then the reference would test "whole tile done" and stage the next 256
         const uint32_t before = (uint32_t)__popcll(__ballot(keep && rank < boundary - pos));
-        if (before) all_done = composite_staged(s, s_xy, s_co, s_rgb, before, f.t_cutoff);
+        if (before) all_done = composite_staged(s, s_xy, s_co, s_rgb, s_raw, before, f.t_cutoff);
         if (all_done) return true;
         staged += min((uint32_t)kBatch, f.total - boundary);
         first = before;
     }
-    if (kept > first) all_done = composite_staged(s, s_xy + first, s_co + first, s_rgb + first, kept - first, f.t_cutoff);
+    if (kept > first) all_done = composite_staged(s, s_xy + first, s_co + first, s_rgb + first, s_raw + first, kept - first, f.t_cutoff);
     return all_done;
 }
 

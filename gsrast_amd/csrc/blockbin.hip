@@ -423,6 +423,7 @@ __global__ __launch_bounds__(1024) void tile_start_kernel(const uint32_t* __rest
 // Every (unit, tile) run is therefore written front to back by one wave in consecutive bursts (whole
 // lines form in L2); there is no per-entry serial work and no staging of keys in LDS.
 constexpr int kEmitWaves = 4;                // independent waves per workgroup
+constexpr uint32_t kDenseUnitKeys = 40000;   // keys per unit (2048 entries) from which units are dealt in quarters
 constexpr uint32_t kGroup = 128;             // keys per dense store group: 8 key lines + 4 value lines
 constexpr uint32_t kRun = 512;               // slots of the per-wave run buffer (>= kGroup - 1 + 4 batches of 64)
 constexpr int kCheck = 4;                    // batches between two looks at the run buffer's fill
@@ -471,18 +472,33 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
     const uint32_t* ent_rd32 = reinterpret_cast<const uint32_t*>(ent_rd);
     uint2* run_buf = s_run[wave];
     uint2* scrap = run_buf + kRun + lane;
-    // Units differ in key count, so they come from a work queue — except the first one of every wave
+    // Work items differ in key count, so they come from a work queue — except the first one of every wave
     // (ticket = wave number): thousands of waves hitting one counter at launch would queue up on it.
+    // An item is a unit or, on frames of large splats, a quarter of a unit's tiles (tile rows 0-1 | 2-3 | 4-5 | 6-7 of the
+    // block; each quarter loads the unit's entries and masks for itself). With whole units the bench frame has 2.9 units
+    // per wave and units of very different weight (the splats next to the camera cover their whole block): some waves end
+    // on their second unit and others on their fourth, and the waves were resident for 83 % of the launch on average
+    // (SQ_WAVE_CYCLES). Measured, whole units / halves / quarters: bench frame (22 keys per entry) 0.688 / 0.656 / 0.634 ms;
+    // 3840 x 2160 (35 keys per entry, 8 units per wave) 2.997 / 2.959 / 2.903 ms; but eye (0,0,-9) (17 keys per entry)
+    // 0.591 / - / 0.603 ms and from outside the cloud (11 keys per entry) 0.361 / 0.372 / 0.397 ms: there the units are
+    // alike and an item's own loads (24 KB of entries and masks) weigh more than the tail. Eighths: 0.683 ms on the bench
+    // frame, 2.844 ms at 3840 x 2160. The four quarters of a unit taken by the four waves of one workgroup together (one
+    // ticket per workgroup, so that the loads miss the caches once): 0.650 ms on the bench frame, the waves wait for the
+    // slowest quarter. (`gpurun_out/r3b` - `r3d`.)
     const uint32_t nwaves = gridDim.x * kEmitWaves;
+    const uint32_t keys_per_unit = r_total / max(total_units, 1u);
+    const uint32_t parts = (total_units >= 32u * nwaves || keys_per_unit < kDenseUnitKeys) ? 1u : 4u;
+    const uint32_t total_items = total_units * parts, tiles_per_item = 64u / parts;
     bool first = true;
     for (;;) {
-        uint32_t u = blockIdx.x * kEmitWaves + (uint32_t)wave;
+        uint32_t item = blockIdx.x * kEmitWaves + (uint32_t)wave;
         if (!first) {
-            if (lane == 0) u = nwaves + atomicAdd(&meta.tickets()[1], 1u);
-            u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+            if (lane == 0) item = nwaves + atomicAdd(&meta.tickets()[1], 1u);
+            item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         }
         first = false;
-        if (u >= total_units) break;
+        if (item >= total_items) break;
+        const uint32_t u = item / parts, t_first = (item % parts) * tiles_per_item;
         const UnitInfo ui = locate_unit(u, meta, nb, nbx);
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e0);
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e1);
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
         __builtin_amdgcn_wave_barrier();
 
         // ---- tiles ----
-        for (uint32_t t = 0; t < 64; ++t) {
+        for (uint32_t t = t_first; t < t_first + tiles_per_item; ++t) {
             const uint2 xm = s_maskT[wave][t & 7u][lane & (kBatches - 1)];
             const uint2 ym = s_maskT[wave][8u + (t >> 3)][lane & (kBatches - 1)];
             const uint32_t tm_lo = (lane < kBatches) ? (xm.x & ym.x) : 0u, tm_hi = (lane < kBatches) ? (xm.y & ym.y) : 0u;
@@ -523,9 +539,11 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
             if (base + run > r_total || base + run < base) continue;      // (never beyond the arrays)
             // The run is compacted through the run buffer: batch by batch the covered entries write
             // {depth, index} at slot (output index mod 512), output index = where the batch starts +
-            // v_mbcnt rank; the other lanes write their scrap slot (v_cndmask on the mask: no EXEC
-            // change, no branch, so consecutive batches overlap freely). Every 4 batches the complete
-            // groups of the output are stored densely.
+            // v_mbcnt rank; the other lanes write their scrap slot (no branch, so consecutive batches overlap
+            // freely; the compiler computes the slot under an EXEC mask — a v_cndmask on the mask's SGPR pair
+            // instead, forced through inline assembly, measured the same: 0.637 ms either way). Every 4 batches the
+            // complete groups of the output are stored densely. (Splitting a group's store into the LDS read at one
+            // look and the HBM stores at the next, so that the read's latency is covered: no change either.)
             const uint32_t start_v = base + incl - c;                 // lane w: output index of batch w's first key
             // Where the groups are cut. Coarse: at multiples of 128 keys — the run's keys in front of its first multiple and
             // behind its last one take the narrow path (18 % of all keys on the bench frame). Fine: at lines of the value
@@ -626,9 +644,7 @@ struct BlockBlendParams {
 };
 
 __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendParams p) {
-    __shared__ float2 s_xy[kWave];
-    __shared__ float4 s_co[kWave];
-    __shared__ float4 s_rgb[kWave];
+    __shared__ StagedRecords s_staged;
     const int wpt = p.waves_per_tile;
     const int tile_local = tile_of_workgroup((int)blockIdx.x / wpt, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
     if (tile_local < 0) return;
@@ -692,7 +708,7 @@ __global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendPar
     while (b0.valid && !all_done) {
         fetch_records(b1, feed);
         RecordBatch b2 = next_batch();
-        all_done = stage_and_composite(s, feed, s_xy, s_co, s_rgb, b0, staged);
+        all_done = stage_and_composite(s, feed, s_staged, b0, staged);
         b0 = b1;
         b1 = b2;
     }
@@ -830,7 +846,8 @@ int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo
     // measured 1.5 % slower on the bench frame and at 4K), four where they cover few (short runs, the waves wait more than
     // they store: 0.416 -> 0.366 ms from outside the cloud, R / V = 23 against 88 on the bench frame).
     const uint32_t per_cu = (uint64_t)r_total >= 48ull * (uint64_t)n ? 2u : 4u;
-    const uint32_t emit_wgs = std::min<uint32_t>((t.max_units + kEmitWaves - 1) / kEmitWaves, 256u * per_cu);
+    // (a unit may be dealt as four items, see the kernel: a wave per item on small frames)
+    const uint32_t emit_wgs = std::min<uint32_t>(t.max_units, 256u * per_cu);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, t.meta, t.nb, t.nbx, grid_x, grid_y,
                        ent_rd, ent_idx, t.unit_masks, t.cnt, t.tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");
