@@ -87,14 +87,12 @@ __device__ __forceinline__ void tile_lanes_init(TileLanes& s, int tx, int ty, in
         s.done[k] = s.inside[k] ? 0u : 1u;
         s.T[k] = 1.0f; s.cr[k] = s.cg[k] = s.cb[k] = 0.0f; s.last[k] = 0;
     }
-#if GSR_BLEND_FAST
     // a finished pixel's row coordinate is NaN: its power is NaN and fails the candidate range test without a test of its own
     const float qnan = __builtin_nanf("");
     if (s.done[0]) s.fy01.x = qnan;
     if (s.done[1]) s.fy01.y = qnan;
     if (s.done[2]) s.fy23.x = qnan;
     if (s.done[3]) s.fy23.y = qnan;
-#endif
 }
 
 __device__ __forceinline__ bool tile_lanes_all_done(const TileLanes& s) {
@@ -103,16 +101,9 @@ __device__ __forceinline__ bool tile_lanes_all_done(const TileLanes& s) {
 
 // Composites the `chunk` records staged in wave-private LDS (s_rgb[j].w carries, as bits, the record's 1-based
 // position in the tile's list: the contributor number of GSCuda.cu:624 — records dropped at staging leave gaps).
-// dx and the terms that only depend on it are computed once per record
-// and lane; the per-row terms run as packed f32 pairs (v_pk_mul_f32 / v_pk_add_f32: two IEEE single
-// operations per issue, same rounding as the scalar form, no fused multiply-add). Returns true as soon as
-// every pixel of the tile is finished.
-#ifndef GSR_BLEND_FAST
-#define GSR_BLEND_FAST 1
-#endif
+// Returns true as soon as every pixel of the tile is finished.
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kFilterSlack = 0.25f;      // in units of the power: covers terms up to 4e6 in magnitude (see composite_staged)
-#if GSR_BLEND_FAST
 // A cheap FILTER in front of the reference's arithmetic. Of the records a tile stages, most reach only a part of its four
 // 16 x 4 strips, and finding that out cost as much as compositing: the reference's power (GSCuda.cu:634) for all four
 // pixels of a lane, 18 issues, and twelve compares. The filter evaluates the power a second way: the staged conic is
@@ -202,55 +193,6 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
     }
     return false;
 }
-#else
-__device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
-                                                 const float4*, uint32_t chunk, float t_cutoff) {
-    for (uint32_t j = 0; j < chunk; ++j) {
-        const float2 xy = s_xy[j];
-        const float4 co = s_co[j];
-        const float dx = xy.x - s.fx;
-        const float adx = co.x * dx;
-        const float t1 = adx * dx;
-        const float bdx = co.y * dx;
-        f32x2 gy; gy.x = xy.y; gy.y = xy.y;
-        const f32x2 dy01 = gy - s.fy01, dy23 = gy - s.fy23;
-        const f32x2 pw01 = -0.5f * (t1 + (co.z * dy01) * dy01) - bdx * dy01;
-        const f32x2 pw23 = -0.5f * (t1 + (co.z * dy23) * dy23) - bdx * dy23;
-        const float power[4] = {pw01.x, pw01.y, pw23.x, pw23.y};
-        const bool wide = co.w > 1.0f;       // wave-uniform: the floor only holds for opacity <= 1
-        bool cand[4];
-        bool any_cand = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cand[k] = s.done[k] == 0u && !(power[k] > 0.0f) && (power[k] >= kPowerFloor || wide);
-            any_cand = any_cand || cand[k];
-        }
-        if (__ballot(any_cand) == 0ull) continue;
-        const float4 col = s_rgb[j];
-        const uint32_t contributor = __float_as_uint(col.w);
-        bool newly_done = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (__ballot(cand[k]) == 0ull) continue;      // nobody in this strip sees the record
-            const float alpha = fminf(0.99f, co.w * __expf(power[k]));
-            const bool live = cand[k] && !(alpha < 1.0f / 255.0f);
-            const float test = s.T[k] * (1.0f - alpha);
-            const bool stop = live && test < t_cutoff;
-            if (live && !stop) {
-                s.cr[k] += col.x * alpha * s.T[k];
-                s.cg[k] += col.y * alpha * s.T[k];
-                s.cb[k] += col.z * alpha * s.T[k];
-                s.T[k] = test;
-                s.last[k] = contributor;
-            }
-            s.done[k] |= stop ? 1u : 0u;
-            newly_done = newly_done || stop;
-        }
-        if (__ballot(newly_done) != 0ull && tile_lanes_all_done(s)) return true;
-    }
-    return false;
-}
-#endif
 
 // Stages the records of one batch of up to 64 list entries and composites them. Lane l holds entry l of the batch
 // (`present`: the lane has an entry; `id`: its Gaussian; `number`: its 1-based position in the tile's list).
@@ -312,12 +254,8 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
         const float* c = f.colors + 3 * (size_t)b.id;
         s_xy[slot] = b.xy;
-#if GSR_BLEND_FAST
         s_co[slot] = make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, b.co.w);
         s_raw[slot] = b.co;
-#else
-        s_co[slot] = b.co;
-#endif
         s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
     }
     // wave-private LDS: the writes above and the reads of composite_staged are ordered inside the wave
