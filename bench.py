@@ -58,8 +58,12 @@ def parse_args():
                    help="inria: the upstream rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA), SH evaluated up to --sh-degree")
     p.add_argument("--sh-degree", type=int, default=3)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=3, help="CPU baseline renders every k-th splat (about 10 s of host time)")
+    p.add_argument("--cpu-sample", type=int, default=1,
+                   help="CPU baseline renders every k-th splat of the workload (1 = the whole frame: 20-30 s on the box's host cores, "
+                        "about 14 GB of host memory for the 267 M pairs of the default frame)")
     p.add_argument("--no-rebalance", action="store_true")
+    p.add_argument("--gather", default="all", choices=["all", "root"],
+                   help="N > 1: every rank receives every band (all), or only rank 0 does (root: 1/N of the traffic when one rank displays)")
     p.add_argument("--no-extras", action="store_true", help="skip the extra frames (second pose, blend-bound, no sorted lists, config 3 at N > 1)")
     p.add_argument("--backward", action="store_true",
                    help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
@@ -181,21 +185,25 @@ def make_scene(name: str, n: int, device, full_sh: bool = False):
 
 
 def cpu_baseline(scene, cam, every: int):
-    """Times the scalar C++ oracle (oracle/gsr_oracle.cpp, the CPU restatement of the same tile
-    loop) on a bounded sample of the workload: every k-th splat, same camera and resolution."""
+    """Times the scalar C++ oracle (oracle/gsr_oracle.cpp, the CPU restatement of the same pipeline: preprocess, key
+    duplication, stable 64-bit sort, tile ranges, tile loop) on the bench workload itself (every == 1) or on every k-th
+    splat of it, same camera and resolution, on all host cores."""
     from gsrast_amd import scenes
     from oracle import cpu_oracle
-    sub = scenes.scene_rows(scene, slice(None, None, every))
+    sub = scene if every == 1 else scenes.scene_rows(scene, slice(None, None, every))
     n = int(sub["means3D"].shape[0])
     cores = cpu_oracle.hardware_concurrency() or 1
     t = {}
     st = cpu_oracle.forward(sub, cam, threads=cores, timings=t)
+    whole = every == 1
     return {
         "value": round(n / t["total_s"] / 1e6, 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
-        "sample": (f"every {every}th splat of the workload (n={n}, R={st['num_rendered']}) at the same camera and "
-                   f"resolution; preprocess and key duplication single-thread, stable sort and tile loop on {cores} std::threads; "
-                   f"total {t['total_s']:.2f}s = preprocess {t['preprocess_s']:.2f} + bin/sort {t['bin_s']:.2f} + "
-                   f"blend {t['blend_s']:.2f}"),
+        "comparable": whole,        # True: the same frame as `value` (same N, same R); False: a sub-sampled frame, fewer instances per splat
+        "sample": ((f"the bench frame itself (n={n}, R={st['num_rendered']})" if whole else
+                    f"every {every}th splat of the workload (n={n}, R={st['num_rendered']}: NOT the bench frame)")
+                   + f" at the same camera and resolution; preprocess, key duplication, stable sort and tile loop on {cores} "
+                     f"std::threads (scan and tile ranges: one thread); total {t['total_s']:.2f}s = preprocess {t['preprocess_s']:.2f} + "
+                     f"bin/sort {t['bin_s']:.2f} + blend {t['blend_s']:.2f}"),
     }
 
 
@@ -209,7 +217,7 @@ class Runner:
         self.W, self.H, self.device, self.distributed, self.args = W, H, device, distributed, args
         self.rast = SplatRasterizer(W, H, device=device)
         self.rast.configure_from_scene(dev_scene)
-        self.exch = sharding.RowBandExchange(W, H, device) if distributed else None
+        self.exch = sharding.RowBandExchange(W, H, device, root=0 if args.gather == "root" else None) if distributed else None
         self.grid_x, self.grid_y = (W + 15) // 16, (H + 15) // 16
         self.dl_dout = None
         self.bw_ms = [0.0, 0.0]
@@ -532,6 +540,8 @@ def main() -> int:
                        "semantics": args.semantics + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)")
                                     + (", colours passed as colorsPrecomp" if args.colors_precomp else ""),
                        "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "rccl_ranks": world if distributed else 0,
+                       "band_exchange": ({"transport": run.exch.transport, "gather": args.gather, "note": run.exch.transport_note}
+                                         if distributed else None),
                        "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -143,6 +143,13 @@ SIGNATURES = {
     "gsr_sort_temp_bytes": (C.c_size_t, [C.c_size_t]),
     "gsr_sort_pairs_u64_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p]),
+    "gsr_exchange_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "gsr_exchange_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsr_exchange_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
+    "gsr_exchange_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gsr_exchange_destroy": (C.c_int, [C.c_void_p]),
+    "gsr_exchange_last_error": (C.c_char_p, []),
     "gsr_ply_parse_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "gsr_ply_activate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),

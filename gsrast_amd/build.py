@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False, tag: str = "") -> str:
         objs = list(ex.map(lambda s: _compile(s, force, obj_dir), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(lib_path) or os.path.getmtime(lib_path) < newest:
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -339,6 +339,30 @@ char* gsr_points_image_from_chunk(char* chunk, int size, gsr_points_image_state*
 size_t gsr_required_points_image(int size);
 int gsr_forward_points(gsr_forward_args* args);
 
+/* ---- multi-GPU: the row-band exchange of a frame sharded by screen tile rows (the reference is single-GPU:
+ * nothing of this replaces a reference interface) ----
+ * One process per GPU. Every rank holds the whole planar frame (3 x height x width floats, device memory) and has rendered
+ * tile rows [bounds[rank], bounds[rank + 1]) of it (gsr_forward_args.tile_row_begin / _end); one call moves every band
+ * into place in the peers' frames: ncclGroupStart, one ncclSend / ncclRecv per (peer, colour plane) of exact size, ncclGroupEnd
+ * — no staging, no padding. RCCL is loaded at run time from `rccl_path` (NULL: librccl.so.1; a process that uses PyTorch
+ * passes the copy torch has mapped), so the library does not depend on it.
+ *   gsr_exchange_unique_id : one rank creates the 128-byte id (ncclGetUniqueId) and hands it to the others by any means
+ *   gsr_exchange_create    : every rank, with ITS device current (ncclCommInitRank: collective, blocks until all have called)
+ *   gsr_exchange_bands     : bounds = world + 1 tile-row boundaries (0 ... ceil(height / 16), non-decreasing; empty bands
+ *                            allowed); root < 0: every rank receives every band (all-gather); root = r: only rank r
+ *                            receives (gather: 1 / world of the traffic when one rank displays). Asynchronous on `stream`.
+ *   gsr_exchange_plan      : host only, no communicator: the transfers a rank would issue, in order (tests, tools)
+ * All return GSR_OK or an error code (gsr_exchange_plan: the count, or the negated code); gsr_exchange_last_error() has
+ * the RCCL / loader message behind a GSR_ERR_HIP. */
+typedef struct gsr_exchange gsr_exchange;
+int gsr_exchange_unique_id(const char* rccl_path, char* id128);
+int gsr_exchange_create(const char* rccl_path, const char* id128, int rank, int world, gsr_exchange** out);
+int gsr_exchange_bands(gsr_exchange* x, float* frame, int width, int height, const int32_t* bounds, int root, void* stream);
+int gsr_exchange_plan(int rank, int world, int width, int height, const int32_t* bounds, int root, int max_ops,
+                      int32_t* is_send, int32_t* peer, uint64_t* offset, uint64_t* count);
+int gsr_exchange_destroy(gsr_exchange* x);
+const char* gsr_exchange_last_error(void);
+
 /* ---- scene loading (next row after the hot path) ---- */
 /* Header of a 3DGS .ply as the reference reads it (apps/gsrast/SplatData.cpp:114-145): vertex
  * count = third token of the third line; data starts after the "end_header" line. Host only.

@@ -32,6 +32,7 @@ def lib(contract: bool = False) -> ctypes.CDLL:
         build()
         L = ctypes.CDLL(_LIB_PATH_CONTRACT if contract else _LIB_PATH)
         L.gsro_preprocess.restype = ctypes.c_uint64
+        L.gsro_preprocess_mt.restype = ctypes.c_uint64
         L.gsro_blend.restype = ctypes.c_uint64
         L.gsro_higher_msb.restype = ctypes.c_uint32
         L.gsro_hardware_concurrency.restype = ctypes.c_uint
@@ -76,12 +77,12 @@ def forward(scene: dict, cam, background=(0.0, 0.0, 0.0), use_rects: bool = True
         "rects": np.zeros((n, 2), np.int32) if use_rects else None,
     }
     t0 = time.perf_counter()
-    R = int(L.gsro_preprocess(
+    R = int(L.gsro_preprocess_mt(
         ctypes.c_int(n), _p(means), _p(scales), ctypes.c_float(scale_modifier), _p(rots), _p(opac), _p(shs),
         None, None, _p(view), _p(proj), ctypes.c_int(W), ctypes.c_int(H),
         ctypes.c_float(cam.tan_fovx), ctypes.c_float(cam.tan_fovy),
         _p(o["radii"]), _p(o["means2D"]), _p(o["depths"]), _p(o["cov3D"]), _p(o["rgb"]),
-        _p(o["conicOpacity"]), _p(o["tilesTouched"]), _p(o["rects"]), _p(o["pointOffsets"])))
+        _p(o["conicOpacity"]), _p(o["tilesTouched"]), _p(o["rects"]), _p(o["pointOffsets"]), ctypes.c_int(threads)))
     t1 = time.perf_counter()
     o["num_rendered"] = R
     bg = np.asarray(background, dtype=np.float32)

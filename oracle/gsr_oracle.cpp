@@ -148,6 +148,17 @@ inline uint32_t f2bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; 
 
 }  // namespace
 
+// f(begin, end) over [0, n) on `threads` host threads (contiguous ranges; threads <= 1: one call). Only used where the
+// iterations are independent, so the result does not depend on the thread count.
+template <typename F>
+static void parallel_ranges(uint64_t n, int threads, F f) {
+    if (threads <= 1 || n < 4096) { f((uint64_t)0, n); return; }
+    const uint64_t parts = std::min<uint64_t>((uint64_t)threads, n);
+    std::vector<std::thread> pool;
+    for (uint64_t p = 0; p < parts; ++p) pool.emplace_back([&, p] { f(n * p / parts, n * (p + 1) / parts); });
+    for (auto& t : pool) t.join();
+}
+
 // Stable sort of `order` by `less` on `threads` host threads: the chunks are sorted independently, then merged pairwise
 // (std::merge keeps the elements of the left range in front of equal ones of the right range: the result is the one
 // std::stable_sort gives, whatever the thread count). Used by the timed CPU baseline; threads <= 1 is std::stable_sort.
@@ -202,6 +213,16 @@ uint32_t gsro_higher_msb(uint32_t n) {
 // reference for a culled Gaussian are left untouched here too. `rects` may be null
 // (radius-based rect) exactly as in the reference; `radii` is the caller's array.
 // Returns numRendered (GSCuda.cu:772).
+uint64_t gsro_preprocess_mt(int n, const float* means3d /*vec4*/, const float* scales /*vec4*/,
+                            float scale_modifier, const float* rotations /*vec4*/,
+                            const float* opacities, const float* shs /*48 per splat*/,
+                            const float* cov3d_precomp, const float* colors_precomp,
+                            const float* view, const float* proj, int width, int height,
+                            float tan_fovx, float tan_fovy,
+                            int* radii, float* means2d, float* depths, float* cov3ds, float* rgb,
+                            float* conic_opacity, uint32_t* tiles_touched, int* rects,
+                            uint32_t* point_offsets, int threads);
+
 uint64_t gsro_preprocess(int n, const float* means3d /*vec4*/, const float* scales /*vec4*/,
                          float scale_modifier, const float* rotations /*vec4*/,
                          const float* opacities, const float* shs /*48 per splat*/,
@@ -211,9 +232,26 @@ uint64_t gsro_preprocess(int n, const float* means3d /*vec4*/, const float* scal
                          int* radii, float* means2d, float* depths, float* cov3ds, float* rgb,
                          float* conic_opacity, uint32_t* tiles_touched, int* rects,
                          uint32_t* point_offsets) {
+    return gsro_preprocess_mt(n, means3d, scales, scale_modifier, rotations, opacities, shs, cov3d_precomp, colors_precomp, view,
+                              proj, width, height, tan_fovx, tan_fovy, radii, means2d, depths, cov3ds, rgb, conic_opacity,
+                              tiles_touched, rects, point_offsets, 1);
+}
+
+// (threads > 1: the Gaussians are independent — one thread per grid thread in the reference — so ranges of them run on
+// host threads; the scan stays one loop. Same outputs whatever the thread count.)
+uint64_t gsro_preprocess_mt(int n, const float* means3d /*vec4*/, const float* scales /*vec4*/,
+                            float scale_modifier, const float* rotations /*vec4*/,
+                            const float* opacities, const float* shs /*48 per splat*/,
+                            const float* cov3d_precomp, const float* colors_precomp,
+                            const float* view, const float* proj, int width, int height,
+                            float tan_fovx, float tan_fovy,
+                            int* radii, float* means2d, float* depths, float* cov3ds, float* rgb,
+                            float* conic_opacity, uint32_t* tiles_touched, int* rects,
+                            uint32_t* point_offsets, int threads) {
     const float focal = (float)height / (2.0f * tan_fovy);          // GSCuda.cu:721
     const int grid_x = (width + kTile - 1) / kTile, grid_y = (height + kTile - 1) / kTile;
-    for (int idx = 0; idx < n; ++idx) {
+    parallel_ranges((uint64_t)(n < 0 ? 0 : n), threads, [&](uint64_t first, uint64_t last) {
+    for (int idx = (int)first; idx < (int)last; ++idx) {
         radii[idx] = 0;
         tiles_touched[idx] = 0;
         float ph[4];
@@ -267,6 +305,7 @@ uint64_t gsro_preprocess(int n, const float* means3d /*vec4*/, const float* scal
         conic_opacity[4 * idx + 3] = opacities[idx];
         tiles_touched[idx] = area;
     }
+    });
     uint32_t run = 0;                                              // GSCuda.cu:771 (u32 wrap as CUB)
     for (int i = 0; i < n; ++i) { run += tiles_touched[i]; point_offsets[i] = run; }
     return n > 0 ? point_offsets[n - 1] : 0;
@@ -293,7 +332,9 @@ void gsro_bin_mt(int n, int width, int height, const int* radii, const float* me
                  uint64_t num_rendered, uint64_t* keys_unsorted, uint32_t* values_unsorted,
                  uint64_t* keys, uint32_t* values, uint32_t* ranges, int threads) {
     const int grid_x = (width + kTile - 1) / kTile, grid_y = (height + kTile - 1) / kTile;
-    for (int idx = 0; idx < n; ++idx) {
+    // (every Gaussian writes its own range of the arrays, GSCuda.cu:447: ranges of Gaussians run on host threads)
+    parallel_ranges((uint64_t)(n < 0 ? 0 : n), threads, [&](uint64_t first, uint64_t last) {
+    for (int idx = (int)first; idx < (int)last; ++idx) {
         if (radii[idx] <= 0) continue;
         uint32_t off = (idx == 0) ? 0u : point_offsets[idx - 1];
         uint32_t rmin[2], rmax[2];
@@ -311,6 +352,7 @@ void gsro_bin_mt(int n, int width, int height, const int* radii, const float* me
                 ++off;
             }
     }
+    });
     const uint32_t bits = 32 + gsro_higher_msb((uint32_t)(grid_x * grid_y));
     const uint64_t mask = (bits >= 64) ? ~0ull : ((1ull << bits) - 1ull);
     std::vector<uint64_t> order(num_rendered);
@@ -318,10 +360,12 @@ void gsro_bin_mt(int n, int width, int height, const int* radii, const float* me
     parallel_stable_sort(order, threads, [&](uint64_t a, uint64_t b) {
         return (keys_unsorted[a] & mask) < (keys_unsorted[b] & mask);
     });
-    for (uint64_t i = 0; i < num_rendered; ++i) {
-        keys[i] = keys_unsorted[order[i]];
-        values[i] = values_unsorted[order[i]];
-    }
+    parallel_ranges(num_rendered, threads, [&](uint64_t first, uint64_t last) {
+        for (uint64_t i = first; i < last; ++i) {
+            keys[i] = keys_unsorted[order[i]];
+            values[i] = values_unsorted[order[i]];
+        }
+    });
     for (uint64_t idx = 0; idx < num_rendered; ++idx) {
         const uint32_t cur = (uint32_t)(keys[idx] >> 32);
         if (idx == 0) {

@@ -336,3 +336,33 @@ def test_nan_positions_of_either_sign_match_the_oracle():
         assert np.array_equal(b["values"].cpu().numpy().view(np.uint32), exp["values"])
         assert not (b["values"].cpu().numpy() == 7).any()
         assert np.abs(img - exp["out_color"]).max() <= 1e-4
+
+
+def test_the_librarys_rccl_communicator_comes_up_on_one_rank():
+    """gsr_exchange_* load RCCL at run time (the copy PyTorch has mapped) and call it through hand-declared prototypes
+    (ncclUniqueId is 128 bytes BY VALUE): on the one-GPU box a communicator of one rank is all that can be created, which
+    still exercises dlopen, ncclGetUniqueId, ncclCommInitRank, the band validation of gsr_exchange_bands and
+    ncclCommDestroy. (The transfers themselves need peers: their plan is checked on the CPU, tests/test_sharding_gloo.py.)"""
+    import torch
+    from gsrast_amd import _capi, sharding
+    L = _capi.lib()
+    path = sharding._torch_rccl_path()
+    cpath = path.encode() if path else None
+    ident = C.create_string_buffer(128)
+    rc = L.gsr_exchange_unique_id(cpath, ident)
+    assert rc == _capi.GSR_OK, L.gsr_exchange_last_error().decode()
+    assert any(b != 0 for b in ident.raw)
+    handle = C.c_void_p()
+    with torch.cuda.device(0):
+        rc = L.gsr_exchange_create(cpath, ident.raw, 0, 1, C.byref(handle))
+    assert rc == _capi.GSR_OK and handle.value, L.gsr_exchange_last_error().decode()
+    W, H = 320, 200
+    frame = torch.rand((3, H, W), device="cuda")
+    keep = frame.clone()
+    bounds = (C.c_int32 * 2)(0, (H + 15) // 16)
+    assert L.gsr_exchange_bands(handle, frame.data_ptr(), W, H, bounds, -1, None) == _capi.GSR_OK
+    bad = (C.c_int32 * 2)(0, 5)
+    assert L.gsr_exchange_bands(handle, frame.data_ptr(), W, H, bad, -1, None) == _capi.GSR_ERR_INVALID_ARG
+    torch.cuda.synchronize()
+    assert torch.equal(frame, keep)
+    assert L.gsr_exchange_destroy(handle) == _capi.GSR_OK

@@ -56,3 +56,19 @@ def test_radius_rect_path_agrees():
     for k in ("radii", "tilesTouched", "keys", "values", "ranges", "nContrib"):
         assert np.array_equal(a[k], b[k]), k
     assert np.abs(a["out_color"] - b["out_color"]).max() <= 1e-6
+
+
+def test_threaded_oracle_gives_the_single_thread_result():
+    """bench.py's cpu_baseline runs the oracle on all host cores: preprocess, key emission, the stable sort and the tile
+    loop must give, bit for bit, what the single-thread restatement gives."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.garden_like_scene(30_000, seed=9)
+    scene["means3D"][:, :3] *= 0.3
+    cam = camera.default_camera(320, 200, near=0.05, far=60.0)
+    a = cpu_oracle.forward(scene, cam, (0.1, 0.2, 0.3), threads=1)
+    b = cpu_oracle.forward(scene, cam, (0.1, 0.2, 0.3), threads=7)
+    assert a["num_rendered"] == b["num_rendered"] > 100_000 and a["records_staged"] == b["records_staged"]
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, b[k]), k
