@@ -52,6 +52,10 @@ def parse_args():
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--splats", type=int, default=DEFAULT_SPLATS)
     p.add_argument("--scene", default="garden_like", choices=["garden_like", "stress", "isotropic"])
+    p.add_argument("--ply", default=os.environ.get("GSR_GARDEN_PLY", ""),
+                   help="a trained 3DGS .ply in the reference's format (apps/gsrast/SplatData.cpp:114-156), e.g. Mip-NeRF360 garden: "
+                        "replaces the synthetic stand-in when the file exists (default: $GSR_GARDEN_PLY); loaded through "
+                        "gsr_ply_activate, camera as the app sets it up (GSRastWindow.cpp:30-36)")
     p.add_argument("--pose", default=None, help="camera position x,y,z (default: the reference's (0,0,-5); (0,0,-25) for --scene stress)")
     p.add_argument("--opacity-scale", type=float, default=1.0, help="multiplies every opacity (0.1: blend-bound variant, R_f ~ R)")
     p.add_argument("--semantics", default="gscuda", choices=["gscuda", "inria"],
@@ -158,10 +162,18 @@ def dry_run(args) -> int:
 
 
 # ---- workload ---------------------------------------------------------------------------------------------------------
-def make_scene(name: str, n: int, device, full_sh: bool = False):
+def make_scene(name: str, n: int, device, full_sh: bool = False, ply_path: str = ""):
     """Returns (scene dict, near, far, default position, label). The 50 M stress scene is generated on the device (same
-    splitmix64 definition, gsrast_amd/scenes.py); the others on the host as in round 1."""
+    splitmix64 definition, gsrast_amd/scenes.py); the others on the host as in round 1. ply_path: a scene file in the
+    reference's format instead (its label starts with "ply:")."""
     from gsrast_amd import scenes
+    if ply_path:
+        from gsrast_amd import ply
+        sc = ply.load_ply(ply_path, device=device, sh_layout="coefficient_major" if full_sh else "file")
+        span = float((sc["bbox_max"] - sc["bbox_min"]).max().item())      # GSRastWindow.cpp:30-36: far = largest bbox span
+        sc = {k: sc[k] for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        n_file = int(sc["means3D"].shape[0])
+        return sc, 0.001 * span, span, (0.0, 0.0, -5.0), f"ply:{os.path.basename(ply_path)} (N={n_file}, the reference's loader semantics)"
     if name == "garden_like":
         sc = scenes.garden_like_scene(n, seed=43)
         span = float(np.max(sc["means3D"][:, :3].max(0) - sc["means3D"][:, :3].min(0)))
@@ -190,7 +202,7 @@ def cpu_baseline(scene, cam, every: int):
     splat of it, same camera and resolution, on all host cores."""
     from gsrast_amd import scenes
     from oracle import cpu_oracle
-    sub = scene if every == 1 else scenes.scene_rows(scene, slice(None, None, every))
+    sub = scenes.scene_rows(scene, slice(None, None, every))        # (host float32 copies, whatever the scene is held as)
     n = int(sub["means3D"].shape[0])
     cores = cpu_oracle.hardware_concurrency() or 1
     t = {}
@@ -399,22 +411,27 @@ def main() -> int:
     full_sh = inria and args.sh_degree > 0
     scene = None
     if rank == 0 or not distributed:
-        scene, near, far, pos, label = make_scene(args.scene, args.splats, device, full_sh)
+        ply_path = args.ply if (args.ply and os.path.exists(args.ply)) else ""
+        if args.ply and not ply_path:
+            print(f"bench.py: --ply {args.ply} does not exist: using the synthetic stand-in", file=sys.stderr)
+        scene, near, far, pos, label = make_scene(args.scene, args.splats, device, full_sh, ply_path)
         if args.pose:
             pos = tuple(float(v) for v in args.pose.split(","))
         if args.opacity_scale != 1.0:
-            scene["opacities"] = scene["opacities"] * np.float32(args.opacity_scale)
+            scene["opacities"] = scene["opacities"] * float(args.opacity_scale)
             label += f", opacities x {args.opacity_scale}"
-        meta = [near, far, *pos]
+        meta = [near, far, *pos, 1.0 if label.startswith("ply:") else 0.0]
     else:
-        meta, label = [0.0] * 5, ""
+        meta, label = [0.0] * 6, ""
     if distributed:
         from gsrast_amd import sharding
         m = torch.tensor(meta, dtype=torch.float64, device=device)
         dist.broadcast(m, 0)
         near, far, pos = float(m[0]), float(m[1]), tuple(float(v) for v in m[2:5])
+        from_file = bool(m[5].item() != 0.0)
         dev_scene = sharding.broadcast_scene(scene, device, 0)          # RCCL broadcast of the SoA
     else:
+        from_file = label.startswith("ply:")
         dev_scene = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v)).to(device))
                      for k, v in scene.items()}
     cam = camera.default_camera(W, H, near=near, far=far, position=pos)
@@ -428,7 +445,8 @@ def main() -> int:
                    sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp)
     m = run.measure(cam, args.steps, args.warmup, **draw_kw)
 
-    default_frame = (args.scene == "garden_like" and args.splats == DEFAULT_SPLATS and (W, H) == (1920, 1080) and not args.pose
+    # (extras and the committed PMC figures belong to the default workload; with --ply the frame is the file's)
+    default_frame = (not from_file and args.scene == "garden_like" and args.splats == DEFAULT_SPLATS and (W, H) == (1920, 1080) and not args.pose
                      and args.opacity_scale == 1.0 and not inria and not args.backward and args.plan == "auto"
                      and not args.overlap and not args.no_sorted_lists and not args.colors_precomp)
     extras = {}
@@ -531,7 +549,7 @@ def main() -> int:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": label.split(" ")[0] if label.startswith("ply:") else "synthetic",
             "config": {"workload": f"{label}, {W}x{H} forward, camera at {tuple(round(v, 3) for v in pos)}"
                                    + (" (the reference's default pose)" if not args.pose and args.scene != "stress" else ""),
                        "width": W, "height": H, "splats": n_splats, "visible": m["visible"], "num_rendered": m["num_rendered_total"],

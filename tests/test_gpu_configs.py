@@ -49,7 +49,11 @@ def _compare_with_oracle(r, exp, img, what):
     assert n_bad <= 20 and max_err <= 8e-3, (what, max_err, n_bad)        # 1e-4 abs per channel but for threshold flips
     assert np.percentile(per_pixel, 99.99) <= 1e-5, what
     nc = r.map_image_state()["nContrib"].cpu().numpy().view(np.uint32)
-    assert (nc != exp["nContrib"]).sum() <= 40, what
+    flips = int((nc != exp["nContrib"]).sum())
+    # (the numbers behind the bounds: pytest -s shows them; tests/fullsize_parity_report.py writes the round's report)
+    print(f"[parity] {what}: R={r.last_num_rendered} R_f={r.last_records_staged} plan={r.last_plan} max abs err {max_err:.3e}, "
+          f"pixels > 1e-4: {n_bad}, nContrib flips: {flips}")
+    assert flips <= 40, what
     return max_err, n_bad
 
 

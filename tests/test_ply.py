@@ -110,3 +110,33 @@ def test_ply_with_higher_order_sh_renders_under_the_inria_profile(tmp_path):
     wrong = ply.load_ply(p)                                               # file order fed to the [16][3] reader
     r.configure_from_scene({k: wrong[k] for k in host})
     assert np.abs(r.draw(cam, semantics="inria", sh_degree=3).cpu().numpy() - exp["out_color"]).max() > 1e-2
+
+
+@pytest.mark.gpu
+def test_bench_takes_a_scene_file_when_one_is_there(tmp_path):
+    """bench.py --ply PATH (or $GSR_GARDEN_PLY): the scene comes through the reference's loader semantics
+    (SplatData.cpp:114-156) and the app's camera rule (GSRastWindow.cpp:30-36), the line says "data": "ply:<file>" and
+    carries the CPU baseline of that same frame; a path that does not exist leaves the synthetic stand-in in place."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    p = str(tmp_path / "garden_small.ply")
+    sc = _random_scene(40_000, seed=21)
+    sc["position"] *= 0.4
+    ply.write_ply(p, **sc)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "640", "--height", "368",
+           "--ply", p]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["data"] == "ply:garden_small.ply" and d["config"]["splats"] == 40_000 and d["value"] > 0
+    assert "ply:garden_small.ply" in d["config"]["workload"] and d["config"]["num_rendered"] > 0
+    assert d["cpu_baseline"]["comparable"] is True and d["cpu_baseline"]["value"] > 0
+    assert "pose_outside" not in d                      # the extras belong to the default workload
+    env = dict(os.environ, GSR_GARDEN_PLY=str(tmp_path / "absent.ply"))
+    out = subprocess.run(cmd[:-2] + ["--splats", "20000", "--no-cpu-baseline", "--no-extras"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["data"] == "synthetic" and "does not exist" in out.stderr
