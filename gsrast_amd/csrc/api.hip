@@ -417,13 +417,7 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
     // one clear for the four passes' look-back words, tickets, the error word and the digit histograms
     // (the four scratch areas are adjacent in the chunk)
-#ifdef GSR_SORT_NARROW
-    const bool wide = false;
-#else
-    // up to 2^24 Gaussians with a packed rectangle: three wide passes (11 + 11 + 10 bits) instead of four byte passes
-    const bool wide = sort_u32_wide((uint32_t)n, xy_plan);
-#endif
-    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, (wide ? 3 : 4) * sweep_scratch_bytes((size_t)n), stream));
+    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, 4 * sweep_scratch_bytes((size_t)n), stream));
     SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
     // "a bounded look-back spin gave up" is written by the kernel straight into the pinned host words (it never
     // happens on a healthy device; a copy at the end of every frame for it cost 5 us of stream time)
@@ -435,7 +429,7 @@ int gsr_forward(gsr_forward_args* a) {
     // passes: both binning plans want it in depth order, and gathering it by index afterwards is a random 4-byte read per
     // Gaussian (0.93 ms of the 50 M frame).
     GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
-                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, wide));
+                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
@@ -445,20 +439,15 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
-    // (the wide scheme has no conditional pass: all of its three are queued here)
-    if (wide)
-        GSR_STEP(sort_u32_passes_wide(gs.c_k, gs.c_v, gs.c_r, (uint32_t)n, gs.a_k, gs.a_v, gs.a_r, gs.b_k, gs.b_v, gs.b_r, four, stream,
-                                      gs.sort_info + 1));
-    else
-        GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
-                                 xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
+    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
+                             xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
     // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
     // R-sized is touched (launch_sort_pairs draws the same line at n >= 0xFFFFFFFF).
     const unsigned long long true_total = (unsigned long long)g_rb.host[5] | ((unsigned long long)g_rb.host[6] << 32);
     if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
-    const bool four_passes = !wide && g_rb.host[3] > 1u;
+    const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
     if (four_passes)
         GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream, nullptr,

@@ -75,14 +75,7 @@ size_t depth_compact_scratch_bytes(size_t n);
 // index afterwards is a random 4-byte read per Gaussian).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready = false,
-                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr, bool wide = false);   // wide: the histograms of sort_u32_passes_wide
-// The depth order in three wide passes (11 + 11 + 10 bits) instead of four byte passes: keys carrying a second value, at
-// most 2^24 of them. sort_u32_prepare then leaves the wide passes' histograms, and sort_u32_passes_wide runs all three
-// (in -> a -> b -> a: the result is in a_k / a_v / a_s).
-bool sort_u32_wide(uint32_t n, bool with_second_value);
-int sort_u32_passes_wide(const uint32_t* keys_in, const uint32_t* vals_in, const uint32_t* second_in, uint32_t n, uint32_t* a_k,
-                         uint32_t* a_v, uint32_t* a_s, uint32_t* b_k, uint32_t* b_v, uint32_t* b_s, const SweepScratch* sc4,
-                         hipStream_t stream, const uint32_t* n_dev);
+                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr);
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
                     const uint32_t* n_dev = nullptr, const uint32_t* second_in = nullptr, uint32_t* a_s = nullptr,

@@ -42,7 +42,6 @@ constexpr unsigned long long kValueMask = (1ull << 62) - 1ull;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr int kLookWindow = 4;                          // predecessors' status words read per look-back round
 constexpr int kLookLanes = 1;                           // lanes sharing one digit's look-back
-constexpr int kWideMaxKeys = 1 << 24;                   // the wide (11-bit) passes of the depth order run on at most this many keys
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t digit_of(KeyT key, const DigitSpec& s) {
@@ -372,260 +371,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     }
 }
 
-
-// ---- wide digits: the depth order in three passes ------------------------------------------------------------
-// 11 + 11 + 10 bits instead of four bytes: one launch, one histogram and one look-back fewer for the same 32 bits. The
-// structure is the kernel above's with RADIX > workgroup size: every thread owns DPT = RADIX / kThreads CONSECUTIVE digits
-// (so the scans over digits are a per-thread sum, one workgroup scan, a per-thread walk), the per-wave counters are 16 bits
-// wide (a wave holds 1024 keys), and the tile leaves through LDS in four slices. u32 keys with two u32 values only.
-constexpr int kWideBits = 11, kWideRadix = 1 << kWideBits;
-constexpr int kWideStageRounds = 4;
-constexpr int kWideStageSlots = kSortTile / kWideStageRounds;
-static_assert(kItems % kWideStageRounds == 0, "items per lane must split evenly over the staging rounds");
-
-#ifndef GSR_WIDE_WAVES
-#define GSR_WIDE_WAVES 4
-#endif
-template <int BITS>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_WIDE_WAVES))) void onesweep_wide_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                   const uint32_t* __restrict__ vals2_in, uint32_t* __restrict__ vals2_out,
-                                                                   uint32_t n_host, const uint32_t* __restrict__ n_dev, int shift, uint32_t nbins,
-                                                                   const uint32_t* __restrict__ digit_hist,
-                                                                   uint32_t* status, uint32_t* ticket, uint32_t* error_word) {
-    // (status words are 32 bits here — flag in the top two bits, 30 bits of count: the wide passes run on at most
-    // kWideMaxKeys keys — so that 2048 of them per tile cost what 1024 of the 64-bit ones would)
-    constexpr uint32_t kAgg = 1u << 30, kPre = 2u << 30, kVal = (1u << 30) - 1u;
-    const uint32_t n = n_dev ? *n_dev : n_host;
-    constexpr int RADIX = 1 << BITS;
-    constexpr int DPT = RADIX / kThreads;
-    static_assert(DPT >= 1 && DPT * kThreads == RADIX, "digits must split evenly over the threads");
-    __shared__ uint16_t wave_hist[kWaves][RADIX];   // keys of digit d in wave w, then their offset inside the digit's run
-    __shared__ uint16_t run_start[RADIX];           // first slot of digit d inside the ranked tile
-    __shared__ uint32_t tile_hist[RADIX];           // digit counts of the tile
-    __shared__ uint32_t global_start[RADIX];        // output index of this tile's first digit-d key, then minus run_start
-    __shared__ uint32_t scan_ws[kWaves];
-    __shared__ uint32_t s_tile, s_fail;
-    __shared__ uint32_t stage_keys[kWideStageSlots];
-    __shared__ uint32_t stage_vals[kWideStageSlots];
-    __shared__ uint32_t stage_vals2[kWideStageSlots];
-
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (threadIdx.x == 0) {
-        s_tile = atomicAdd(ticket, 1u);
-        s_fail = 0;
-    }
-    for (int i = threadIdx.x; i < kWaves * RADIX / 2; i += kThreads) reinterpret_cast<uint32_t*>(&wave_hist[0][0])[i] = 0u;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t tile_base = tile * (uint32_t)kSortTile;
-    if (tile_base >= n) return;
-    const uint32_t valid = min((uint32_t)kSortTile, n - tile_base);
-    const uint32_t dmask = (uint32_t)RADIX - 1u;
-    const int d0 = threadIdx.x * DPT;               // this thread's digits: d0 .. d0 + DPT - 1
-
-    uint32_t key[kItems], val[kItems], rd[kItems];
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        key[i] = (local < valid) ? keys_in[tile_base + local] : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        val[i] = (local < valid) ? vals_in[tile_base + local] : 0u;
-    }
-    // exclusive scan of the global digit histogram -> first output index of every digit
-    {
-        uint32_t h[DPT], sum = 0;
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) { h[j] = ((uint32_t)(d0 + j) < nbins) ? digit_hist[d0 + j] : 0u; sum += h[j]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += o;
-        }
-        if (lane == kWave - 1) scan_ws[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w)
-            if (w < wave) run += scan_ws[w];
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) { global_start[d0 + j] = run; run += h[j]; }
-        __syncthreads();
-    }
-
-    // stable ranks: wave64 match groups + one 16-bit LDS counter per (wave, digit), as in the kernel above
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        const uint32_t d = (local < valid) ? ((key[i] >> shift) & dmask) : dmask;      // padding ranks last, in the top digit
-        uint32_t peers_lo = ~0u, peers_hi = ~0u;
-#pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const int m = __builtin_amdgcn_sbfe((int)d, b, 1);
-            const unsigned long long bal = __ballot(m != 0);
-            peers_lo &= ~((uint32_t)bal ^ (uint32_t)m);
-            peers_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)m);
-        }
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(peers_hi, __builtin_amdgcn_mbcnt_lo(peers_lo, 0u));
-        const uint32_t prior = wave_hist[wave][d];
-        if (below == 0) wave_hist[wave][d] = (uint16_t)(prior + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi));
-        rd[i] = (d << 16) | (prior + below);
-    }
-    __syncthreads();
-    uint32_t val2[kItems];
-    {
-        uint32_t first = tile_base + (uint32_t)(wave * kWaveSpan + lane);
-        asm volatile("" : "+v"(first));
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            const uint32_t e = first + (uint32_t)(i * kWave);
-            val2[i] = (e < tile_base + valid) ? vals2_in[e] : 0u;
-        }
-    }
-
-    // per digit: exclusive offsets across waves (-> the tile's count), publish, then the exclusive scan across digits
-    uint32_t cnt[DPT], sum = 0;
-#pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-        const int d = d0 + j;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t c = wave_hist[w][d];
-            wave_hist[w][d] = (uint16_t)acc;
-            acc += c;
-        }
-        const uint32_t real = (d == RADIX - 1) ? acc - ((uint32_t)kSortTile - valid) : acc;      // padding is not published
-        tile_hist[d] = real;
-        if ((uint32_t)d < nbins)
-            __hip_atomic_store(status + (size_t)tile * RADIX + d, (tile == 0 ? kPre : kAgg) | real, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        cnt[j] = acc;
-        sum += acc;
-    }
-    {
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += o;
-        }
-        if (lane == kWave - 1) scan_ws[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w)
-            if (w < wave) run += scan_ws[w];
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) { run_start[d0 + j] = (uint16_t)run; run += cnt[j]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t d = rd[i] >> 16;
-        rd[i] = (rd[i] & 0xFFFF0000u) | ((rd[i] & 0xFFFFu) + (uint32_t)run_start[d] + (uint32_t)wave_hist[wave][d]);
-    }
-
-    // decoupled look-back, DPT digits per thread side by side: a round reads kLookWindow predecessors of every digit
-    if (tile != 0) {
-        uint32_t excl[DPT];
-        uint32_t t[DPT];
-        bool found[DPT];
-        bool all_found = true;
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) {
-            excl[j] = 0;
-            t[j] = tile;
-            found[j] = (uint32_t)(d0 + j) >= nbins;
-            all_found = all_found && found[j];
-        }
-        uint32_t spins = 0;
-        while (!all_found) {
-            uint32_t sw[DPT][kLookWindow];
-#pragma unroll
-            for (int j = 0; j < DPT; ++j)
-#pragma unroll
-                for (int k = 0; k < kLookWindow; ++k) {
-                    const uint32_t tk = (t[j] > (uint32_t)k) ? t[j] - 1 - (uint32_t)k : 0u;
-                    sw[j][k] = found[j] ? 0u : __hip_atomic_load(status + (size_t)tk * RADIX + (d0 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            bool progress = false;
-            all_found = true;
-#pragma unroll
-            for (int j = 0; j < DPT; ++j) {
-                if (found[j]) continue;
-                bool open = true;
-#pragma unroll
-                for (int k = 0; k < kLookWindow; ++k) {
-                    if (open && t[j] > 0u) {
-                        const uint32_t f = sw[j][k] & ~kVal;
-                        if (f != 0) {
-                            excl[j] += sw[j][k] & kVal;
-                            t[j] -= 1u;
-                            progress = true;
-                            if (f == kPre) { found[j] = true; open = false; }
-                        } else {
-                            open = false;
-                        }
-                    }
-                }
-                all_found = all_found && found[j];
-            }
-            if (!all_found && !progress) {
-                if (++spins > kSpinLimit) { s_fail = 1; *reinterpret_cast<volatile uint32_t*>(error_word) = 1u; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) {
-            const int d = d0 + j;
-            if ((uint32_t)d < nbins && found[j]) {
-                __hip_atomic_store(status + (size_t)tile * RADIX + d, kPre | (excl[j] + tile_hist[d]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                global_start[d] += excl[j];
-            }
-        }
-    }
-    __syncthreads();
-    if (s_fail) return;
-#pragma unroll
-    for (int j = 0; j < DPT; ++j) global_start[d0 + j] -= (uint32_t)run_start[d0 + j];      // (u32 wrap-around: a delta)
-    __syncthreads();
-
-#pragma unroll
-    for (int r = 0; r < kWideStageRounds; ++r) {
-        if (r > 0) __syncthreads();
-#pragma unroll
-        for (int i = 0; i < kItems; ++i) {
-            const uint32_t slot = (rd[i] & 0xFFFFu) - (uint32_t)(r * kWideStageSlots);
-            if (slot < (uint32_t)kWideStageSlots) {
-                stage_keys[slot] = key[i];
-                stage_vals[slot] = val[i];
-                stage_vals2[slot] = val2[i];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < kItems / kWideStageRounds; ++i) {
-            const uint32_t q = (uint32_t)(i * kThreads) + threadIdx.x;
-            const uint32_t p = q + (uint32_t)(r * kWideStageSlots);
-            if (p < valid) {
-                const uint32_t k = stage_keys[q];
-                const uint32_t dst = p + global_start[(k >> shift) & dmask];
-                if (dst < n) {
-                    keys_out[dst] = k;
-                    vals_out[dst] = stage_vals[q];
-                    vals2_out[dst] = stage_vals2[q];
-                }
-            }
-        }
-    }
-}
-
 inline int radix_bits_for(uint32_t nbins) {
     int bits = 1;
     while ((1u << bits) < nbins) ++bits;
@@ -673,26 +418,21 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
-// Look-back words of one pass over n keys: 256 x 8 bytes per tile for the byte passes; a wide pass (n <= kWideMaxKeys)
-// takes 2048 x 4 bytes per tile.
-static size_t status_bytes(size_t n) {
-    const size_t tiles = (n + kSortTile - 1) / kSortTile;
-    return align_up(tiles * (n <= (size_t)kWideMaxKeys ? (size_t)kWideRadix * sizeof(uint32_t) : 256 * sizeof(unsigned long long)), 128);
-}
-constexpr size_t kHistWords = 3 * kWideRadix;        // >= 8 x 256: the digit counts of every pass of a sort
-
 size_t sweep_scratch_bytes(size_t n) {
-    return status_bytes(n) + 128 /*ticket*/ + 128 /*error*/ + align_up(kHistWords * sizeof(uint32_t), 128);
+    const size_t tiles = (n + kSortTile - 1) / kSortTile;
+    return align_up(tiles * 256 * sizeof(unsigned long long), 128) + 128 /*ticket*/ + 128 /*error*/ +
+           align_up(8 * 256 * sizeof(uint32_t), 128);
 }
 
 SweepScratch carve_sweep_scratch(char* base, size_t n) {
+    const size_t tiles = (n + kSortTile - 1) / kSortTile;
     SweepScratch s;
     size_t off = 0;
     s.ticket = reinterpret_cast<uint32_t*>(base + off); off += 128;     // directly in front of the status
     s.status = reinterpret_cast<unsigned long long*>(base + off);      // words: one clear covers both
-    off += status_bytes(n);
+    off += align_up(tiles * 256 * sizeof(unsigned long long), 128);
     s.error_word = reinterpret_cast<uint32_t*>(base + off); off += 128;
-    s.hist = reinterpret_cast<uint32_t*>(base + off); off += align_up(kHistWords * sizeof(uint32_t), 128);
+    s.hist = reinterpret_cast<uint32_t*>(base + off); off += align_up(8 * 256 * sizeof(uint32_t), 128);
     return s;
 }
 
@@ -807,23 +547,17 @@ __global__ __launch_bounds__(1024) void visible_scan_kernel(uint32_t* __restrict
 // visible key (the histograms of the four sort passes) on the way
 // rect_by_index / out_r (may be null): the visible Gaussians' packed rectangles are compacted with the pairs — here, in
 // index order, that read is coalesced; they then travel through the depth passes as the keys' second value.
-// WIDE: the histograms are those of the three wide passes (bits 0-10, 11-21, 22-31: 2048 + 2048 + 1024 counters), and
-// info[4] (the frame's count of tiles with a list, see top_digit_count_kernel) is zeroed here.
-template <bool WIDE>
 __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                           const uint32_t* __restrict__ partial,
                                                                           const uint32_t* __restrict__ rect_by_index,
                                                                           uint32_t* __restrict__ out_k, uint32_t* __restrict__ out_v,
                                                                           uint32_t* __restrict__ out_r,
-                                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ info) {
+                                                                          uint32_t* __restrict__ hist) {
     constexpr int kCompactWaves = kCompactThreads / kWave;
     static_assert(kCompactRows * kCompactWaves == kWave, "one wave scans the (row, wave) counts");
-    constexpr int kHist = WIDE ? 3 * kWideRadix : 4 * 256;
-    constexpr int kTopAt = WIDE ? 2 * kWideRadix : 768, kTopShift = WIDE ? 2 * kWideBits : 24;
-    __shared__ uint32_t lds[kHist];
+    __shared__ uint32_t lds[4 * 256];
     __shared__ uint32_t s_off[kCompactRows * kCompactWaves];       // (row, wave): keys of that row in that wave, then where they go
-    for (int i = threadIdx.x; i < kHist; i += kCompactThreads) lds[i] = 0;
-    if (WIDE && blockIdx.x == 0 && threadIdx.x == 0) info[4] = 0u;
+    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads) lds[i] = 0;
     const uint32_t base = blockIdx.x * kCompactChunk;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     // All rows are loaded before anything is counted (one round trip), and the output offsets of all (row, wave)
@@ -872,28 +606,23 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
             out_k[pos] = k[r];
             out_v[pos] = e;
             if (out_r) out_r[pos] = rect[r];
-            if constexpr (WIDE) {
-                atomicAdd(&lds[k[r] & (kWideRadix - 1u)], 1u);
-                atomicAdd(&lds[kWideRadix + ((k[r] >> kWideBits) & (kWideRadix - 1u))], 1u);
-            } else {
-                atomicAdd(&lds[k[r] & 255u], 1u);
-                atomicAdd(&lds[256 + ((k[r] >> 8) & 255u)], 1u);
-                atomicAdd(&lds[512 + ((k[r] >> 16) & 255u)], 1u);
-            }
+            atomicAdd(&lds[k[r] & 255u], 1u);
+            atomicAdd(&lds[256 + ((k[r] >> 8) & 255u)], 1u);
+            atomicAdd(&lds[512 + ((k[r] >> 16) & 255u)], 1u);
         }
-        // The top digit of float bit patterns takes few distinct values: one LDS atomic per distinct value
+        // The top byte of float bit patterns takes few distinct values: one LDS atomic per distinct value
         // and wave instead of 64 colliding on the same counter.
-        const uint32_t d = k[r] >> kTopShift;
+        const uint32_t d = k[r] >> 24;
         unsigned long long todo = m[r];
         while (todo) {
             const uint32_t v = (uint32_t)__shfl((int)d, __ffsll((long long)todo) - 1, kWave);
             const unsigned long long same = __ballot(vis && d == v) & todo;
-            if (lane == __ffsll((long long)same) - 1) atomicAdd(&lds[kTopAt + v], (uint32_t)__popcll(same));
+            if (lane == __ffsll((long long)same) - 1) atomicAdd(&lds[768 + v], (uint32_t)__popcll(same));
             todo &= ~same;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kHist; i += kCompactThreads)
+    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads)
         if (lds[i]) atomicAdd(&hist[i], lds[i]);
 }
 }  // namespace
@@ -904,13 +633,10 @@ size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChu
 // the four sort passes, and (top_digits) the number of distinct top-byte digits: with at most one the
 // fourth pass would move nothing. info[0] = top_digits, info[1] = visible count (device words); info[4] is zeroed
 // (the frame's non-empty-tile counter; info must hold at least five words).
-bool sort_u32_wide(uint32_t n, bool with_second_value) { return with_second_value && n <= (uint32_t)kWideMaxKeys; }
-
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready,
-                     const uint32_t* rect_by_index, uint32_t* out_r, bool wide) {
+                     const uint32_t* rect_by_index, uint32_t* out_r) {
     if (n == 0) return GSR_OK;
-    if (wide && !sort_u32_wide(n, rect_by_index != nullptr)) return GSR_ERR_INVALID_ARG;
     const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
     if (!offsets_ready) {
         hipLaunchKernelGGL(visible_count_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial);
@@ -919,41 +645,11 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
         GSR_LAUNCH_CHECK("visible_scan_kernel");
     }
     if ((rect_by_index == nullptr) != (out_r == nullptr)) return GSR_ERR_INVALID_ARG;
-    if (wide) {
-        // three wide passes follow whatever the keys are: no count of distinct top digits, one launch fewer
-        hipLaunchKernelGGL(visible_compact_kernel<true>, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial,
-                           rect_by_index, out_k, out_v, out_r, sc4[0].hist, info);
-        GSR_LAUNCH_CHECK("visible_compact_kernel");
-        return GSR_OK;
-    }
-    hipLaunchKernelGGL(visible_compact_kernel<false>, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
-                       out_k, out_v, out_r, sc4[0].hist, info);
+    hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
+                       out_k, out_v, out_r, sc4[0].hist);
     GSR_LAUNCH_CHECK("visible_compact_kernel");
     hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info);
     GSR_LAUNCH_CHECK("top_digit_count_kernel");
-    return GSR_OK;
-}
-
-// The three wide passes (bits 0-10, 11-21, 22-31) of the depth order: in -> a -> b -> a; the result is in (a_k, a_v, a_s).
-// sc4: the scratch of sort_u32_prepare (look-back words of passes 0-2 in sc4[0..2], histograms and error word in sc4[0]).
-int sort_u32_passes_wide(const uint32_t* keys_in, const uint32_t* vals_in, const uint32_t* second_in, uint32_t n, uint32_t* a_k,
-                         uint32_t* a_v, uint32_t* a_s, uint32_t* b_k, uint32_t* b_v, uint32_t* b_s, const SweepScratch* sc4,
-                         hipStream_t stream, const uint32_t* n_dev) {
-    if (n == 0) return GSR_OK;
-    if (!sort_u32_wide(n, second_in != nullptr)) return GSR_ERR_INVALID_ARG;
-    const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
-    const uint32_t *src_k = keys_in, *src_v = vals_in, *src_s = second_in;
-    for (int p = 0; p < 3; ++p) {
-        uint32_t* dst_k = (p % 2 == 0) ? a_k : b_k;
-        uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
-        uint32_t* dst_s = (p % 2 == 0) ? a_s : b_s;
-        const uint32_t nbins = p < 2 ? (uint32_t)kWideRadix : 1u << (32 - 2 * kWideBits);
-        hipLaunchKernelGGL(onesweep_wide_kernel<kWideBits>, dim3(tiles), dim3(kThreads), 0, stream, src_k, src_v, dst_k, dst_v, src_s,
-                           dst_s, n, n_dev, p * kWideBits, nbins, sc4[0].hist + p * kWideRadix,
-                           reinterpret_cast<uint32_t*>(sc4[p].status), sc4[p].ticket, sc4[0].error_word);
-        GSR_LAUNCH_CHECK("onesweep_wide_kernel");
-        src_k = dst_k; src_v = dst_v; src_s = dst_s;
-    }
     return GSR_OK;
 }
 
