@@ -486,7 +486,9 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
     // ticket per workgroup, so that the loads miss the caches once): 0.650 ms on the bench frame, the waves wait for the
     // slowest quarter. One queue per XCD (XCD x takes the units u = x mod 8, so that the four quarters of a unit are loaded
     // through one L2): 0.703 ms on the bench frame, 3.17 ms at 3840 x 2160 — the quarters' re-reads (FETCH_SIZE 84 -> 248 MB
-    // per launch) are not what the kernel waits for. (`gpurun_out/r3b` - `r3d`.)
+    // per launch) are not what the kernel waits for. Nor does dealing the first 50 / 70 / 85 % of the units statically
+    // (workgroup g: units g, g + G, ..., a quarter per wave, no waiting) and only the rest from the queue help: 0.645 /
+    // 0.654 / 0.704 ms. What pays is the fine-grained dynamic dealing itself. (`gpurun_out/r3b` - `r3d`.)
     const uint32_t nwaves = gridDim.x * kEmitWaves;
     const uint32_t keys_per_unit = r_total / max(total_units, 1u);
     const uint32_t parts = (total_units >= 32u * nwaves || keys_per_unit < kDenseUnitKeys) ? 1u : 4u;
