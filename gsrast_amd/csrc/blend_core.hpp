@@ -291,6 +291,22 @@ __device__ __forceinline__ void tile_lanes_write(const TileLanes& s, int width, 
     }
 }
 
+// Issue priority of a tile's wave by what is LEFT of its list (re-evaluated batch by batch). A frame lasts as long as its
+// deepest tile, every tile's wave is resident from the start (8 160 tiles, 8 per SIMD), and without this a deep tile gets an
+// eighth of its SIMD's issue slots until the shallow ones are gone. Used by the blend from the sorted lists, one wave per
+// tile, where the lists are long on average (8 192 entries per tile with a list) — the frames of small splats seen from
+// outside, whose lists differ widely in length: 0.427 -> 0.416 ms from outside the cloud, 3.29 -> 2.84 ms with faint splats.
+// (Shorter lists, eye (0,0,-30): 0.502 -> 0.52 ms with it — not used there.) On frames whose tiles all finish after a few hundred entries of 32 K-entry lists (the bench
+// frame, block-fed) any difference in priority only delays somebody's chain of round trips (0.098 -> 0.101 ms), and where
+// every tile walks a list of about the same length (bench frame with faint splats) it changes nothing: the block-fed
+// blend and the four-waves-per-tile mode do not use it (`gpurun_out`, ab_extras runs after `r3n`).
+__device__ __forceinline__ void set_tile_priority(uint32_t remaining) {
+    if (remaining > 32768u) __builtin_amdgcn_s_setprio(3);
+    else if (remaining > 8192u) __builtin_amdgcn_s_setprio(2);
+    else if (remaining > 2048u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // Tile of a workgroup. Workgroup b runs on XCD b % 8, and each XCD has its own L2. Tiles dealt in tile order put every
 // eighth tile on an XCD: perfectly level, but the eight neighbours of a tile — which gather largely the same Gaussians —
 // are on the seven other L2s. Giving every XCD one contiguous eighth of the image measured 6-23 % SLOWER (the image's
