@@ -501,6 +501,7 @@ def main() -> int:
             c3 = brief(e, n_splats, "BASELINE config 3: same scene and pose at 3840x2160, tile rows sharded over the ranks")
             c3["per_rank"], c3["bands"] = e["per_rank"], e["bands"]
             extras["config3_4k"] = c3
+            run4k.exch.close()
             del run4k
 
     if rank == 0:
@@ -579,6 +580,8 @@ def main() -> int:
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)
     if distributed:
+        if run.exch is not None:
+            run.exch.close()                  # (the library's own RCCL communicator, if the exchange ran on it)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
