@@ -148,6 +148,7 @@ SIGNATURES = {
     "gsr_exchange_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "gsr_exchange_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gsr_exchange_loopback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "gsr_exchange_destroy": (C.c_int, [C.c_void_p]),
     "gsr_exchange_last_error": (C.c_char_p, []),
     "gsr_ply_parse_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),

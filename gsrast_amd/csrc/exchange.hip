@@ -204,6 +204,28 @@ int gsr_exchange_plan(int rank, int world, int width, int height, const int32_t*
     return rc == GSR_OK ? n : -rc;
 }
 
+// A rank's transfer to itself: `planes` pieces of `count` floats from src to dst through ncclSend / ncclRecv in one group,
+// the shape of a peer's band. What a one-GPU box can run of the transfer path (RCCL matches a send to the own rank with
+// the receive from it inside a group).
+int gsr_exchange_loopback(gsr_exchange* x, const float* src, float* dst, uint64_t count, int planes, void* stream) {
+    g_exchange_error[0] = 0;
+    if (!x || !src || !dst || planes < 1) return record_error(GSR_ERR_INVALID_ARG);
+    auto run = [&]() -> int {
+        GSR_RCCL_TRY(g_rccl.group_start(), "ncclGroupStart");
+        int rc = GSR_OK;
+        for (int c = 0; c < planes && rc == GSR_OK; ++c) {
+            int e = g_rccl.send(src + (size_t)c * count, (size_t)count, kNcclFloat32, x->rank, x->comm, (hipStream_t)stream);
+            if (e == 0) e = g_rccl.recv(dst + (size_t)c * count, (size_t)count, kNcclFloat32, x->rank, x->comm, (hipStream_t)stream);
+            if (e != 0) rc = rccl_failed(e, "ncclSend / ncclRecv to the own rank");
+        }
+        const int ce = g_rccl.group_end();
+        if (rc != GSR_OK) return rc;
+        if (ce != 0) return rccl_failed(ce, "ncclGroupEnd");
+        return GSR_OK;
+    };
+    return record_error(run());
+}
+
 int gsr_exchange_bands(gsr_exchange* x, float* frame, int width, int height, const int32_t* bounds, int root, void* stream) {
     g_exchange_error[0] = 0;
     return record_error(exchange_impl(x, frame, width, height, bounds, root, (hipStream_t)stream));

@@ -352,6 +352,8 @@ int gsr_forward_points(gsr_forward_args* args);
  *                            allowed); root < 0: every rank receives every band (all-gather); root = r: only rank r
  *                            receives (gather: 1 / world of the traffic when one rank displays). Asynchronous on `stream`.
  *   gsr_exchange_plan      : host only, no communicator: the transfers a rank would issue, in order (tests, tools)
+ *   gsr_exchange_loopback  : `planes` pieces of `count` floats sent from src to dst on the OWN rank through the same
+ *                            group of ncclSend / ncclRecv (a diagnostic: what a single GPU can run of the transfers)
  * All return GSR_OK or an error code (gsr_exchange_plan: the count, or the negated code); gsr_exchange_last_error() has
  * the RCCL / loader message behind a GSR_ERR_HIP. */
 typedef struct gsr_exchange gsr_exchange;
@@ -360,6 +362,7 @@ int gsr_exchange_create(const char* rccl_path, const char* id128, int rank, int 
 int gsr_exchange_bands(gsr_exchange* x, float* frame, int width, int height, const int32_t* bounds, int root, void* stream);
 int gsr_exchange_plan(int rank, int world, int width, int height, const int32_t* bounds, int root, int max_ops,
                       int32_t* is_send, int32_t* peer, uint64_t* offset, uint64_t* count);
+int gsr_exchange_loopback(gsr_exchange* x, const float* src, float* dst, uint64_t count, int planes, void* stream);
 int gsr_exchange_destroy(gsr_exchange* x);
 const char* gsr_exchange_last_error(void);
 

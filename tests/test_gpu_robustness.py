@@ -365,4 +365,16 @@ def test_the_librarys_rccl_communicator_comes_up_on_one_rank():
     assert L.gsr_exchange_bands(handle, frame.data_ptr(), W, H, bad, -1, None) == _capi.GSR_ERR_INVALID_ARG
     torch.cuda.synchronize()
     assert torch.equal(frame, keep)
+    # the transfers themselves, as far as one GPU goes: a band's three pieces sent to the own rank (ncclGroupStart,
+    # ncclSend, ncclRecv, ncclGroupEnd through the hand-declared prototypes, on a stream that is not the default one)
+    side = torch.cuda.Stream()
+    y0, y1 = 48, 160
+    src = frame[:, y0:y1, :].contiguous()
+    dst = torch.full_like(src, -1.0)
+    torch.cuda.synchronize()
+    rc = L.gsr_exchange_loopback(handle, src.data_ptr(), dst.data_ptr(), (y1 - y0) * W, 3, side.cuda_stream)
+    assert rc == _capi.GSR_OK, L.gsr_exchange_last_error().decode()
+    side.synchronize()
+    assert torch.equal(dst, src)
+    assert L.gsr_exchange_loopback(handle, None, dst.data_ptr(), 16, 1, None) == _capi.GSR_ERR_INVALID_ARG
     assert L.gsr_exchange_destroy(handle) == _capi.GSR_OK
