@@ -464,6 +464,11 @@ def main() -> int:
             # (b) forward-only callers: GSR_FLAG_NO_SORTED_LISTS on the headline frame
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["no_sorted_lists"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_SORTED_LISTS (block plan: the 12 R bytes of sorted keys / values are not written)")
+            # (b'') GSR_FLAG_OVERLAP_EMIT on the headline frame: the blend on a second stream beside the emission
+            e = run.measure(cam, **short, **{**draw_kw, "overlap_emit": True})
+            extras["overlap_emit"] = brief(e, n_splats, "headline frame with GSR_FLAG_OVERLAP_EMIT: the blend (vector-issue-bound) runs on a second stream beside "
+                                                        "the emission (HBM-write-bound); same outputs. Each kernel runs longer while they share the chip, so the "
+                                                        "headline and its per-kernel roofline figures are taken WITHOUT the flag")
             # (b') the caller-side route the reference's signature offers around the 192-byte-stride DC read: colorsPrecomp
             e = run.measure(cam, **short, **{**draw_kw, "colors_precomp": True})
             b = brief(e, n_splats, "headline frame with the colours passed as colorsPrecomp (GSCuda.cuh:111; computed once per scene, "

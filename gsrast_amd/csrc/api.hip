@@ -122,7 +122,7 @@ struct Readback {
     int begin_of[GSR_NUM_STAGES] = {};        // event index a stage starts at (default 2s)
     void ev_alias_begin(int stage, int after_stage) { begin_of[stage] = 2 * after_stage + 1; }
     hipEvent_t ev_r = nullptr;                // "numRendered has landed in host memory"
-    hipStream_t side = nullptr;               // block plan: the emission runs here, beside the blend
+    hipStream_t side = nullptr;               // block plan, GSR_FLAG_OVERLAP_EMIT: the blend runs here, beside the emission
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ensure_side() {
         if (!side) {
@@ -493,6 +493,8 @@ int gsr_forward(gsr_forward_args* a) {
     // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
     if (!use_blocks)
         GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram
+    // (before the streams fork: the blend may run on the side stream)
+    if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     bool forked = false, blend_from_lists = false;
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
@@ -518,14 +520,16 @@ int gsr_forward(gsr_forward_args* a) {
         // from outside the cloud, R/V = 23: 0.65 against 0.45 ms; from far away, R/V = 5: 1.98 against 0.65 ms; bench
         // frame, R/V = 88: equal). With the sorted lists written anyway, sparse frames blend from them.
         blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) && (uint64_t)R < 48ull * (uint64_t)nv;
-        hipStream_t emit_stream = stream;
+        // (the emission stays on the caller's stream and is launched first: its persistent workgroups must be resident
+        // before the blend's thousands of waves arrive — the other way round the blend takes every register file and the
+        // emission starts when the blend is nearly over: no gain)
         if (!serial) {
             GSR_STEP(g_rb.ensure_side());
             GSR_HIP_TRY(hipEventRecord(g_rb.ev_fork, stream));
             GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_fork, 0));
-            emit_stream = g_rb.side;
             forked = true;
         }
+        hipStream_t emit_stream = stream;
         // (What a gsr_backward call after this one may use — the block lists and, for its per-entry gradient sums, the
         // bytes of keysUnsorted — it works out from the receipt: lists_of_receipt.)
         if (blend_from_lists) a->plan_used |= GSR_PLAN_BLEND_FROM_LISTS;
@@ -543,7 +547,6 @@ int gsr_forward(gsr_forward_args* a) {
                 g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
             }
         }
-        if (forked) GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
         SweepScratch bsw = bs.sweep;
@@ -593,19 +596,22 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_tile_ranges(bin.keys, R, img.ranges, num_tiles, inria, stream, gs.sort_info + 4));
         GSR_END(GSR_STAGE_RANGES);
     }
-    if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
-    GSR_BEGIN(GSR_STAGE_BLEND);
+    hipStream_t blend_stream = forked ? g_rb.side : stream;
+    if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)
         GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
                                      colors, geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color,
-                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, stream));
+                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, blend_stream));
     else
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                              t_cutoff, stream, gs.sort_info + 4, R));                               // :804-810
-    GSR_END(GSR_STAGE_BLEND);
-    if (forked) GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));      // the sorted lists are complete too
+                              t_cutoff, blend_stream, gs.sort_info + 4, R));                         // :804-810
+    if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
+    if (forked) {                                                           // the image is complete when the side stream is
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
+        GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));
+    }
 
     if (profile || count_staged) {
         if (count_staged)

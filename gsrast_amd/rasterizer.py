@@ -129,7 +129,7 @@ class SplatRasterizer:
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
         rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3].
         plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan.
-        overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: emission on a second stream beside the blend).
+        overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: the blend on a second stream beside the emission).
         sorted_lists=False: GSR_FLAG_NO_SORTED_LISTS (forward-only callers; last_lists_written tells whether the
         binning chunk holds the sorted keys / values of this call).
         colors_precomp: pass the scene's colours as the reference's `colorsPrecomp` argument (GSCuda.cuh:111) — computed once

@@ -113,8 +113,11 @@ enum {
  * keysUnsorted / valuesUnsorted then hold that plan's block lists (scratch, as sortingSpace is). */
 #define GSR_FLAG_PLAN_SORT 0x8u
 #define GSR_FLAG_PLAN_BLOCKS 0x10u
-/* Block plan only: run the emission of the sorted lists on a second stream beside the blend (which reads the
- * block lists and does not need them). Same results; the call's work is complete, as always, when `stream` is. */
+/* Block plan only: the blend (which reads the block lists, not the sorted lists) runs on a second stream beside the
+ * emission of the sorted lists: one is bound by vector issue, the other by the HBM write path. Same results; the call's
+ * work is complete, as always, when `stream` is. Shorter frames where the blend is the shorter of the two (bench frame
+ * 1.43 -> 1.38 ms, 4K 4.21 -> 3.97 ms); each kernel runs longer while they share the chip, so per-kernel times are no
+ * longer those of the kernels alone (the bench's default frame does not set it for that reason). */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
 /* Forward-only callers: under the block plan the blend can be fed from the block lists without reading the sorted
  * keys / values (it is by default on frames of 48 or more instances per visible Gaussian), and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
