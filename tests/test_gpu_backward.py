@@ -25,7 +25,8 @@ def _forward_state(r):
 @pytest.mark.parametrize("w,h,n,seed,bg,feed", [(64, 48, 300, 1, (0.0, 0.0, 0.0), "sorted"),
                                                 (100, 70, 1200, 2, (0.2, 0.5, 0.9), "sorted"),
                                                 (100, 70, 1200, 2, (0.2, 0.5, 0.9), "blocks"),
-                                                (200, 136, 7000, 3, (0.1, 0.0, 0.3), "blocks")])
+                                                (200, 136, 7000, 3, (0.1, 0.0, 0.3), "blocks"),
+                                                (200, 136, 7000, 3, (0.1, 0.0, 0.3), "overlap")])
 def test_backward_matches_float64_oracle(w, h, n, seed, bg, feed):
     """feed = "blocks": the forward call ran with GSR_FLAG_NO_SORTED_LISTS, so gsr_backward walks the tile lists out of
     the block lists (several units per block and several blocks in the last case); the oracle gets the sorted list of
@@ -39,7 +40,9 @@ def test_backward_matches_float64_oracle(w, h, n, seed, bg, feed):
     cam = camera.default_camera(w, h, near=0.05, far=50.0)
     r = SplatRasterizer(w, h, background=bg)
     r.configure_from_scene(scene)
-    img = r.draw(cam, plan="blocks" if feed == "blocks" else "auto").cpu().numpy()
+    # ("overlap": GSR_FLAG_OVERLAP_EMIT — the blend ran on the library's second stream beside the emission; the backward
+    # call, on the caller's stream, must find the image state and the sorted lists complete)
+    img = r.draw(cam, plan="auto" if feed == "sorted" else "blocks", overlap_emit=feed == "overlap").cpu().numpy()
     assert r.last_num_rendered > 0
     g, im, b = _forward_state(r)
     if feed == "blocks":
