@@ -348,6 +348,48 @@ def test_random_small_frames_against_oracle(seed):
     _compare_all(r, img, exp, n)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_extreme_but_finite_inputs_against_oracle(seed):
+    """Values a trained scene does not hold but a caller may pass: scales from 1e-8 to screen-filling and 1e6 : 1
+    needles, quaternions far from unit length, opacities 0, 1, above 1 and below 0, splats on the camera plane
+    (clip w = 0: 1 / (w + 0.001)), behind the eye and 1e5 units away, an eye inside the cloud looking anywhere. The
+    integer outputs, every per-Gaussian float and both lists must still be the oracle's bit for bit under both plans
+    (the module fixture); pixels within the tolerance (a pixel on a hard threshold may flip: bounded)."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    rng = np.random.default_rng(7000 + seed)
+    w, h = int(rng.integers(40, 500)), int(rng.integers(40, 300))
+    n = int(rng.integers(200, 3000))
+    scene = scenes.garden_like_scene(n, seed=7100 + seed)
+    scene["means3D"][:, :3] *= 0.3
+    pick = lambda frac: rng.random(n) < frac
+    sc = scene["scales"]
+    sc[pick(0.05), :3] = 1e-8
+    sc[pick(0.05), :3] *= 1e3                                                # screen-filling
+    needle = pick(0.1)
+    sc[needle, 0] *= 1e3; sc[needle, 1] *= 1e-3                              # 1e6 : 1
+    scene["rotations"][pick(0.1)] *= 1e3                                     # far from unit length (the preprocess re-normalises)
+    scene["rotations"][pick(0.1)] *= 1e-3
+    op = scene["opacities"]
+    op[pick(0.05)] = 0.0; op[pick(0.05)] = 1.0; op[pick(0.03)] = 2.0; op[pick(0.03)] = -0.5; op[pick(0.05)] = 1e-9
+    eye = np.array([0.0, 0.0, -1.5]) if seed % 2 else rng.uniform(-1.0, 1.0, 3)
+    yaw, pitch = (0.0, 0.0) if seed % 2 else (float(rng.uniform(-3.1, 3.1)), float(rng.uniform(-1.0, 1.0)))
+    front = np.array([np.cos(pitch) * np.sin(yaw), np.sin(pitch), np.cos(pitch) * np.cos(yaw)])
+    m = scene["means3D"]
+    on_plane = pick(0.03)                                                    # on the camera plane: forward distance exactly 0 (or as near as float32 goes)
+    m[on_plane, :3] -= (((m[on_plane, :3] - eye) @ front)[:, None] * front[None, :]).astype(np.float32)
+    m[pick(0.02), :3] *= 1e5                                                 # far outside the frustum's depth range
+    cam = camera.first_person_camera(tuple(float(v) for v in eye), yaw, pitch, float(np.radians(45.0)), 0.01, 60.0, w, h, True)
+    bg = tuple(float(v) for v in rng.uniform(0, 1, 3))
+    exp = cpu_oracle.forward(scene, cam, bg)
+    if exp["num_rendered"] == 0:
+        pytest.skip("nothing visible for this seed")
+    for k in ("means2D", "conicOpacity", "cov3D", "depths"):
+        assert np.isfinite(exp[k][exp["tilesTouched"] != 0]).all(), f"oracle {k}: not a finite-input case any more"
+    r, img = _run(scene, cam, bg)
+    _compare_all(r, img, exp, n, max_bad_pixels=3)
+
+
 def test_four_waves_per_tile_blend_matches_one_wave_per_tile():
     """Calls with few tiles blend with four waves per tile (one 16 x 4 strip each) unless the staged records are
     counted; both forms must give the same pixels, nContrib and finalT bit for bit."""
