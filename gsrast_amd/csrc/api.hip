@@ -110,7 +110,7 @@ constexpr uint32_t kAsyncSlots = 64;       // error-word slots handed out in tur
 constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned block
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
-    uint32_t* host = nullptr;          // [3] top digits, [4] V, [5..6] u64 un-wrapped instance count, [8..9] staged count;
+    uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count (all three written by the kernels that compute them), [8..9] staged count;
                                        // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
                                        // written by the kernels themselves), serial of the owning call, 0}
     uint32_t serial = 0;               // calls made so far by this thread on this device
@@ -407,17 +407,18 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
+    // Its first launch also clears the depth order's four scratch areas (look-back words, tickets, the digit histograms:
+    // adjacent in the chunk), and its one-workgroup launch leaves V and the un-wrapped instance count in the pinned host
+    // words themselves: a memset and a copy command of their own were two more 5 us stops on this chain of small launches.
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
                                    gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2),
-                                   gs.vis_partial, gs.sort_info + 1));
+                                   gs.vis_partial, gs.sort_info + 1, g_rb.host_dev + 4,
+                                   gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n)));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
     // Gaussian BEFORE duplication (N keys, not R): depth order here, tile order below.
     GSR_BEGIN(GSR_STAGE_DEPTH_ORDER);
-    // one clear for the four passes' look-back words, tickets, the error word and the digit histograms
-    // (the four scratch areas are adjacent in the chunk)
-    GSR_HIP_TRY(hipMemsetAsync(gs.sweep.ticket, 0, 4 * sweep_scratch_bytes((size_t)n), stream));
     SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
     // "a bounded look-back spin gave up" is written by the kernel straight into the pinned host words (it never
     // happens on a healthy device; a copy at the end of every frame for it cost 5 us of stream time)
@@ -429,13 +430,13 @@ int gsr_forward(gsr_forward_args* a) {
     // passes: both binning plans want it in depth order, and gathering it by index afterwards is a random 4-byte read per
     // Gaussian (0.93 ms of the 50 M frame).
     GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
-                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr));
+                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
     // move nothing.
-    // (one copy: numRendered is the low word of the un-wrapped instance count that comes with them)
-    GSR_HIP_TRY(hipMemcpyAsync(g_rb.host + 3, gs.sort_info, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    // (no copy command: the kernels that computed the three figures wrote them into the pinned words as well; numRendered
+    // is the low word of the un-wrapped instance count)
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
@@ -445,7 +446,7 @@ int gsr_forward(gsr_forward_args* a) {
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
     // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
     // R-sized is touched (launch_sort_pairs draws the same line at n >= 0xFFFFFFFF).
-    const unsigned long long true_total = (unsigned long long)g_rb.host[5] | ((unsigned long long)g_rb.host[6] << 32);
+    const unsigned long long true_total = (unsigned long long)g_rb.host[6] | ((unsigned long long)g_rb.host[7] << 32);
     if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
     const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below

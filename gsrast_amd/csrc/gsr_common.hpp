@@ -51,8 +51,11 @@ int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state&
 
 // nonzero (u32 per 4096 elements) / nonzero_total: optional — exclusive prefix of the per-tile counts of non-zero
 // elements and their total (the depth order's compaction offsets, radix_sort.hip)
+// host_words (mapped host memory, optional; needs total64): [0] = the non-zero total, [2..3] = the 64-bit total, written by the
+// scan itself. clear / clear_bytes (optional, 16-byte granules): device memory the first launch also zeroes.
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
-                          unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr);
+                          unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr,
+                          uint32_t* host_words = nullptr, void* clear = nullptr, size_t clear_bytes = 0);
 size_t scan_temp_bytes(size_t n);
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,
@@ -70,12 +73,13 @@ struct SweepScratch;
 size_t depth_compact_scratch_bytes(size_t n);
 // offsets_ready: `partial` / info[1] already hold the compaction offsets per 4096 keys and the visible count (the scan of
 // tilesTouched produced them on the way: a key is the sentinel exactly where tilesTouched is 0)
+// host_top (optional, mapped host memory): gets info[0] too, for a host that reads it after an event.
 // rect_by_index / out_r (both or neither): the visible Gaussians' packed rectangles, compacted with the pairs; passed on as
 // second_in / a_s / b_s they travel through the passes with the indices and arrive in depth order (gathering them by
 // index afterwards is a random 4-byte read per Gaussian).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready = false,
-                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr);
+                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr, uint32_t* host_top = nullptr);
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
                     const uint32_t* n_dev = nullptr, const uint32_t* second_in = nullptr, uint32_t* a_s = nullptr,

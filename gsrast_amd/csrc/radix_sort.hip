@@ -486,11 +486,14 @@ namespace {
 // 0xFFFFFFFF sentinels are compacted away before the histogram, so digit 255 is a real depth — the top byte
 // of a negative NaN, which passes the reference's frustum test — and counts like any other).
 // (out[4]: the frame's count of tiles with a list, accumulated later by the tile-range kernel, starts at zero here)
-__global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __restrict__ hist_top, uint32_t* __restrict__ out) {
+// (host_top, may be null: mapped host memory that gets the count too — read by the host after an event, no copy command)
+__global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __restrict__ hist_top, uint32_t* __restrict__ out,
+                                                              uint32_t* __restrict__ host_top) {
     const int c = __syncthreads_count(hist_top[threadIdx.x] != 0u);
     if (threadIdx.x == 0) {
         out[0] = (uint32_t)c;
         out[4] = 0u;
+        if (host_top) *host_top = (uint32_t)c;
     }
 }
 
@@ -635,7 +638,7 @@ size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChu
 // (the frame's non-empty-tile counter; info must hold at least five words).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready,
-                     const uint32_t* rect_by_index, uint32_t* out_r) {
+                     const uint32_t* rect_by_index, uint32_t* out_r, uint32_t* host_top) {
     if (n == 0) return GSR_OK;
     const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
     if (!offsets_ready) {
@@ -648,7 +651,7 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
     hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
                        out_k, out_v, out_r, sc4[0].hist);
     GSR_LAUNCH_CHECK("visible_compact_kernel");
-    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info);
+    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info, host_top);
     GSR_LAUNCH_CHECK("top_digit_count_kernel");
     return GSR_OK;
 }

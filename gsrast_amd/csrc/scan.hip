@@ -67,9 +67,15 @@ __device__ __forceinline__ void load_items(const uint32_t* in, size_t n, size_t 
 
 // nonzero (may be null): also the number of non-zero elements of the tile — gsr_forward's depth order compacts the
 // Gaussians with tilesTouched != 0 in chunks of the same 4096 elements, and this kernel has them in registers anyway.
+// clear / clear_vecs (may be null / 0): 16-byte words this launch also zeroes, a slice per thread — gsr_forward's depth
+// order wants its look-back words cleared before its first pass, and a memset of its own is one more 5 us stop on a chain
+// of small launches.
 __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
-                                                                    uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero) {
+                                                                    uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero,
+                                                                    uint4* __restrict__ clear, size_t clear_vecs) {
     __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave];
+    for (size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x; i < clear_vecs; i += (size_t)gridDim.x * kScanThreads)
+        clear[i] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t v[kScanItems];
     load_items(in, n, blockIdx.x, v);
     uint32_t s = 0, z = 0;
@@ -92,9 +98,12 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
 // whether the scan's last element is the true total (a tile's own sum cannot wrap: 4096 elements of at most
 // 2^20 tiles each).
 // nonzero / nonzero_total (may be null): the per-tile non-zero counts become their exclusive prefix, the total goes out.
+// host_words (may be null): mapped host memory; [0] also gets the non-zero total, [2..3] (8-byte aligned) the 64-bit total —
+// the caller's host thread reads them after an event, without a copy command in between.
 __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict__ partial, size_t tiles,
                                                             unsigned long long* __restrict__ total64,
-                                                            uint32_t* __restrict__ nonzero, uint32_t* __restrict__ nonzero_total) {
+                                                            uint32_t* __restrict__ nonzero, uint32_t* __restrict__ nonzero_total,
+                                                            uint32_t* __restrict__ host_words) {
     __shared__ uint32_t wave_sums[1024 / kWave];
     __shared__ unsigned long long wide_sums[1024 / kWave];
     uint32_t carry = 0, carry_nz = 0;
@@ -115,7 +124,10 @@ __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict
             carry_nz += total_nz;
         }
     }
-    if (nonzero && threadIdx.x == 0) *nonzero_total = carry_nz;
+    if (nonzero && threadIdx.x == 0) {
+        *nonzero_total = carry_nz;
+        if (host_words) host_words[0] = carry_nz;
+    }
     if (total64) {
 #pragma unroll
         for (int off = kWave / 2; off > 0; off >>= 1) wide += __shfl_down(wide, off, kWave);
@@ -126,6 +138,7 @@ __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict
 #pragma unroll
             for (int w = 0; w < 1024 / kWave; ++w) t += wide_sums[w];
             *total64 = t;
+            if (host_words) *reinterpret_cast<unsigned long long*>(host_words + 2) = t;
         }
     }
 }
@@ -171,13 +184,16 @@ size_t scan_temp_bytes(size_t n) {
 }
 
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
-                          unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total) {
+                          unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total, uint32_t* host_words,
+                          void* clear, size_t clear_bytes) {
     if (n == 0) return GSR_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
-    hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero);
+    if (clear_bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(clear) & 15) != 0 || (host_words && !total64)) return GSR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero,
+                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0);
     GSR_LAUNCH_CHECK("tile_reduce_kernel");
-    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total);
+    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total, host_words);
     GSR_LAUNCH_CHECK("partial_scan_kernel");
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, partial);
     GSR_LAUNCH_CHECK("tile_scan_kernel");
