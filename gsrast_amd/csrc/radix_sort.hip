@@ -561,8 +561,14 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
     __shared__ uint32_t lds[4 * 256];
     __shared__ uint32_t s_off[kCompactRows * kCompactWaves];       // (row, wave): keys of that row in that wave, then where they go
     for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads) lds[i] = 0;
-    const uint32_t base = blockIdx.x * kCompactChunk;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    // A workgroup takes several chunks (chunk = blockIdx.x, += gridDim.x) and adds its digit counts to the global
+    // histograms ONCE: with a workgroup per chunk the 1 425 workgroups of the bench frame each sent 1 024 atomics to the same
+    // 1 024 words, and same-address atomics are served one at a time (about 17 ns each on this part).
+    const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const uint32_t base = chunk * kCompactChunk;
+    __syncthreads();                                     // (s_off of the previous chunk has been read by everybody)
     // All rows are loaded before anything is counted (one round trip), and the output offsets of all (row, wave)
     // pieces come from ONE 64-lane scan: two barriers per workgroup (a barrier pair per row before: 32).
     uint32_t k[kCompactRows], rect[kCompactRows];
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
             const uint32_t o = __shfl_up(incl, off, kWave);
             if (lane >= off) incl += o;
         }
-        s_off[lane] = partial[blockIdx.x] + incl - c;
+        s_off[lane] = partial[chunk] + incl - c;
     }
     __syncthreads();
 #pragma unroll
@@ -624,6 +630,7 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
             todo &= ~same;
         }
     }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads)
         if (lds[i]) atomicAdd(&hist[i], lds[i]);
@@ -648,7 +655,10 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
         GSR_LAUNCH_CHECK("visible_scan_kernel");
     }
     if ((rect_by_index == nullptr) != (out_r == nullptr)) return GSR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(visible_compact_kernel, dim3(chunks), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
+    // (chunks per workgroup: bench frame, 1 425 chunks: 41 -> 32 us with two, no better with three to six; 50 M Gaussians,
+    // 12 208 chunks: 288 -> 205 us with two to six)
+    const uint32_t per_wg = chunks >= 4096u ? 4u : 2u;
+    hipLaunchKernelGGL(visible_compact_kernel, dim3((chunks + per_wg - 1) / per_wg), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
                        out_k, out_v, out_r, sc4[0].hist);
     GSR_LAUNCH_CHECK("visible_compact_kernel");
     hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info, host_top);
