@@ -72,7 +72,7 @@ def parse_args():
     p.add_argument("--backward", action="store_true",
                    help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
     p.add_argument("--overlap", action="store_true",
-                   help="GSR_FLAG_OVERLAP_EMIT: block plan's emission on a second stream beside the blend (shorter frames, "
+                   help="GSR_FLAG_OVERLAP_EMIT: block plan's blend on a second stream beside the emission (shorter frames, "
                         "but per-kernel times are then those of kernels sharing the chip)")
     p.add_argument("--no-sorted-lists", action="store_true", help="GSR_FLAG_NO_SORTED_LISTS for the headline frame (forward-only callers)")
     p.add_argument("--colors-precomp", action="store_true",

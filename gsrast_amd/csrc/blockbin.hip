@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
 // ---- blend straight from the block lists -------------------------------------------------------------
 // The tile's records, in list order, are the entries of its block whose (column mask & row mask) bit is
 // set — the same filter the emission applies. Reading them from the block lists makes the blend
-// independent of the emission (which may run beside it on a second stream, or not at all:
+// independent of the emission (beside which it may run, on a second stream — or which may not run at all:
 // GSR_FLAG_NO_SORTED_LISTS). Per batch of 64 entries the covered ones fetch their record, the ones whose
 // footprint can reach the tile are staged compacted (v_mbcnt rank) in wave-private LDS and composited by the
 // shared core (blend_core.hpp); the 256-record batches of the reference survive as the granularity of the

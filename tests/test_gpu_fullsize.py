@@ -207,7 +207,7 @@ def test_cpp_harness_through_the_reference_signature(tmp_path):
 
 
 def test_overlapped_emission_gives_the_same_frame():
-    """GSR_FLAG_OVERLAP_EMIT: the emission runs on a second stream beside the blend (which reads the block lists).
+    """GSR_FLAG_OVERLAP_EMIT: the blend (which reads the block lists) runs on a second stream beside the emission.
     Keys, values, ranges, pixels, nContrib and the staged-record count must not change."""
     import torch
     from gsrast_amd import camera, scenes
