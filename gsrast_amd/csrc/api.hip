@@ -48,8 +48,11 @@ struct GeoScratch {
     uint32_t* sort_info;      // [0] distinct top-byte digits of the visible depth keys, [1] visible Gaussians V,
                               // [2..3] u64: sum of tilesTouched without the u32 wrap-around, [4] tiles with a list
     uint32_t* vis_partial;    // per 4096-key chunk: visible keys before it (compaction)
+    uint32_t* main_partial;   // the same for the keys with the main top byte only (the depth order's side way, radix_sort.hip)
+    uint32_t* others_per_wave;  // per 64 Gaussians: visible ones with another top byte (written by the preprocess, summed by the scan)
+    uint32_t *side_k, *side_v, *side_r;   // the side list (kDepthSideMax entries); its words: sort_info[8..10]
     uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
-    uint32_t *a_k, *a_v;      // depth-sort ping
+    uint32_t *a_k, *a_v;      // depth-sort ping (three passes end here; kDepthSideMax elements of room in front of each a_*)
     uint32_t *b_k, *b_v;      // depth-sort pong = result (sorted depth bits, sorted index)
     uint32_t *c_r, *a_r, *b_r;  // the packed rectangles of the same Gaussians, moved with the pairs (tile grids up to 255 x 255)
     SweepScratch sweep;       // onesweep status words for the N-sized sort: pass 0 (+ error word, digit histograms)
@@ -66,14 +69,19 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.rect_idx = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sort_info = reinterpret_cast<uint32_t*>(base + off); off += 128;
     g.vis_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
+    g.main_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
+    g.others_per_wave = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * ((n + 63) / 64));
+    g.side_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
+    g.side_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
+    g.side_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
     g.c_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.c_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
-    g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
-    g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    off += 4 * kDepthSideMax; g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    off += 4 * kDepthSideMax; g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.c_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
-    g.a_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    off += 4 * kDepthSideMax; g.a_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
     for (auto& sw : g.sweep_more) { sw = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n); }
@@ -110,7 +118,8 @@ constexpr uint32_t kAsyncSlots = 64;       // error-word slots handed out in tur
 constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned block
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
-    uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count (all three written by the kernels that compute them), [8..9] staged count;
+    uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
+                                       // byte, [12] side keys (all written by the kernels that compute them), [8..9] staged count;
                                        // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
                                        // written by the kernels themselves), serial of the owning call, 0}
     uint32_t serial = 0;               // calls made so far by this thread on this device
@@ -401,9 +410,9 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (inria)
-        GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));
+        GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));
     else
-        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream));                 // :744-768
+        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
@@ -413,7 +422,8 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
                                    gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2),
                                    gs.vis_partial, gs.sort_info + 1, g_rb.host_dev + 4,
-                                   gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n)));
+                                   gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n),
+                                   gs.others_per_wave, gs.main_partial, kDepthSideMax, gs.sort_info + 8));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
@@ -429,8 +439,15 @@ int gsr_forward(gsr_forward_args* a) {
     // With a packed rectangle per Gaussian (grids up to 255 x 255) the rectangle travels with the index through the depth
     // passes: both binning plans want it in depth order, and gathering it by index afterwards is a random 4-byte read per
     // Gaussian (0.93 ms of the 50 M frame).
+    // (the depth keys are float bits of NDC z: nearly every visible Gaussian has z in [0.5, 1) and the top byte 0x3F; the
+    // handful that does not — 23 of 3 M on the bench frame — goes a side way instead of costing everybody a fourth pass)
+    DepthSide side;
+    side.words = gs.sort_info + 8;
+    side.main_partial = gs.main_partial;
+    side.keys = gs.side_k; side.vals = gs.side_v; side.rects = xy_plan ? gs.side_r : nullptr;
+    side.capacity = kDepthSideMax;
     GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
-                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3));
+                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3, &side));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
@@ -448,15 +465,20 @@ int gsr_forward(gsr_forward_args* a) {
     // R-sized is touched (launch_sort_pairs draws the same line at n >= 0xFFFFFFFF).
     const unsigned long long true_total = (unsigned long long)g_rb.host[6] | ((unsigned long long)g_rb.host[7] << 32);
     if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
+    const bool side_way = g_rb.host[10] != 0u;             // (then the stream's keys share their top byte: three passes)
     const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
+    const uint32_t side_m = side_way ? g_rb.host[12] : 0u, side_lo = side_way ? g_rb.host[11] : 0u;
+    if (side_way && (four_passes || side_m > kDepthSideMax || side_lo > side_m || side_m > (uint32_t)nv)) return fail(GSR_ERR_INTERNAL);
     if (four_passes)
         GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream, nullptr,
                                  xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
+    if (side_way)
+        GSR_STEP(launch_depth_side(side, side_m, side_lo, (uint32_t)nv - side_m, gs.a_k, gs.a_v, xy_plan ? gs.a_r : nullptr, stream));
     // depth-sorted keys / indices, and the other pair of buffers (free from here on)
-    uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k;
-    uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v;
-    const uint32_t* const sorted_r = four_passes ? gs.b_r : gs.a_r;      // (xy_plan only)
+    uint32_t* const sorted_k = four_passes ? gs.b_k : gs.a_k - side_lo;
+    uint32_t* const sorted_v = four_passes ? gs.b_v : gs.a_v - side_lo;
+    const uint32_t* const sorted_r = four_passes ? gs.b_r : gs.a_r - side_lo;      // (xy_plan only)
     uint32_t* const spare_k = four_passes ? gs.a_k : gs.b_k;
     const uint32_t R = (uint32_t)true_total;               // (= pointOffsets[N - 1], GSCuda.cu:772)
     a->num_rendered = R;

@@ -42,20 +42,24 @@ struct FrameDims {
 
 // ---- stage launchers (each asynchronous on `stream`) ----
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
+                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream,
+                      uint32_t* others_per_wave = nullptr);
 
 int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t stream);
 
 int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
-                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream);
+                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint32_t* others_per_wave = nullptr);
 
 // nonzero (u32 per 4096 elements) / nonzero_total: optional — exclusive prefix of the per-tile counts of non-zero
 // elements and their total (the depth order's compaction offsets, radix_sort.hip)
 // host_words (mapped host memory, optional; needs total64): [0] = the non-zero total, [2..3] = the 64-bit total, written by the
 // scan itself. clear / clear_bytes (optional, 16-byte granules): device memory the first launch also zeroes.
+// others_per_wave / main_count / side_max / side_words (all or none; need nonzero): the depth order's side list, see scan.hip.
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
                           unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr,
-                          uint32_t* host_words = nullptr, void* clear = nullptr, size_t clear_bytes = 0);
+                          uint32_t* host_words = nullptr, void* clear = nullptr, size_t clear_bytes = 0,
+                          const uint32_t* others_per_wave = nullptr, uint32_t* main_count = nullptr,
+                          uint32_t side_max = 0, uint32_t* side_words = nullptr);
 size_t scan_temp_bytes(size_t n);
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,
@@ -68,6 +72,19 @@ int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_
                       uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word = nullptr);
 size_t sort_temp_bytes(size_t n);
 struct SweepScratch;
+// The depth order's side list (radix_sort.hip, depth_side_kernel): the visible keys whose top byte is not main_top, when
+// the scan found few of them. words: [0] the side way is taken (decided by the scan), [1] keys on the list, [2] those of
+// them below main_top. main_partial: the compaction's offsets counted for the main keys only.
+constexpr uint32_t kDepthSideMax = 1024;
+constexpr uint32_t kDepthMainTop = 0x3Fu;            // float bits of [0.5, 1)
+struct DepthSide {
+    uint32_t* words = nullptr;
+    const uint32_t* main_partial = nullptr;
+    uint32_t *keys = nullptr, *vals = nullptr, *rects = nullptr;
+    uint32_t capacity = 0, main_top = kDepthMainTop;
+};
+int launch_depth_side(const DepthSide& side, uint32_t m, uint32_t m_lo, uint32_t main_count, uint32_t* out_k, uint32_t* out_v,
+                      uint32_t* out_r, hipStream_t stream);
 // Depth order (radix_sort.hip). sc4: one scratch area per pass, already zeroed by the caller (look-back words,
 // tickets, error word, histograms); the error word and the digit histograms live in sc4[0].
 size_t depth_compact_scratch_bytes(size_t n);
@@ -79,7 +96,8 @@ size_t depth_compact_scratch_bytes(size_t n);
 // index afterwards is a random 4-byte read per Gaussian).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready = false,
-                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr, uint32_t* host_top = nullptr);
+                     const uint32_t* rect_by_index = nullptr, uint32_t* out_r = nullptr, uint32_t* host_top = nullptr,
+                     const DepthSide* side = nullptr);
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
                     const uint32_t* n_dev = nullptr, const uint32_t* second_in = nullptr, uint32_t* a_s = nullptr,

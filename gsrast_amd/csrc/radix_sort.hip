@@ -487,13 +487,17 @@ namespace {
 // of a negative NaN, which passes the reference's frustum test — and counts like any other).
 // (out[4]: the frame's count of tiles with a list, accumulated later by the tile-range kernel, starts at zero here)
 // (host_top, may be null: mapped host memory that gets the count too — read by the host after an event, no copy command)
+// (side, may be null: the side list's words — [1] keys on it, [2] those of them below the main top byte; host_top[8] gets [2])
 __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __restrict__ hist_top, uint32_t* __restrict__ out,
-                                                              uint32_t* __restrict__ host_top) {
+                                                              uint32_t* __restrict__ host_top, const uint32_t* __restrict__ side) {
     const int c = __syncthreads_count(hist_top[threadIdx.x] != 0u);
     if (threadIdx.x == 0) {
         out[0] = (uint32_t)c;
         out[4] = 0u;
-        if (host_top) *host_top = (uint32_t)c;
+        if (host_top) {
+            host_top[0] = (uint32_t)c;
+            if (side) host_top[8] = side[2];
+        }
     }
 }
 
@@ -551,11 +555,11 @@ __global__ __launch_bounds__(1024) void visible_scan_kernel(uint32_t* __restrict
 // rect_by_index / out_r (may be null): the visible Gaussians' packed rectangles are compacted with the pairs — here, in
 // index order, that read is coalesced; they then travel through the depth passes as the keys' second value.
 __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const uint32_t* __restrict__ keys, uint32_t n,
-                                                                          const uint32_t* __restrict__ partial,
+                                                                          const uint32_t* partial,
                                                                           const uint32_t* __restrict__ rect_by_index,
                                                                           uint32_t* __restrict__ out_k, uint32_t* __restrict__ out_v,
                                                                           uint32_t* __restrict__ out_r,
-                                                                          uint32_t* __restrict__ hist) {
+                                                                          uint32_t* __restrict__ hist, const DepthSide side) {
     constexpr int kCompactWaves = kCompactThreads / kWave;
     static_assert(kCompactRows * kCompactWaves == kWave, "one wave scans the (row, wave) counts");
     __shared__ uint32_t lds[4 * 256];
@@ -566,6 +570,9 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
     // histograms ONCE: with a workgroup per chunk the 1 425 workgroups of the bench frame each sent 1 024 atomics to the same
     // 1 024 words, and same-address atomics are served one at a time (about 17 ns each on this part).
     const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
+    // The side way (DepthSide): only the keys with the main top byte are compacted, with the offsets counted for them
+    const bool side_on = side.words != nullptr && side.words[0] != 0u;
+    if (side_on) partial = side.main_partial;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
     const uint32_t base = chunk * kCompactChunk;
     __syncthreads();                                     // (s_off of the previous chunk has been read by everybody)
@@ -576,6 +583,23 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
     for (int r = 0; r < kCompactRows; ++r) {
         const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
         k[r] = (e < n) ? keys[e] : 0xFFFFFFFFu;
+    }
+    if (side_on) {
+        // the few other visible keys go to the side list (any order: depth_side_kernel ranks them) and leave this stream
+#pragma unroll
+        for (int r = 0; r < kCompactRows; ++r) {
+            if (k[r] != 0xFFFFFFFFu && (k[r] >> 24) != side.main_top) {
+                const uint32_t e = base + (uint32_t)r * kCompactThreads + threadIdx.x;
+                const uint32_t slot = atomicAdd(&side.words[1], 1u);
+                if (slot < side.capacity) {              // (always: the scan counted them before it chose this way)
+                    side.keys[slot] = k[r];
+                    side.vals[slot] = e;
+                    if (side.rects) side.rects[slot] = rect_by_index ? rect_by_index[e] : 0u;
+                }
+                if ((k[r] >> 24) < side.main_top) atomicAdd(&side.words[2], 1u);
+                k[r] = 0xFFFFFFFFu;
+            }
+        }
     }
     if (rect_by_index) {
         // (unconditional: the preprocess writes a rectangle word for every Gaussian, 0 for the culled ones)
@@ -635,7 +659,44 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
     for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads)
         if (lds[i]) atomicAdd(&hist[i], lds[i]);
 }
+// ---- the side way: the few visible keys whose top byte is not the main one -----------------------------------------
+// Depth keys are float bits of NDC z. Nearly every visible Gaussian has z in [0.5, 1): top byte 0x3F; the fourth sort
+// pass exists for the others — 23 of 3 043 608 on the bench frame, one of 5.6 M from outside the cloud — and moved every key
+// for them (35 - 52 us). When they are few (the scan counts them: scan.hip) the compaction leaves them out of the stream,
+// three passes sort the rest, and this kernel ranks the side list by (key, index) — the order a stable sort gives — and
+// puts the keys below the main top byte in front of the sorted stream (the arrays have room there) and those above behind.
+__global__ __launch_bounds__(1024) void depth_side_kernel(const DepthSide side, uint32_t m, uint32_t m_lo, uint32_t main_count,
+                                                          uint32_t* __restrict__ out_k, uint32_t* __restrict__ out_v,
+                                                          uint32_t* __restrict__ out_r) {
+    __shared__ uint32_t s_k[kDepthSideMax], s_v[kDepthSideMax];
+    const uint32_t t = threadIdx.x;
+    uint32_t key = 0, val = 0, rect = 0;
+    if (t < m) { key = side.keys[t]; val = side.vals[t]; rect = side.rects ? side.rects[t] : 0u; s_k[t] = key; s_v[t] = val; }
+    __syncthreads();
+    if (t >= m) return;
+    const bool low = (key >> 24) < side.main_top;
+    uint32_t rank = 0;                           // keys of the same side in front of this one
+    for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t kj = s_k[j], vj = s_v[j];
+        const bool same = ((kj >> 24) < side.main_top) == low;
+        rank += (same && (kj < key || (kj == key && vj < val))) ? 1u : 0u;
+    }
+    // out_*: the sorted stream's first element; low keys at [-m_lo, 0), high keys at [main_count, main_count + m - m_lo)
+    const long long at = low ? (long long)rank - (long long)m_lo : (long long)main_count + (long long)rank;
+    out_k[at] = key;
+    out_v[at] = val;
+    if (out_r) out_r[at] = rect;
+}
 }  // namespace
+
+int launch_depth_side(const DepthSide& side, uint32_t m, uint32_t m_lo, uint32_t main_count, uint32_t* out_k, uint32_t* out_v,
+                      uint32_t* out_r, hipStream_t stream) {
+    if (m == 0) return GSR_OK;
+    if (m > kDepthSideMax || m_lo > m) return GSR_ERR_INTERNAL;
+    hipLaunchKernelGGL(depth_side_kernel, dim3(1), dim3(1024), 0, stream, side, m, m_lo, main_count, out_k, out_v, out_r);
+    GSR_LAUNCH_CHECK("depth_side_kernel");
+    return GSR_OK;
+}
 
 size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChunk - 1) / kCompactChunk) * sizeof(uint32_t), 128); }
 
@@ -645,7 +706,7 @@ size_t depth_compact_scratch_bytes(size_t n) { return align_up(((n + kCompactChu
 // (the frame's non-empty-tile counter; info must hold at least five words).
 int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint32_t* out_v, uint32_t* partial,
                      const SweepScratch* sc4, uint32_t* info, hipStream_t stream, bool offsets_ready,
-                     const uint32_t* rect_by_index, uint32_t* out_r, uint32_t* host_top) {
+                     const uint32_t* rect_by_index, uint32_t* out_r, uint32_t* host_top, const DepthSide* side) {
     if (n == 0) return GSR_OK;
     const uint32_t chunks = (n + kCompactChunk - 1) / kCompactChunk;
     if (!offsets_ready) {
@@ -658,10 +719,12 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
     // (chunks per workgroup: bench frame, 1 425 chunks: 41 -> 32 us with two, no better with three to six; 50 M Gaussians,
     // 12 208 chunks: 288 -> 205 us with two to six)
     const uint32_t per_wg = chunks >= 4096u ? 4u : 2u;
+    DepthSide no_side;
     hipLaunchKernelGGL(visible_compact_kernel, dim3((chunks + per_wg - 1) / per_wg), dim3(kCompactThreads), 0, stream, keys_in, n, partial, rect_by_index,
-                       out_k, out_v, out_r, sc4[0].hist);
+                       out_k, out_v, out_r, sc4[0].hist, side ? *side : no_side);
     GSR_LAUNCH_CHECK("visible_compact_kernel");
-    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info, host_top);
+    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info, host_top,
+                       side ? side->words : nullptr);
     GSR_LAUNCH_CHECK("top_digit_count_kernel");
     return GSR_OK;
 }

@@ -70,19 +70,31 @@ __device__ __forceinline__ void load_items(const uint32_t* in, size_t n, size_t 
 // clear / clear_vecs (may be null / 0): 16-byte words this launch also zeroes, a slice per thread — gsr_forward's depth
 // order wants its look-back words cleared before its first pass, and a memset of its own is one more 5 us stop on a chain
 // of small launches.
+// others_per_wave / main_count (both or none): others_per_wave[i] = how many of elements [64 i, 64 i + 64) are non-zero but
+// NOT "main" (the depth order's keys with another top byte than the main one: the preprocess kernels count them, a word per
+// wave of theirs); main_count[tile] = the tile's non-zero elements minus those.
 __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                     uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero,
-                                                                    uint4* __restrict__ clear, size_t clear_vecs) {
+                                                                    uint4* __restrict__ clear, size_t clear_vecs,
+                                                                    const uint32_t* __restrict__ others_per_wave,
+                                                                    uint32_t* __restrict__ main_count) {
     __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave];
     for (size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x; i < clear_vecs; i += (size_t)gridDim.x * kScanThreads)
         clear[i] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t v[kScanItems];
     load_items(in, n, blockIdx.x, v);
+    uint32_t others = 0;
+    if (others_per_wave && threadIdx.x < kScanTile / kWave) {          // (the first wave: kScanTile / 64 = 64 words per tile)
+        const size_t w = (size_t)blockIdx.x * (kScanTile / kWave) + threadIdx.x;
+        others = (w * kWave < n) ? others_per_wave[w] : 0u;
+    }
     uint32_t s = 0, z = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) { s += v[k]; z += v[k] != 0u ? 1u : 0u; }
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) { s += __shfl_down(s, off, kWave); z += __shfl_down(z, off, kWave); }
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, kWave); z += __shfl_down(z, off, kWave); others += __shfl_down(others, off, kWave);
+    }
     if ((threadIdx.x & (kWave - 1)) == 0) { wave_sums[threadIdx.x / kWave] = s; wave_nz[threadIdx.x / kWave] = z; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -91,6 +103,7 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
         for (int w = 0; w < kScanThreads / kWave; ++w) { t += wave_sums[w]; tz += wave_nz[w]; }
         partial[blockIdx.x] = t;
         if (nonzero) nonzero[blockIdx.x] = tz;
+        if (main_count) main_count[blockIdx.x] = tz - others;             // (thread 0 holds the first wave's sum)
     }
 }
 
@@ -103,10 +116,11 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
 __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict__ partial, size_t tiles,
                                                             unsigned long long* __restrict__ total64,
                                                             uint32_t* __restrict__ nonzero, uint32_t* __restrict__ nonzero_total,
-                                                            uint32_t* __restrict__ host_words) {
+                                                            uint32_t* __restrict__ host_words, uint32_t* __restrict__ main_count,
+                                                            uint32_t side_max, uint32_t* __restrict__ side_words) {
     __shared__ uint32_t wave_sums[1024 / kWave];
     __shared__ unsigned long long wide_sums[1024 / kWave];
-    uint32_t carry = 0, carry_nz = 0;
+    uint32_t carry = 0, carry_nz = 0, carry_main = 0;
     unsigned long long wide = 0;
     for (size_t base = 0; base < tiles; base += 1024) {
         const size_t i = base + threadIdx.x;
@@ -123,9 +137,28 @@ __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict
             if (i < tiles) nonzero[i] = carry_nz + excl_nz;
             carry_nz += total_nz;
         }
+        if (main_count) {
+            const uint32_t m = (i < tiles) ? main_count[i] : 0u;
+            uint32_t total_m;
+            const uint32_t excl_m = block_exclusive_scan<1024>(m, wave_sums, total_m);
+            if (i < tiles) main_count[i] = carry_main + excl_m;
+            carry_main += total_m;
+        }
     }
+    // main_count / side_words (depth order, radix_sort.hip): the keys whose top byte is not the main one go a side way when
+    // there are few of them. side_words[0] = 1 if so, [1] and [2] = 0 (the side list's counters), and the count the sort
+    // passes read (*nonzero_total) is then that of the main keys; host_words[0] keeps the count of ALL non-zero elements,
+    // host_words[6] = the side flag, host_words[8] = how many keys go the side way.
     if (nonzero && threadIdx.x == 0) {
-        *nonzero_total = carry_nz;
+        uint32_t stream = carry_nz, side = 0u;
+        if (main_count) {
+            const uint32_t others = carry_nz - carry_main;
+            side = (carry_main != 0u && others != 0u && others <= side_max) ? 1u : 0u;
+            if (side) stream = carry_main;
+            side_words[0] = side; side_words[1] = 0u; side_words[2] = 0u;
+            if (host_words) { host_words[6] = side; host_words[8] = side ? others : 0u; }
+        }
+        *nonzero_total = stream;
         if (host_words) host_words[0] = carry_nz;
     }
     if (total64) {
@@ -185,15 +218,18 @@ size_t scan_temp_bytes(size_t n) {
 
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
                           unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total, uint32_t* host_words,
-                          void* clear, size_t clear_bytes) {
+                          void* clear, size_t clear_bytes, const uint32_t* others_per_wave, uint32_t* main_count,
+                          uint32_t side_max, uint32_t* side_words) {
     if (n == 0) return GSR_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
     if (clear_bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(clear) & 15) != 0 || (host_words && !total64)) return GSR_ERR_INVALID_ARG;
+    if ((others_per_wave != nullptr) != (main_count != nullptr) || (main_count && (!nonzero || !side_words))) return GSR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero,
-                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0);
+                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, others_per_wave, main_count);
     GSR_LAUNCH_CHECK("tile_reduce_kernel");
-    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total, host_words);
+    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total, host_words,
+                       main_count, side_max, side_words);
     GSR_LAUNCH_CHECK("partial_scan_kernel");
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, partial);
     GSR_LAUNCH_CHECK("tile_scan_kernel");

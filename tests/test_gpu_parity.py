@@ -390,6 +390,38 @@ def test_extreme_but_finite_inputs_against_oracle(seed):
     _compare_all(r, img, exp, n, max_bad_pixels=3)
 
 
+@pytest.mark.parametrize("near,extra", [(0.5, 12), (0.5, 1), (1.3, 0), (3.0, 0), (0.01, 0)])
+def test_depth_keys_outside_the_main_top_byte(near, extra):
+    """The depth order sorts the keys whose top byte is 0x3F (NDC z in [0.5, 1): nearly all of them) in three passes and
+    ranks the few others on a side list (radix_sort.hip, depth_side_kernel); with more than 1 024 others it falls back to
+    the fourth pass. near 0.5 + a dozen (or one) splats between two and four times the near distance (z < 0.5): the side way, low keys in front;
+    near 1.3: half of the scene below z = 0.5, the fallback; near 3.0: nothing BUT others (no side way either); near 0.01: no others at all. Lists, ranges, pixels as the oracle's."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    n, w, h = 3000, 320, 200
+    scene = scenes.garden_like_scene(n, seed=8100)
+    scene["means3D"][:, :3] *= 0.25
+    scene["scales"][:, :3] *= 2.0
+    if extra:
+        rng = np.random.default_rng(8101)
+        sel = rng.choice(n, extra, replace=False)
+        d = rng.uniform(near * 2.2, near * 3.6, extra)                   # NDC z (glm: [-1, 1]) is 0 at ~2 near and 0.5 at ~4 near
+        scene["means3D"][sel, 0] = rng.uniform(-0.05, 0.05, extra) * d
+        scene["means3D"][sel, 1] = rng.uniform(-0.05, 0.05, extra) * d
+        scene["means3D"][sel, 2] = -5.0 + d
+        scene["scales"][sel, :3] = 0.01
+    cam = camera.default_camera(w, h, near=near, far=100.0)
+    exp = cpu_oracle.forward(scene, cam, (0.0, 0.0, 0.0))
+    vis = exp["tilesTouched"] != 0
+    top = exp["depths"].view(np.uint32)[vis] >> 24
+    others = int((top != 0x3F).sum())
+    nvis = int(vis.sum())
+    assert {(0.5, 12): 2 <= others <= 16, (0.5, 1): 1 <= others <= 3, (1.3, 0): 1024 < others < nvis, (3.0, 0): others == nvis,
+            (0.01, 0): others == 0}[(near, extra)], (others, nvis)
+    r, img = _run(scene, cam)
+    _compare_all(r, img, exp, n)
+
+
 def test_four_waves_per_tile_blend_matches_one_wave_per_tile():
     """Calls with few tiles blend with four waves per tile (one 16 x 4 strip each) unless the staged records are
     counted; both forms must give the same pixels, nContrib and finalT bit for bit."""
