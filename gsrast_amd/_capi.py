@@ -28,10 +28,8 @@ GSR_FLAG_PLAN_SORT = 0x8
 GSR_FLAG_PLAN_BLOCKS = 0x10
 GSR_FLAG_OVERLAP_EMIT = 0x20
 GSR_FLAG_NO_SORTED_LISTS = 0x40
-GSR_FLAG_DEPTH_LSD = 0x80
 GSR_PLAN_LISTS_SKIPPED = 0x100
 GSR_PLAN_BLEND_FROM_LISTS = 0x200
-GSR_PLAN_DEPTH_BUCKETS = 0x400
 GSR_SH_LAYOUT_FILE, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 0, 1
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8
@@ -157,7 +155,6 @@ SIGNATURES = {
     "gsr_ply_activate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "gsr_colors_from_dc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gsr_depth_bucket_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]),
     "gsr_footprint_misses_tile": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsr_ply_activate_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]),

@@ -12,7 +12,6 @@
 #include "gsr_common.hpp"
 #include "blockbin.hpp"
 #include "radix_sort.hpp"
-#include "depth_buckets.hpp"
 
 namespace gsr {
 
@@ -58,7 +57,6 @@ struct GeoScratch {
     uint32_t *c_r, *a_r, *b_r;  // the packed rectangles of the same Gaussians, moved with the pairs (tile grids up to 255 x 255)
     SweepScratch sweep;       // onesweep status words for the N-sized sort: pass 0 (+ error word, digit histograms)
     SweepScratch sweep_more[3];   // passes 1-3: their own look-back words, so one clear up front covers all four
-    DepthBuckets buckets;     // the two-pass depth order (depth_buckets.hip); its counters directly behind the sweep areas: the same clear
     char* emit_scratch;       // column-major emission: [chunk][column] table, block partials, column starts
     char* block_scratch;      // block binning: [chunk][block] table, partials, block meta, tile counts / starts
     size_t bytes;
@@ -87,7 +85,6 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.b_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
     for (auto& sw : g.sweep_more) { sw = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n); }
-    g.buckets = carve_depth_buckets(base + off, n); off += align128(depth_buckets_scratch_bytes(n));
     g.emit_scratch = base + off; off += align128(emit_scratch_bytes(n));
     g.block_scratch = base + off; off += align128(blockbin_geo_bytes(n));
     g.bytes = off;
@@ -122,8 +119,7 @@ constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned 
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
     uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
-                                       // byte, [12] side keys (all written by the kernels that compute them), [8..9] staged count,
-                                       // [13] the two-pass depth order gave up (zeroed by the host before the call, set by its kernels);
+                                       // byte, [12] side keys (all written by the kernels that compute them), [8..9] staged count;
                                        // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
                                        // written by the kernels themselves), serial of the owning call, 0}
     uint32_t serial = 0;               // calls made so far by this thread on this device
@@ -315,19 +311,6 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
     return fail(launch_footprint_test(n, means2D, conic_opacity, tile_xy, width, height, misses, (hipStream_t)stream));
 }
 
-int gsr_depth_bucket_stats(char* geometry_chunk, int n, uint32_t info[4], uint32_t* counts, uint32_t max_counts) {
-    g_hip_error[0] = 0;
-    if (!geometry_chunk || n <= 0 || !info || !depth_buckets_supported((size_t)n)) return fail(GSR_ERR_INVALID_ARG);
-    gsr_geometry_state geom;
-    gsr_geometry_from_chunk(geometry_chunk, n, &geom);
-    const GeoScratch gs = carve_geo_scratch(geom.scanning_space, (size_t)n);
-    GSR_HIP_TRY(hipMemcpy(info, gs.buckets.words, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    info[3] = kDepthBucketCap;
-    if (counts && max_counts)
-        GSR_HIP_TRY(hipMemcpy(counts, gs.buckets.counts, sizeof(uint32_t) * std::min<uint32_t>(max_counts, kDepthMaxBuckets), hipMemcpyDeviceToHost));
-    return fail(GSR_OK);
-}
-
 int gsr_poll_async_error(const gsr_forward_receipt* r) {
     if (!r || r->magic != GSR_RECEIPT_MAGIC || !r->async_words) return fail(GSR_ERR_INVALID_ARG);
     const volatile uint32_t* w = r->async_words;
@@ -432,20 +415,15 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
-    // Depth order in two memory passes (depth_buckets.hip) where the packed rectangles exist and the sample fits the
-    // splitter kernel; the LSD passes otherwise, on request, and when a bucket outgrows its region (never seen: a 1e-7 event)
-    const bool try_buckets = xy_plan && depth_buckets_supported((size_t)n) && !(a->flags & GSR_FLAG_DEPTH_LSD);
-    g_rb.host[13] = 0u;
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
-    // Its first launch also clears the depth order's scratch areas (look-back words, tickets, the digit histograms, the bucket
-    // counters: adjacent in the chunk), and its one-workgroup launch leaves V and the un-wrapped instance count in the pinned host
+    // Its first launch also clears the depth order's four scratch areas (look-back words, tickets, the digit histograms:
+    // adjacent in the chunk), and its one-workgroup launch leaves V and the un-wrapped instance count in the pinned host
     // words themselves: a memset and a copy command of their own were two more 5 us stops on this chain of small launches.
     GSR_STEP(launch_inclusive_scan(geom.tiles_touched, geom.point_offsets, (size_t)n,      // :771
                                    gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2),
                                    gs.vis_partial, gs.sort_info + 1, g_rb.host_dev + 4,
-                                   gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n) + depth_buckets_cleared_bytes(),
-                                   gs.others_per_wave, gs.main_partial, kDepthSideMax, gs.sort_info + 8,
-                                   try_buckets ? gs.depth_key : nullptr, try_buckets ? gs.buckets.samples : nullptr));
+                                   gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n),
+                                   gs.others_per_wave, gs.main_partial, kDepthSideMax, gs.sort_info + 8));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
@@ -468,21 +446,8 @@ int gsr_forward(gsr_forward_args* a) {
     side.main_partial = gs.main_partial;
     side.keys = gs.side_k; side.vals = gs.side_v; side.rects = xy_plan ? gs.side_r : nullptr;
     side.capacity = kDepthSideMax;
-    auto lsd_prepare = [&]() -> int {
-        return sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
-                                xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3, &side);
-    };
-    // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
-    // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
-    auto lsd_first_passes = [&]() -> int {
-        return sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
-                               xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr);
-    };
-    if (try_buckets)
-        GSR_STEP(launch_depth_bucket_scatter(gs.buckets, gs.depth_key, gs.rect_idx, (uint32_t)n, gs.sort_info + 1,
-                                             g_rb.host_dev + 13, stream));
-    else
-        GSR_STEP(lsd_prepare());
+    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
+                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3, &side));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
@@ -490,30 +455,22 @@ int gsr_forward(gsr_forward_args* a) {
     // (no copy command: the kernels that computed the three figures wrote them into the pinned words as well; numRendered
     // is the low word of the un-wrapped instance count)
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
-    if (try_buckets)
-        GSR_STEP(launch_depth_bucket_sort(gs.buckets, (uint32_t)n, gs.b_k, gs.b_v, gs.b_r, stream));   // (its workgroups leave at once if the scatter gave up)
-    else
-        GSR_STEP(lsd_first_passes());
+    // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
+    // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
+    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
+                             xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
     // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
     // R-sized is touched (launch_sort_pairs draws the same line at n >= 0xFFFFFFFF).
     const unsigned long long true_total = (unsigned long long)g_rb.host[6] | ((unsigned long long)g_rb.host[7] << 32);
     if (true_total >= 0xFFFFFFFFull) return fail(GSR_ERR_TOO_LARGE);
-    const bool buckets_done = try_buckets && g_rb.host[13] == 0u;
-    if (try_buckets && !buckets_done) {
-        // the rare way back: the LSD passes after all (one more wait for the figures their preparation reports)
-        GSR_STEP(lsd_prepare());
-        GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
-        GSR_STEP(lsd_first_passes());
-        GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
-    }
-    const bool side_way = !buckets_done && g_rb.host[10] != 0u;   // (then the stream's keys share their top byte: three passes)
-    const bool four_passes = buckets_done || g_rb.host[3] > 1u;   // (the bucket sort leaves its result where four passes would)
+    const bool side_way = g_rb.host[10] != 0u;             // (then the stream's keys share their top byte: three passes)
+    const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
     const uint32_t side_m = side_way ? g_rb.host[12] : 0u, side_lo = side_way ? g_rb.host[11] : 0u;
     if (side_way && (four_passes || side_m > kDepthSideMax || side_lo > side_m || side_m > (uint32_t)nv)) return fail(GSR_ERR_INTERNAL);
-    if (four_passes && !buckets_done)
+    if (four_passes)
         GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream, nullptr,
                                  xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     if (side_way)
@@ -555,7 +512,7 @@ int gsr_forward(gsr_forward_args* a) {
     // the instances per VISIBLE Gaussian. Measured (binning without the blend, sort / blocks): R/V = 2.7 (50 M tiny splats)
     // 5.6 / 5.9 ms, 5.3 (the bench scene from far away) 0.98 / 1.00 ms, 7.5: 2.08 / 1.81 ms, 11: 2.76 / 1.58 ms, 88: 2x.
     if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 6ull * (uint64_t)nv;
-    a->plan_used = (use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC)) | (buckets_done ? GSR_PLAN_DEPTH_BUCKETS : 0u);
+    a->plan_used = use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC);
     // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
     if (!use_blocks)
         GSR_HIP_TRY(hipMemsetAsync(bs.sweep.error_word, 0, 128 + 256 * sizeof(uint32_t), stream));   // error word + tile-row histogram

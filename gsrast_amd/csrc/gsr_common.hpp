@@ -59,8 +59,7 @@ int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* tem
                           unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr,
                           uint32_t* host_words = nullptr, void* clear = nullptr, size_t clear_bytes = 0,
                           const uint32_t* others_per_wave = nullptr, uint32_t* main_count = nullptr,
-                          uint32_t side_max = 0, uint32_t* side_words = nullptr,
-                          const uint32_t* sample_keys = nullptr, unsigned long long* samples = nullptr);   // (depth_buckets.hip)
+                          uint32_t side_max = 0, uint32_t* side_words = nullptr);
 size_t scan_temp_bytes(size_t n);
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,

@@ -10,7 +10,6 @@
 // Integer wrap-around is that of u32 addition, as in the reference; the un-wrapped 64-bit total is available
 // on request (gsr_forward refuses frames whose instance count does not fit the u32 offsets).
 #include "gsr_common.hpp"
-#include "depth_buckets.hpp"
 
 namespace gsr {
 namespace {
@@ -78,21 +77,8 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
                                                                     uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero,
                                                                     uint4* __restrict__ clear, size_t clear_vecs,
                                                                     const uint32_t* __restrict__ others_per_wave,
-                                                                    uint32_t* __restrict__ main_count,
-                                                                    const uint32_t* __restrict__ sample_keys,
-                                                                    unsigned long long* __restrict__ samples) {
+                                                                    uint32_t* __restrict__ main_count) {
     __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave];
-    // sample_keys / samples (both or none; depth_buckets.hip): one element of every kDepthSampleStride, picked by a hash of its
-    // group: samples[group] = sample_keys[e] << 32 | e if in[e] != 0, else ~0 — the two-pass depth order draws its bucket
-    // boundaries from them (in[] = tilesTouched, sample_keys[] = the depth bits).
-    static_assert(kScanTile % kDepthSampleStride == 0 && kScanTile / kDepthSampleStride <= kScanThreads, "samples per tile");
-    if (samples && threadIdx.x < kScanTile / kDepthSampleStride) {
-        const uint32_t g = blockIdx.x * (kScanTile / kDepthSampleStride) + threadIdx.x;
-        const uint32_t e = depth_sample_index(g);
-        unsigned long long s = ~0ull;
-        if (e < n && in[e] != 0u) s = ((unsigned long long)sample_keys[e] << 32) | e;
-        samples[g] = s;
-    }
     for (size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x; i < clear_vecs; i += (size_t)gridDim.x * kScanThreads)
         clear[i] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t v[kScanItems];
@@ -233,16 +219,14 @@ size_t scan_temp_bytes(size_t n) {
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
                           unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total, uint32_t* host_words,
                           void* clear, size_t clear_bytes, const uint32_t* others_per_wave, uint32_t* main_count,
-                          uint32_t side_max, uint32_t* side_words, const uint32_t* sample_keys, unsigned long long* samples) {
+                          uint32_t side_max, uint32_t* side_words) {
     if (n == 0) return GSR_OK;
-    if ((sample_keys != nullptr) != (samples != nullptr) || (samples && n >= 0xFFFFFFFFull)) return GSR_ERR_INVALID_ARG;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
     if (clear_bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(clear) & 15) != 0 || (host_words && !total64)) return GSR_ERR_INVALID_ARG;
     if ((others_per_wave != nullptr) != (main_count != nullptr) || (main_count && (!nonzero || !side_words))) return GSR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero,
-                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, others_per_wave, main_count,
-                       sample_keys, samples);
+                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, others_per_wave, main_count);
     GSR_LAUNCH_CHECK("tile_reduce_kernel");
     hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total, host_words,
                        main_count, side_max, side_words);

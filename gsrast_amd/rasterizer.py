@@ -123,8 +123,7 @@ class SplatRasterizer:
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
              sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
-             overlap_emit: bool = False, sorted_lists: bool = True, colors_precomp: bool = False,
-             depth_order: str = "auto") -> torch.Tensor:
+             overlap_emit: bool = False, sorted_lists: bool = True, colors_precomp: bool = False) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
@@ -135,9 +134,7 @@ class SplatRasterizer:
         binning chunk holds the sorted keys / values of this call).
         colors_precomp: pass the scene's colours as the reference's `colorsPrecomp` argument (GSCuda.cuh:111) — computed once
         per scene by gsr_colors_from_dc, bit-equal to what the preprocess writes to geomState.rgb per frame (gscuda semantics
-        only: there the colour does not depend on the view).
-        depth_order: "auto" | "lsd" — "lsd" forces the radix passes (GSR_FLAG_DEPTH_LSD); last_depth_buckets tells whether the
-        two-pass bucket order produced this frame's depth order."""
+        only: there the colour does not depend on the view)."""
         if cam is not None:
             self.set_camera(cam)
         a = _capi.ForwardArgs()
@@ -148,8 +145,7 @@ class SplatRasterizer:
                    | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0)
                    | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan]
                    | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else 0)
-                   | (0 if sorted_lists else _capi.GSR_FLAG_NO_SORTED_LISTS)
-                   | {"auto": 0, "lsd": _capi.GSR_FLAG_DEPTH_LSD}[depth_order])
+                   | (0 if sorted_lists else _capi.GSR_FLAG_NO_SORTED_LISTS))
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
         a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()
@@ -180,7 +176,6 @@ class SplatRasterizer:
         self.last_records_staged = int(a.records_staged)
         self.last_plan = _capi.PLAN_NAMES[int(a.plan_used) & 0xFF]
         self.last_lists_written = not (int(a.plan_used) & _capi.GSR_PLAN_LISTS_SKIPPED)
-        self.last_depth_buckets = bool(int(a.plan_used) & _capi.GSR_PLAN_DEPTH_BUCKETS)
         # block plan only: did the blend read the sorted lists (sparse frames) instead of the block lists
         self.last_blend_from_lists = bool(int(a.plan_used) & _capi.GSR_PLAN_BLEND_FROM_LISTS)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
@@ -327,18 +322,6 @@ class SplatRasterizer:
             "rgb": v(st.rgb, 3 * n, torch.float32).view(n, 3),
             "pointOffsets": v(st.point_offsets, n, torch.int32),
         }
-
-    def depth_bucket_stats(self) -> dict:
-        """The two-pass depth order's buckets as the last draw() left them (gsr_depth_bucket_stats): number of buckets,
-        give-up flag, valid samples, region capacity, entries per bucket."""
-        info = (C.c_uint32 * 4)()
-        counts = np.zeros(4096, np.uint32)
-        torch.cuda.current_stream(self.device).synchronize()
-        with torch.cuda.device(self.device):
-            rc = self.lib.gsr_depth_bucket_stats(self.geom.base(), self.num_gaussians, info, counts.ctypes.data, 4096)
-        _capi.check(rc, "gsr_depth_bucket_stats")
-        return {"buckets": int(info[0]), "gave_up": bool(info[1]), "samples": int(info[2]), "capacity": int(info[3]),
-                "counts": counts[: int(info[0])].copy()}
 
     def map_image_state(self) -> dict:
         st = _capi.ImageState()

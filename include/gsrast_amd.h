@@ -127,15 +127,10 @@ enum {
  * Pixels, ranges, finalT, nContrib and numRendered are unchanged. Ignored under the other plans, whose blend
  * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
 #define GSR_FLAG_NO_SORTED_LISTS 0x40u
-/* Depth order of the visible Gaussians by the LSD radix passes (radix_sort.hip) even where the two-pass bucket order
- * (depth_buckets.hip: sampled splitters, one scatter, one in-LDS sort per bucket) applies — tile grids up to 255 x 255 and
- * up to 8.4 M Gaussians. Same order, same lists; for A/B measurements and the parity tests of both ways. */
-#define GSR_FLAG_DEPTH_LSD 0x80u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
        GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer
-                                            than 48 instances per visible Gaussian), not the block lists */,
-       GSR_PLAN_DEPTH_BUCKETS = 0x400 /* or-ed in: the depth order came from the two-pass bucket order */ };
+                                            than 48 instances per visible Gaussian), not the block lists */ };
 
 /* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
  * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this
@@ -254,12 +249,6 @@ int gsr_colors_from_dc(int n, const float* shs, float* colors, void* stream);
  * All pointers are device pointers. For the tests: a dropped record that could light a pixel would be a parity bug. */
 int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_opacity, const int32_t* tile_xy,
                               int width, int height, uint8_t* misses, void* stream);
-
-/* The two-pass depth order's buckets as the last gsr_forward call on `geometry_chunk` (N Gaussians) left them, for the
- * tests and for tuning: info[0] = buckets, info[1] = its give-up flag, info[2] = valid samples, info[3] = the capacity of
- * a bucket's region; counts (host memory, `max_counts` words, may be NULL) gets the entries per bucket. Synchronous on the
- * calling thread (copies device memory). GSR_ERR_INVALID_ARG if that call could not have used the bucket order (N). */
-int gsr_depth_bucket_stats(char* geometry_chunk, int n, uint32_t info[4], uint32_t* counts, uint32_t max_counts);
 
 /* ---- backward pass (next row after the hot path: BASELINE config 5) ----
  * Gradients of L = sum(dL_dout_color * out_color) of ONE gsr_forward call (gscuda semantics) w.r.t. the
