@@ -155,6 +155,7 @@ SIGNATURES = {
     "gsr_ply_activate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "gsr_colors_from_dc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_blend_expf": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_footprint_misses_tile": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "gsr_ply_activate_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]),

@@ -304,6 +304,12 @@ int gsr_colors_from_dc(int n, const float* shs, float* colors, void* stream) {
     return fail(launch_colors_from_dc(n, shs, colors, (hipStream_t)stream));
 }
 
+int gsr_blend_expf(int n, const float* in, float* out, void* stream) {
+    g_hip_error[0] = 0;
+    if (n > 0 && (!in || !out)) return fail(GSR_ERR_INVALID_ARG);
+    return fail(launch_exp_test(n, in, out, (hipStream_t)stream));
+}
+
 int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_opacity, const int32_t* tile_xy, int width,
                               int height, uint8_t* misses, void* stream) {
     g_hip_error[0] = 0;

@@ -152,6 +152,8 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     __shared__ float2 s_xy[kWave];
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
+    __shared__ unsigned long long s_exp[32];
+    exp_table_init(s_exp, (int)threadIdx.x);       // (wave-private LDS: ordered inside the wave)
 
     // (tiles dealt to the XCDs in patches, as in the forward blend: blend_core.hpp)
     const int tile_local = tile_of_workgroup((int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
                 const float dy = xy.y - fy[k];
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
                 if (power > 0.0f) continue;
-                const float G = __expf(power);                   // the forward's exp: same contributing set
+                const float G = exp_ref(power, s_exp);           // the forward's exp: same contributing set
                 const float raw = co.w * G;
                 const float alpha = fminf(0.99f, raw);
                 if (alpha < 1.0f / 255.0f) continue;

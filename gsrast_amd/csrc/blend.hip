@@ -12,6 +12,7 @@
 // Differences that do not change any pixel: a record no lane of the wave can see (power > 0 or below the
 // 1/255 cut for every lane) is skipped after the power evaluation by one ballot.
 
+#include <algorithm>
 #include <type_traits>
 
 #include "blend_core.hpp"
@@ -62,6 +63,7 @@ constexpr uint32_t kPriorityMeanList = 8192;     // entries per tile with a list
 // staged-record count R_f, which therefore stay identical to the reference's.
 __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     __shared__ StagedRecords s_staged;
+    exp_table_init(s_staged.exp_tab, (int)threadIdx.x);      // (wave-private LDS: ordered inside the wave)
 
     // workgroups [k * base, (k + 1) * base) are strip k of the tiles: the three extra sets leave at once unless the frame
     // has few tiles with a list (they are the END of the launch, and a tile's four waves run on one XCD)
@@ -136,7 +138,21 @@ __global__ __launch_bounds__(256) void footprint_test_kernel(int n, const float2
     misses[i] = record_misses_tile(xy[i], co[i], tile_box(tile[i].x, tile[i].y, width, height)) ? 1 : 0;
 }
 
+// Stage entry point for the tests: the blend's exponential (blend_core.hpp, exp_ref), argument by argument.
+__global__ __launch_bounds__(64) void exp_test_kernel(int n, const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ unsigned long long s_exp[32];
+    exp_table_init(s_exp, (int)threadIdx.x);
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < n; i += gridDim.x * 64) out[i] = exp_ref(in[i], s_exp);
+}
+
 }  // namespace
+
+int launch_exp_test(int n, const float* in, float* out, hipStream_t stream) {
+    if (n <= 0) return GSR_OK;
+    hipLaunchKernelGGL(exp_test_kernel, dim3((unsigned)std::min(65536, (n + 63) / 64)), dim3(64), 0, stream, n, in, out);
+    GSR_LAUNCH_CHECK("exp_test_kernel");
+    return GSR_OK;
+}
 
 int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,
                           uint8_t* misses, hipStream_t stream) {

@@ -57,11 +57,68 @@ __device__ __forceinline__ bool record_misses_tile(const float2 xy, const float4
     return pd && !inside && (best + 2e-3f < threshold);
 }
 
-// exp(power) >= 1/255 needs power >= -ln(255) = -5.5413; anything below -5.56 fails the
-// alpha >= 1/255 test for every opacity <= 1 with a 1.9 % margin, far outside rounding.
-constexpr float kPowerFloor = -5.56f;
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- the exponential of GSCuda.cu:645 -------------------------------------------------------------------------------
+// alpha = min(0.99, opacity * exp(power)) feeds two hard tests (alpha >= 1/255, T (1 - alpha) >= cut-off) and, through T,
+// every later record of the pixel: an exponential that is 3 ulp off (v_exp_f32 on a single-rounded power * log2 e: the
+// product alone carries |power| * 2^-24 into the result) lets T drift by 1e-6 over a deep list and flips a threshold for a
+// few pixels per 8 M (round 3: 6 pixels of the 4K parity frame beyond 1e-4, up to 1.3e-3). GSR_EXP_VARIANT:
+//   2 (default) the float exponential as glibc computes it (sysdeps/ieee754/flt-32/e_expf.c since 2.27, from ARM's optimized
+//     routines; error 0.502 ulp): double arithmetic, exp(x) = 2^(k/32) * p(r), k = round(32 x / ln 2), r = 32 x / ln 2 - k,
+//     2^(i/32) from a 32-entry table, p of degree 3, rounded to float once. Restated here constant for constant (checked
+//     against libm on 2e8 arguments on the host: no difference; on the device: tests/test_gpu_parity.py), so alpha, T and every
+//     decision are bit for bit the CPU oracle's. The f64 pipe issues at the f32 rate on this part: 14 more issues per strip.
+//   1 v_exp_f32 on a two-term product (hi = x * log2e_hi rounded, lo = the exact remainder + x * log2e_lo), e * (1 + lo ln 2):
+//     ~1.2 ulp, 5 more issues.    0: __expf, as round 3 shipped.
+#ifndef GSR_EXP_VARIANT
+#define GSR_EXP_VARIANT 2
+#endif
+__constant__ const unsigned long long kExp2Table[32] = {       // asuint64(2^(i/32)) - (i << 47)
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+// tab: the table above in LDS (exp_table_init). Arguments below -104 give 0 (glibc: underflow); NaN gives NaN; arguments
+// above 88.7 are not met here (the power is tested against 0 first, and nothing reads the lanes that fail).
+__device__ __forceinline__ void exp_table_init(unsigned long long* tab, int lane) {
+    if (lane < 32) tab[lane] = kExp2Table[lane];
+}
+__device__ __forceinline__ float exp_ref(float x, const unsigned long long* tab) {
+#if GSR_EXP_VARIANT == 2
+    constexpr double kN = 32.0, kInvLn2N = 0x1.71547652b82fep+0 * kN, kShift = 0x1.8p+52;
+    constexpr double kC0 = 0x1.c6af84b912394p-5 / kN / kN / kN, kC1 = 0x1.ebfce50fac4f3p-3 / kN / kN, kC2 = 0x1.62e42ff0c52d6p-1 / kN;
+    // (below -104 the result is 0, as glibc's underflow path returns: exp(-104) already rounds to it)
+    const double z = kInvLn2N * (double)fmaxf(x, -104.0f);
+    double kd = z + kShift;
+    const uint32_t ki = (uint32_t)__double_as_longlong(kd);         // k: its low bits pick the table entry, the rest is the exponent
+    kd -= kShift;
+    const double r = z - kd;
+    // 2^(k/32) = the table entry with k << 47 added: that only reaches the high word
+    const unsigned long long t = tab[ki & 31u];
+    const double sc = __hiloint2double((int)((uint32_t)(t >> 32) + (ki << 15)), (int)(uint32_t)t);
+    const double zz = __builtin_fma(kC0, r, kC1);
+    const double r2 = r * r;
+    double y = __builtin_fma(kC2, r, 1.0);
+    y = __builtin_fma(zz, r2, y);
+    y = y * sc;
+    return (float)y;
+#elif GSR_EXP_VARIANT == 1
+    (void)tab;
+    constexpr float kHi = 1.44269502162933349609375f;          // log2(e) rounded to float
+    constexpr float kLo = 1.925963033500011e-8f;               // log2(e) - kHi
+    const float hi = x * kHi;
+    const float lo = __builtin_fmaf(x, kHi, -hi) + x * kLo;
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(e, lo * 0.693147182464599609375f, e);
+#else
+    (void)tab;
+    return __expf(x);
+#endif
+}
 
 struct TileLanes {                 // per-lane state of the four pixels a lane owns
     int px, py0;
@@ -103,25 +160,28 @@ __device__ __forceinline__ bool tile_lanes_all_done(const TileLanes& s) {
 // position in the tile's list: the contributor number of GSCuda.cu:624 — records dropped at staging leave gaps).
 // Returns true as soon as every pixel of the tile is finished.
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kFilterSlack = 0.25f;      // in units of the power: covers terms up to 4e6 in magnitude (see composite_staged)
+constexpr float kFilterSlack = 0.25f;      // in units of the power: covers the rounding of terms up to 4e6 in magnitude; records that can exceed 1e6 are not filtered (stage_and_composite)
 // A cheap FILTER in front of the reference's arithmetic. Of the records a tile stages, most reach only a part of its four
 // 16 x 4 strips, and finding that out cost as much as compositing: the reference's power (GSCuda.cu:634) for all four
 // pixels of a lane, 18 issues, and twelve compares. The filter evaluates the power a second way: the staged conic is
-// pre-scaled (stage_and_composite), q = (-0.5 log2(e) A, -log2(e) B, -0.5 log2(e) C, opacity), so that
+// pre-scaled (stage_and_composite), q = (-0.5 log2(e) A, -log2(e) B, -0.5 log2(e) C, the record's floor), so that
 //   log2(e) * power = q.x dx^2 + dy (q.z dy + q.y dx)
 // is four scalar operations for the dx terms and three packed ones per pair of rows (a subtract, two v_pk_fma_f32); a
 // finished pixel has a NaN row coordinate (tile_lanes_init), so the range test "floor <= power <= 0" is the whole
-// candidate test, two compares per pixel whose results stay lane masks in scalar registers. Its floor has a margin
-// (kPowerFloor is 1.9 % below -ln 255) and a record fails it only if every lane is outside [floor, 0], so it decides
-// nothing the reference's tests decide: for the pairs of strips that have a candidate the power is evaluated again in the
+// candidate test, two compares per pixel whose results stay lane masks in scalar registers. Its floor — the power below
+// which THIS record's opacity cannot reach alpha = 1/255 — has margins, and a record fails it only if every lane is outside
+// [floor, 0], so it decides nothing the reference's tests decide: for the pairs of strips that have a candidate the power is evaluated again in the
 // reference's operation order (unfused; raw conic from s_raw), and alpha, the 1/255 test, T and the cut-off test follow
 // from THAT — T and every decision are bit for bit what they were. (Feeding alpha from the fused evaluation was built
 // first: 25 % faster still, but alpha then differs by 1e-7 relative, T drifts by 1e-6 to 1e-5 over a deep list, and a
 // pixel whose T (1 - alpha) lands that close to the cut-off stops one record earlier or later: 59 to 109 pixels of the
 // 8.3 M of the 4K parity frame beyond 1e-4 instead of fewer than 20, `gpurun_out/r3e`, `r3f`.) Only the colour sums
 // take a fused form, three multiply-adds on alpha T — they feed no test, and move the pixel by a few 1e-8.
+// (A record whose power terms are too large for the filter's slack is staged with a zero filter conic and no floor: every
+// unfinished pixel is its candidate, stage_and_composite.)
 __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
-                                                 const float4* s_raw, uint32_t chunk, float t_cutoff) {
+                                                 const float4* s_raw, uint32_t chunk, float t_cutoff,
+                                                 const unsigned long long* exp_tab) {
     const float qnan = __builtin_nanf("");
     constexpr float kAlphaMin = 1.0f / 255.0f;
     for (uint32_t j = 0; j < chunk; ++j) {
@@ -138,15 +198,17 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
         const f32x2 fw01 = __builtin_elementwise_fma(dy01, __builtin_elementwise_fma(cz, dy01, gg), hh);
         const f32x2 fw23 = __builtin_elementwise_fma(dy23, __builtin_elementwise_fma(cz, dy23, gg), hh);
         const float filter[4] = {fw01.x, fw01.y, fw23.x, fw23.y};
-        // exp(power) >= 1/255 needs power >= -ln(255) = -5.5413; below kPowerFloor it fails for every opacity <= 1 (wave-uniform
-        // test). The filter's window is wider than the reference's tests at both ends by kFilterSlack: the two evaluations
-        // of the power differ by rounding, 6e-8 of the largest of three terms that may cancel — for a needle-shaped splat seen
-        // along its axis those terms reach 1e6 while the power is -1 — and a pixel the reference would accept must never be
-        // filtered out. The reference's own "power > 0" and "alpha < 1/255" tests follow below, on its own arithmetic.
-        const float floor2 = q.w > 1.0f ? -__builtin_inff() : (kPowerFloor - kFilterSlack) * kLog2e;
+        // A pixel can pass alpha >= 1/255 only if power >= -ln(255 opacity): the record's own floor (q.w, set at staging with
+        // its margins: a faint record's strips are candidates only where it is bright enough to count, and only candidates pay
+        // for the exponential). The filter's window is wider than the reference's tests at both ends by kFilterSlack: the two
+        // evaluations of the power differ by rounding, 6e-8 of the largest of three terms that may cancel — a record whose terms
+        // can exceed what the slack covers has a zero filter conic — and a pixel the reference would accept must never be
+        // filtered out. The reference's own "power > 0" and "alpha < 1/255" tests follow below, on its
+        // own arithmetic.
         unsigned long long cand[4];       // lane masks (every lane of the wave is active here); false for a finished pixel: NaN
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cand[k] = __ballot(filter[k] <= kFilterSlack * kLog2e) & __ballot(filter[k] >= floor2);
+        for (int k = 0; k < 4; ++k)
+            cand[k] = __ballot(filter[k] <= kFilterSlack * kLog2e) & __ballot(filter[k] >= q.w);
         if ((cand[0] | cand[1] | cand[2] | cand[3]) == 0ull) continue;
         const float4 col = s_rgb[j];
         const float4 raw = s_raw[j];
@@ -160,12 +222,15 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
             // (finished pixels: their dy is NaN, and so is their power — they are no candidates)
             const f32x2 dy = pair == 0 ? dy01 : dy23;
             const f32x2 pw = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
+            // both strips' exponentials side by side (two independent chains of double operations: a deep tile's wave, alone on
+            // its SIMD at the end of the frame, waits for every result it cannot overlap)
+            const float e0 = exp_ref(pw.x, exp_tab), e1 = exp_ref(pw.y, exp_tab);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * pair + h;
                 if (cand[k] == 0ull) continue;                // nobody in this strip sees the record
                 const float power = h == 0 ? pw.x : pw.y;
-                const float alpha = fminf(0.99f, raw.w * __expf(power));
+                const float alpha = fminf(0.99f, raw.w * (h == 0 ? e0 : e1));
                 const unsigned long long live = cand[k] & ~__ballot(power > 0.0f) & ~__ballot(alpha < kAlphaMin);
                 const float test = s.T[k] * (1.0f - alpha);
                 const unsigned long long stop = live & __ballot(test < t_cutoff);
@@ -237,6 +302,7 @@ struct StagedRecords {
     float4 co[kWave];              // conic as the compositing loop wants it (pre-scaled), opacity
     float4 rgb[kWave];             // colour, and (as bits) the record's 1-based position in the tile's list
     float4 raw[kWave];             // conic + opacity as fetched: the reference-order evaluation of the lanes near a threshold
+    unsigned long long exp_tab[32];   // exp_ref's table (exp_table_init at the top of the kernel)
 };
 
 __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, StagedRecords& st,
@@ -254,7 +320,20 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
         const float* c = f.colors + 3 * (size_t)b.id;
         s_xy[slot] = b.xy;
-        s_co[slot] = make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, b.co.w);
+        // the filter's floor for this record, in units of log2: -ln(255 opacity) less the margins (1e-3 for the rounding of the
+        // exponential and the product; kFilterSlack for the filter's own evaluation of the power). Opacity <= 0: +inf, no
+        // candidate (alpha <= 0 fails the 1/255 test); NaN opacity: -inf (the reference's min(0.99, NaN) is 0.99: it counts).
+        const float p0 = -__logf(255.0f * b.co.w);
+        const float floor2 = b.co.w != b.co.w ? -__builtin_inff() : (b.co.w <= 0.0f ? __builtin_inff() : (p0 - 1e-3f - kFilterSlack) * kLog2e);
+        // The filter's slack covers the rounding of power terms up to 4e6 (kFilterSlack / 6e-8). A record whose terms can be
+        // larger somewhere on the tile — a screen-filling needle seen along its axis at 4K: conic entries up to 3.3, |d| in the
+        // thousands — gets a zero filter conic and no floor: its filter value is 0 for every unfinished pixel (NaN for the
+        // finished ones, as always), all of them are candidates, and the reference-order evaluation decides alone.
+        const float dxm = fmaxf(fabsf(b.xy.x - f.box.x_lo), fabsf(b.xy.x - f.box.x_hi)), dym = fmaxf(fabsf(b.xy.y - f.box.y_lo), fabsf(b.xy.y - f.box.y_hi));
+        const float terms = fabsf(b.co.x) * dxm * dxm + fabsf(b.co.z) * dym * dym + 2.0f * fabsf(b.co.y) * dxm * dym;
+        const bool filtered = terms < 1.0e6f;                                   // (NaN: not filtered)
+        s_co[slot] = filtered ? make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, floor2)
+                              : make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
         s_raw[slot] = b.co;
         s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
     }
@@ -265,12 +344,12 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
     if (boundary < pos + count) {
         // records in front of the boundary first; then the reference would test "whole tile done" and stage the next 256
         const uint32_t before = (uint32_t)__popcll(__ballot(keep && rank < boundary - pos));
-        if (before) all_done = composite_staged(s, s_xy, s_co, s_rgb, s_raw, before, f.t_cutoff);
+        if (before) all_done = composite_staged(s, s_xy, s_co, s_rgb, s_raw, before, f.t_cutoff, st.exp_tab);
         if (all_done) return true;
         staged += min((uint32_t)kBatch, f.total - boundary);
         first = before;
     }
-    if (kept > first) all_done = composite_staged(s, s_xy + first, s_co + first, s_rgb + first, s_raw + first, kept - first, f.t_cutoff);
+    if (kept > first) all_done = composite_staged(s, s_xy + first, s_co + first, s_rgb + first, s_raw + first, kept - first, f.t_cutoff, st.exp_tab);
     return all_done;
 }
 

@@ -650,8 +650,9 @@ struct BlockBlendParams {
     int waves_per_tile;          // 1, or 4 (one 16 x 4 strip per wave) when the call has few tiles
 };
 
-__global__ __launch_bounds__(kWave) void blend_blocks_kernel(const BlockBlendParams p) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_blocks_kernel(const BlockBlendParams p) {
     __shared__ StagedRecords s_staged;
+    exp_table_init(s_staged.exp_tab, (int)threadIdx.x);      // (wave-private LDS: ordered inside the wave)
     const int wpt = p.waves_per_tile;
     const int tile_local = tile_of_workgroup((int)blockIdx.x / wpt, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
     if (tile_local < 0) return;

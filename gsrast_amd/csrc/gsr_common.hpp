@@ -135,6 +135,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
                  const uint32_t* nonempty_tiles = nullptr, uint32_t num_rendered = 0);      // (both: see blend.hip, four waves per tile)
 
+int launch_exp_test(int n, const float* in, float* out, hipStream_t stream);
 int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,
                           uint8_t* misses, hipStream_t stream);
 

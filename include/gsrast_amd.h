@@ -243,6 +243,11 @@ int gsr_sort_pairs_u64_u32(const uint64_t* keys_in, uint64_t* keys_out, const ui
  * Gaussian — and the 12 N bytes of geomState.rgb: same pixels bit for bit. Device pointers; asynchronous on stream. */
 int gsr_colors_from_dc(int n, const float* shs, float* colors, void* stream);
 
+/* The blend's exponential (csrc/blend_core.hpp, exp_ref: the float exponential of GSCuda.cu:645 computed as glibc's expf
+ * computes it), argument by argument: out[i] = exp(in[i]), in[i] <= 0.5 and not NaN; device pointers. For the tests: it must
+ * agree bit for bit with the host's expf, which is what makes alpha, T and every threshold decision of the blend those of the CPU oracle. */
+int gsr_blend_expf(int n, const float* in, float* out, void* stream);
+
 /* The blend's footprint test (csrc/blend_core.hpp), record by record: misses[i] = 1 iff the library would drop record i
  * (centre means2D[i], conic + opacity conic_opacity[i]) when it stages the list of tile tile_xy[i] = (tx, ty) of a
  * width x height image, i.e. iff it has PROVEN that no pixel of that tile passes alpha >= 1/255 (GSCuda.cu:645-646).

@@ -48,6 +48,14 @@ def higher_msb(n: int) -> int:
     return int(lib().gsro_higher_msb(ctypes.c_uint32(n)))
 
 
+def expf(x: np.ndarray) -> np.ndarray:
+    """exp of float32 arguments as the oracle's tile loop computes it (libm's expf)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().gsro_expf(ctypes.c_long(x.size), _p(x), _p(out))
+    return out
+
+
 def hardware_concurrency() -> int:
     return int(lib().gsro_hardware_concurrency())
 

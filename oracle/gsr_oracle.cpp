@@ -482,4 +482,10 @@ uint64_t gsro_blend(int width, int height, const uint32_t* ranges, const uint32_
 
 unsigned gsro_hardware_concurrency(void) { return std::thread::hardware_concurrency(); }
 
+// out[i] = exp(in[i]) exactly as the tile loop above computes it (GSCuda.cu:645: the float overload, libm's expf): the checker
+// of the HIP blend's exponential (tests/test_gpu_parity.py).
+void gsro_expf(long n, const float* in, float* out) {
+    for (long i = 0; i < n; ++i) out[i] = std::exp(in[i]);
+}
+
 }  // extern "C"

@@ -48,6 +48,26 @@ def image_report(got, exp, tol=1e-4):
     return float(d.max()), int(bad.sum()), per_pixel
 
 
+PIXEL_TOL = 2e-6     # measured 3.6e-7: the colour sums are three fused multiply-adds on alpha T where the reference rounds twice
+
+
+def assert_blend_parity(img, final_t, n_contrib, exp, what="", bitwise_t=True):
+    """The tile loop's outputs against the oracle's. The HIP blend evaluates power, the exponential (as glibc's expf: the
+    oracle's), alpha, T and every test in the reference's float32 operation order, so the transmittance and the last
+    contributor are the oracle's BIT FOR BIT — no pixel sits on the other side of a threshold — and the colours differ by the
+    rounding of the fused sums only: far inside the north star's 1e-4. bitwise_t=False: `exp` comes from the committed fixture,
+    minted by the numpy restatement (whose float32 exp is not libm's): transmittance within 1e-6 then."""
+    nc = np.asarray(n_contrib).view(np.uint32)
+    flips = int((nc != exp["nContrib"]).sum())
+    ft = np.asarray(final_t)
+    t_diff = int((ft.view(np.uint32) != exp["finalT"].view(np.uint32)).sum())
+    max_err, n_bad, _ = image_report(np.asarray(img), exp["out_color"], 1e-4)
+    print(f"[parity] {what}: max abs pixel err {max_err:.3e}, pixels > 1e-4: {n_bad}, finalT words differing: {t_diff}, nContrib flips: {flips}")
+    assert flips == 0 and (t_diff == 0 if bitwise_t else float(np.abs(ft - exp["finalT"]).max()) <= 1e-6), (what, flips, t_diff)
+    assert n_bad == 0 and max_err <= PIXEL_TOL, (what, max_err, n_bad)
+    return max_err
+
+
 def check_backward_chain(got, g, scene, cam, w, h, ids):
     """gsr_backward's per-Gaussian chain (conic -> cov3D -> scales / rotations, pixel centre and Jacobian -> means3D)
     for the Gaussians `ids`, against oracle/backward_np.py fed with the GPU's own upstream gradients. `got`: the
