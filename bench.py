@@ -34,6 +34,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# Multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise): set before the HIP
+# runtime comes up, for every way this file is started — the driver's own torch.distributed.run included.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -215,7 +218,9 @@ def cpu_baseline(scene, cam, every: int):
                     f"every {every}th splat of the workload (n={n}, R={st['num_rendered']}: NOT the bench frame)")
                    + f" at the same camera and resolution; preprocess, key duplication, stable sort and tile loop on {cores} "
                      f"std::threads (scan and tile ranges: one thread); total {t['total_s']:.2f}s = preprocess {t['preprocess_s']:.2f} + "
-                     f"bin/sort {t['bin_s']:.2f} + blend {t['blend_s']:.2f}"),
+                     f"bin/sort {t['bin_s']:.2f} + blend {t['blend_s']:.2f}; the key duplication + index-indirect std::stable_sort of the R "
+                     f"pairs is {t['bin_s'] / max(t['total_s'], 1e-9):.0%} of it (the tile loop BASELINE names: {t['blend_s']:.2f}s)"),
+        "sort_share": round(t["bin_s"] / max(t["total_s"], 1e-9), 4),
     }
 
 
@@ -233,20 +238,33 @@ class Runner:
         self.grid_x, self.grid_y = (W + 15) // 16, (H + 15) // 16
         self.dl_dout = None
         self.bw_ms = [0.0, 0.0]
+        self.split_ms = [0.0, 0.0]          # sharded runs: device time of the render and of the band exchange (HIP events, profiled frames)
 
     def step(self, cam, profile=False, **kw):
         rast, exch = self.rast, self.exch
         rows = exch.my_tile_rows() if exch else None
+        timed = profile and exch is not None          # (the profiled frames after the timed region: render / exchange split per rank)
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         frame = rast.draw(cam, profile=profile, tile_rows=rows, sync=not self.distributed, **kw)
+        if timed:
+            ev[1].record()
         if self.dl_dout is not None:
-            rast.backward(self.dl_dout, profile=profile, semantics=kw.get("semantics", "gscuda"), sh_degree=kw.get("sh_degree", 3))
+            rast.backward(self.dl_dout, profile=profile, semantics=kw.get("semantics", "gscuda"), sh_degree=kw.get("sh_degree", 3),
+                          wide_sums=os.environ.get("GSR_BW_WIDE_SUMS", "1") != "0")
             if profile:
                 self.bw_ms[0] += rast.last_backward_ms[0]
                 self.bw_ms[1] += rast.last_backward_ms[1]
         if exch:
             exch.gather(frame)
+            if timed:
+                ev[2].record()
             torch.cuda.current_stream(self.device).synchronize()
             rast.poll_async_error()
+            if timed:
+                self.split_ms[0] += ev[0].elapsed_time(ev[1])
+                self.split_ms[1] += ev[1].elapsed_time(ev[2])
         return frame
 
     def sync_all(self):
@@ -285,6 +303,7 @@ class Runner:
         prof_steps = max(5, min(steps, 20))
         stage_sum = {}
         self.bw_ms = [0.0, 0.0]
+        self.split_ms = [0.0, 0.0]
         t1 = time.perf_counter()
         for _ in range(prof_steps):
             self.step(cam, profile=True, **kw)
@@ -301,14 +320,18 @@ class Runner:
             import torch.distributed as dist
             t = torch.tensor([out["elapsed"]], dtype=torch.float64, device=self.device)
             mine = torch.tensor([out["elapsed"], float(out["records_staged"]), float(out["num_rendered"]),
-                                 float(out["tile_rows"][0]), float(out["tile_rows"][1])], dtype=torch.float64, device=self.device)
-            allr = torch.zeros((dist.get_world_size(), 5), dtype=torch.float64, device=self.device)
+                                 float(out["tile_rows"][0]), float(out["tile_rows"][1]),
+                                 self.split_ms[0] / prof_steps, self.split_ms[1] / prof_steps], dtype=torch.float64, device=self.device)
+            allr = torch.zeros((dist.get_world_size(), 7), dtype=torch.float64, device=self.device)
             dist.all_gather_into_tensor(allr.view(-1), mine)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             out["elapsed"] = float(t.item())                       # MAX over ranks
             allr = allr.cpu().numpy()
             out["per_rank"] = [{"rank": g, "tile_rows": [int(allr[g, 3]), int(allr[g, 4])], "num_rendered": int(allr[g, 2]),
-                                "records_staged": int(allr[g, 1]), "ms_per_step": round(allr[g, 0] / steps * 1e3, 4)}
+                                "records_staged": int(allr[g, 1]), "ms_per_step": round(allr[g, 0] / steps * 1e3, 4),
+                                # device time between the first launch of the frame and its last kernel / the end of the band
+                                # exchange behind it (HIP events on the launching stream, profiled frames)
+                                "render_ms": round(float(allr[g, 5]), 4), "exchange_ms": round(float(allr[g, 6]), 4)}
                                for g in range(allr.shape[0])]
             out["records_staged_total"], out["num_rendered_total"] = int(allr[:, 1].sum()), int(allr[:, 2].sum())
         else:
@@ -316,6 +339,32 @@ class Runner:
             out["records_staged_total"], out["num_rendered_total"] = out["records_staged"], out["num_rendered"]
         out["ms_per_step"] = out["elapsed"] / steps * 1e3
         return out
+
+
+def cpp_caller(cam, n_splats, seed, steps, warmup):
+    """The same frame timed from a C++ caller: harness/gsr_harness --bench (gscuda::forward through include/gscuda_shim.hpp with
+    the reference caller's device sync per frame, CudaBuffer.hpp:8-12), run as a child process after the timed region. The
+    harness generates the garden-like stand-in itself (scenes.py restated in C++: R may differ in the last places)."""
+    import tempfile
+    exe = os.path.join(ROOT, "harness", "gsr_harness")
+    if not os.path.exists(exe):
+        return {"error": "harness/gsr_harness is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "camera.bin")
+        with open(path, "wb") as f:
+            np.array([cam.width, cam.height], np.int32).tofile(f)
+            np.concatenate([cam.view, cam.proj, cam.cam_pos, [cam.tan_fovx, cam.tan_fovy], [0.0, 0.0, 0.0]]).astype(np.float32).tofile(f)
+        try:
+            out = subprocess.run([exe, "--bench", str(steps), path, str(n_splats), str(seed), str(warmup)], capture_output=True,
+                                 text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            return {"error": "gsr_harness --bench timed out"}
+    if out.returncode != 0:
+        return {"error": (out.stderr or out.stdout).strip()[-300:]}
+    fields = dict(kv.split("=") for kv in out.stdout.split() if "=" in kv)
+    return {"ms_per_step": float(fields["bench_ms"]), "best_ms": float(fields["best_ms"]), "num_rendered": int(fields["numRendered"]),
+            "steps": steps, "warmup": warmup,
+            "what": "harness/gsr_harness --bench: a C++ caller of gscuda::forward (shim over the C ABI), device sync per frame"}
 
 
 def alg_bytes(m, N, W, H, grid_x, sh_floats_read, colors_precomp=False):
@@ -581,6 +630,21 @@ def main() -> int:
             "roofline_blend": rb,
             "kernels": kernels,
         }
+        # what the driver keeps of this line is its head: the representative frames and the whole-frame rate go into `config`
+        cfg = out["config"]
+        cfg["frame_alg_gbs"] = round(sum(v["alg_bytes"] for v in kernels.values()) / (ms_per_step * 1e-3) / 1e9, 1)   # all stages' algorithmic bytes / frame time
+        cfg["frames_ms"] = {k: extras[k]["ms_per_step"] for k in ("pose_outside", "pose_far", "blend_bound", "no_sorted_lists", "config3_4k")
+                            if k in extras}
+        if distributed:
+            proj, src = load_profile_json("band_projection.json")
+            key = f"{W}x{H}"
+            if default_frame and key in proj and str(world) in proj[key].get("recut_ms", {}):
+                cfg["projected_ms"] = {"slowest_band_ms": proj[key]["recut_ms"][str(world)], "one_gpu_ms": proj[key]["recut_ms"].get("1"),
+                                       "source": f"{src}: one GPU rendering each band of the re-cut frame in turn; exchange not included"}
+        elif default_frame and not args.no_extras:
+            cpp = cpp_caller(cam, n_splats, 43, max(5, min(args.steps, 30)), 5)
+            out["cpp_caller_ms"] = cpp.get("ms_per_step")
+            out["cpp_caller"] = cpp
         out.update(extras)
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)

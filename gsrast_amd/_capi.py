@@ -20,6 +20,7 @@ GSR_ERR_HIP = 3
 GSR_ERR_NO_DEVICE = 4
 GSR_ERR_TOO_LARGE = 5
 GSR_ERR_INTERNAL = 6
+GSR_ERR_STALE_RECEIPT = 7
 
 GSR_FLAG_PROFILE = 0x1
 GSR_FLAG_COUNT_STAGED = 0x2
@@ -110,7 +111,8 @@ class BackwardArgs(C.Structure):
         ("means3D", C.c_void_p), ("view_matrix", C.c_void_p), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
         ("dL_dout_color", C.c_void_p),
         ("dL_dmean2D", C.c_void_p), ("dL_dconic_opacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
-        ("dL_dcov3D", C.c_void_p), ("dL_dshs", C.c_void_p),
+        ("dL_dcov3D", C.c_void_p), ("dL_dshs", C.c_void_p), ("dL_dcov2D", C.c_void_p),
+        ("sums_f64", C.c_void_p),
         ("proj_matrix", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("scale_modifier", C.c_float),
         ("dL_dmeans3D", C.c_void_p), ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
         ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),

@@ -119,7 +119,8 @@ constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned 
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
     uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
-                                       // byte, [12] side keys (all written by the kernels that compute them), [8..9] staged count;
+                                       // byte, [12] side keys as the scan counted them, [13] as the compaction listed them (all written by the
+                                       // kernels that compute them), [8..9] staged count;
                                        // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
                                        // written by the kernels themselves), serial of the owning call, 0}
     uint32_t serial = 0;               // calls made so far by this thread on this device
@@ -279,6 +280,7 @@ const char* gsr_error_string(int code) {
         case GSR_ERR_NO_DEVICE: return "no HIP device";
         case GSR_ERR_TOO_LARGE: return "numRendered exceeds 32-bit offsets";
         case GSR_ERR_INTERNAL: return "radix sort look-back gave up (bounded spin expired)";
+        case GSR_ERR_STALE_RECEIPT: return "the receipt's error slot has been handed to a later call";
         default: return "unknown error";
     }
 }
@@ -320,8 +322,9 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
 int gsr_poll_async_error(const gsr_forward_receipt* r) {
     if (!r || r->magic != GSR_RECEIPT_MAGIC || !r->async_words) return fail(GSR_ERR_INVALID_ARG);
     const volatile uint32_t* w = r->async_words;
-    if (w[2] != r->serial) return GSR_OK;                 // the slot has a new owner: nothing is known about that call any more
-    if (w[0] || w[1]) return fail(GSR_ERR_INTERNAL);
+    // (the kernels write the owning call's serial, not 1: a late writer of an older call cannot raise the new owner's flag)
+    if (w[0] == r->serial || w[1] == r->serial) return fail(GSR_ERR_INTERNAL);
+    if (w[2] != r->serial) return fail(GSR_ERR_STALE_RECEIPT);   // the slot has a new owner: nothing is known about that call any more
     return GSR_OK;
 }
 
@@ -392,7 +395,8 @@ int gsr_forward(gsr_forward_args* a) {
     // This call's error words: the next of the slots (the call that owned it 64 calls ago is long complete: the host
     // has waited for every call's read-back since). Zeroed here, written only by a kernel whose bounded look-back spin
     // gave up, read by gsr_poll_async_error through the receipt.
-    const uint32_t serial = ++g_rb.serial;
+    if (++g_rb.serial == 0u) ++g_rb.serial;                    // (0 is what an untouched error word holds)
+    const uint32_t serial = g_rb.serial;
     const uint32_t slot_at = kAsyncBase + 4u * (serial % kAsyncSlots);
     g_rb.host[slot_at] = g_rb.host[slot_at + 1] = g_rb.host[slot_at + 3] = 0;
     g_rb.host[slot_at + 2] = serial;
@@ -438,7 +442,7 @@ int gsr_forward(gsr_forward_args* a) {
     SweepScratch four[4] = {gs.sweep, gs.sweep_more[0], gs.sweep_more[1], gs.sweep_more[2]};
     // "a bounded look-back spin gave up" is written by the kernel straight into the pinned host words (it never
     // happens on a healthy device; a copy at the end of every frame for it cost 5 us of stream time)
-    for (auto& f : four) f.error_word = err_n;
+    for (auto& f : four) { f.error_word = err_n; f.error_value = serial; }
     // Only Gaussians with at least one tile in this call take part from here on (V of N: 52 % on the
     // bench frame, a few per cent per rank when the frame is sharded): their (depth key, index) pairs
     // are compacted in index order — the same kernels count the digits of the four sort passes.
@@ -475,7 +479,10 @@ int gsr_forward(gsr_forward_args* a) {
     const bool four_passes = g_rb.host[3] > 1u;
     const int nv = (int)g_rb.host[4];                      // V: the length of every depth-ordered array below
     const uint32_t side_m = side_way ? g_rb.host[12] : 0u, side_lo = side_way ? g_rb.host[11] : 0u;
-    if (side_way && (four_passes || side_m > kDepthSideMax || side_lo > side_m || side_m > (uint32_t)nv)) return fail(GSR_ERR_INTERNAL);
+    // (host[13]: the keys the compaction actually put on the side list — it must be the count the scan decided on, or
+    // depth_side_kernel would rank entries of an earlier frame)
+    if (side_way && (four_passes || side_m > kDepthSideMax || side_lo > side_m || side_m > (uint32_t)nv || g_rb.host[13] != side_m))
+        return fail(GSR_ERR_INTERNAL);
     if (four_passes)
         GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream, nullptr,
                                  xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
@@ -490,13 +497,13 @@ int gsr_forward(gsr_forward_args* a) {
     a->num_rendered = R;
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
     if (R == 0) {
-        issue_receipt((uint32_t)nv, nullptr);
-        if (!inria) return fail(GSR_OK);                                                    // :775-778
+        if (!inria) { issue_receipt((uint32_t)nv, nullptr); return fail(GSR_OK); }          // :775-778
         // upstream still runs the tile loop: every pixel gets the background
         GSR_HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
         GSR_STEP(launch_blend(d, img.ranges, nullptr, geom.means2D, a->colors_precomp ? a->colors_precomp : geom.rgb,
                               geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color, nullptr,
                               t_cutoff, stream));
+        issue_receipt((uint32_t)nv, nullptr);               // (after the last step that can fail)
         return fail(GSR_OK);
     }
 
@@ -579,7 +586,7 @@ int gsr_forward(gsr_forward_args* a) {
     } else if (xy_plan) {
         uint32_t* hist_y = bs.sweep.hist;
         SweepScratch bsw = bs.sweep;
-        bsw.error_word = err_r;
+        bsw.error_word = err_r; bsw.error_value = serial;
         if (d.grid_y > 1) GSR_STEP(sweep_clear(bsw, R, (uint32_t)d.grid_y, stream));
         // one pass: with a single tile row the column-major list is already the sorted list
         uint64_t* emit_k = d.grid_y > 1 ? bin.keys_unsorted : bin.keys;
@@ -616,7 +623,7 @@ int gsr_forward(gsr_forward_args* a) {
         const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)num_tiles);                 // :791
         GSR_BEGIN(GSR_STAGE_SORT_PASS2);
         GSR_STEP(launch_sort_pairs(bin.keys_unsorted, bin.keys, bin.values_unsorted, bin.values, R, 32, end_bit,
-                                   bin.sorting_space, stream, err_r));
+                                   bin.sorting_space, stream, err_r, serial));
         GSR_END(GSR_STAGE_SORT_PASS2);
     }
     // :800-801 — under the block plan the ranges are the tile starts it has already computed

@@ -37,29 +37,20 @@ struct RenderBackwardParams {
     float* dL_dmean2D;          // vec2[N]
     float* dL_dconic_opacity;   // vec4[N]: dA, dB, dC, dopacity
     float* dL_dcolors;          // vec3[N]
+    float* dL_dcov2D;           // vec4[N]: (m00, m01, m11, 0), the gradient w.r.t. the full symmetric 2-D covariance; or null
+    double* sums64;             // f64[12 N] or null: the twelve sums of every Gaussian, accumulated in double instead of in the four arrays above
     FrameDims dims;
     int num_tiles;
 };
 
-// sum over the 64 lanes, result in lane 63 (row_shr 1,2,4,8; row_bcast:15; row_bcast:31)
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#define GSR_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
-    GSR_DPP_ADD(0x111, 0xf);
-    GSR_DPP_ADD(0x112, 0xf);
-    GSR_DPP_ADD(0x114, 0xf);
-    GSR_DPP_ADD(0x118, 0xf);
-    GSR_DPP_ADD(0x142, 0xa);
-    GSR_DPP_ADD(0x143, 0xc);
-#undef GSR_DPP_ADD
-    return v;
-}
-
-// Sums of NINE per-lane values over the 64 lanes in about half the steps of nine separate reductions: v_permlane32_swap
+// Sums of TWELVE per-lane values over the 64 lanes in about half the steps of twelve separate reductions: v_permlane32_swap
 // and v_permlane16_swap (gfx950) fold the lanes while packing the values side by side — after the first fold a register
 // holds value 2i in its lower 32 lanes and value 2i + 1 in its upper ones, after the second a row of 16 lanes per value —
-// then one select + row_ror:8 packs two registers into one and three quad / half-row steps finish. On return lane
-// 0 / 32 / 16 / 48 / 8 / 40 / 24 / 56 holds the total of value 0 / 1 / ... / 7 and lane 63 that of value 8.
-__device__ __forceinline__ float wave_sum9(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8) {
+// then, for the first eight, one select + row_ror:8 packs two registers into one and three quad / half-row steps finish; the
+// last four (one register after their folds) take four steps inside their rows. On return lane 0 / 32 / 16 / 48 / 8 / 40 /
+// 24 / 56 holds the total of value 0 / 1 / ... / 7 and lane 4 / 36 / 20 / 52 that of value 8 / 9 / 10 / 11.
+__device__ __forceinline__ float wave_sum12(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8,
+                                            float a9, float a10, float a11) {
     const int lane = threadIdx.x & (kWave - 1);
     auto swap32 = [](float& x, float& y) {
         auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -81,9 +72,15 @@ __device__ __forceinline__ float wave_sum9(float a0, float a1, float a2, float a
     u += GSR_DPP(u, 0xB1);                       // quad_perm [1,0,3,2]
     u += GSR_DPP(u, 0x4E);                       // quad_perm [2,3,0,1]
     u += GSR_DPP(u, 0x141);                      // row_half_mirror
+    swap32(a8, a9); float pp = a8 + a9;          // rows 0, 1: value 8; rows 2, 3: value 9
+    swap32(a10, a11); float qq = a10 + a11;      // rows 0, 1: value 10; rows 2, 3: value 11
+    swap16(pp, qq); float w = pp + qq;           // rows: value 8, 10, 9, 11
+    w += GSR_DPP(w, 0x128);                      // row_ror:8
+    w += GSR_DPP(w, 0xB1);
+    w += GSR_DPP(w, 0x4E);
+    w += GSR_DPP(w, 0x141);                      // every lane of a row: the row's total
 #undef GSR_DPP
-    const float v = wave_sum_to_lane63(a8);
-    return lane == kWave - 1 ? v : u;
+    return (lane & 7) == 4 ? w : u;
 }
 
 // Per-entry sums (block feed). A Gaussian that covers hundreds of tiles receives its nine sums from every one of them,
@@ -92,7 +89,7 @@ __device__ __forceinline__ float wave_sum9(float a0, float a1, float a2, float a
 // a record is an ENTRY of its block's list, shared by at most the 64 tiles of the block: the tiles add into nine floats
 // per entry (scratch: the 8 R bytes of keysUnsorted, dead after the forward call), and flush_block_acc_kernel then adds every
 // entry's sums to its Gaussian's — one lane per entry, different addresses in one instruction, and a Gaussian is hit
-// once per block it touches instead of once per tile. Needs 36 bytes per entry: E <= R / 4.5, else the direct path.
+// once per block it touches instead of once per tile. Needs 48 bytes per entry: E <= R / 6, else the direct path.
 // Decided per block: the sums of the part of the list that the forward blend looked into (BlockMeta::walked, whole
 // units) are cleared before and flushed after the kernel, which pays where that part is short — at most kAccMaxUnits
 // units; bench frame, 1-2 units per block: render backward 0.59 -> 0.38 ms. A block whose tiles walk deeper lists (the
@@ -101,8 +98,9 @@ __device__ __forceinline__ float wave_sum9(float a0, float a1, float a2, float a
 // block lists): with per-entry sums for every block that frame went from 1.26 to 1.38 ms, with a limit of four units
 // from 1.04 to 1.14 ms, with two it is unchanged.
 constexpr uint32_t kAccMaxUnits = 2;
+constexpr uint32_t kAccFloats = 12;     // sums per entry: mean2D (2), conic + opacity (4), colour (3), cov2D (3)
 __device__ __forceinline__ bool block_acc_fits(const BlockFeed& f, uint32_t b) {
-    return f.acc != nullptr && 9ull * (unsigned long long)f.meta.list_start()[f.meta.nbp] <= f.acc_floats &&
+    return f.acc != nullptr && (unsigned long long)kAccFloats * (unsigned long long)f.meta.list_start()[f.meta.nbp] <= f.acc_floats &&
            f.meta.walked()[b] <= kAccMaxUnits;
 }
 
@@ -123,27 +121,37 @@ __device__ __forceinline__ void walked_slice(const BlockFeed& f, size_t& e0, siz
 __global__ __launch_bounds__(256) void zero_block_acc_kernel(const BlockFeed f) {
     size_t e0, e1;
     walked_slice(f, e0, e1);
-    for (size_t i = 9 * e0 + threadIdx.x; i < 9 * e1; i += 256) f.acc[i] = 0.0f;
+    for (size_t i = kAccFloats * e0 + threadIdx.x; i < kAccFloats * e1; i += 256) f.acc[i] = 0.0f;
 }
 
 __global__ __launch_bounds__(256) void flush_block_acc_kernel(const BlockFeed f, float* __restrict__ dL_dmean2D,
-                                                              float* __restrict__ dL_dconic_opacity, float* __restrict__ dL_dcolors) {
+                                                              float* __restrict__ dL_dconic_opacity, float* __restrict__ dL_dcolors,
+                                                              float* __restrict__ dL_dcov2D, double* __restrict__ sums64) {
     size_t e0, e1;
     walked_slice(f, e0, e1);
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        const float* a = f.acc + 9 * e;
-        float v[9];
+        const float* a = f.acc + kAccFloats * e;
+        float v[kAccFloats];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = a[k];
+        for (int k = 0; k < (int)kAccFloats; ++k) v[k] = a[k];
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) any = any || v[k] != 0.0f;
+        for (int k = 0; k < (int)kAccFloats; ++k) any = any || v[k] != 0.0f;
         if (!any) continue;
         const size_t id = f.ent_idx[e];
+        if (sums64) {
+#pragma unroll
+            for (int k = 0; k < (int)kAccFloats; ++k)
+                if (v[k] != 0.0f) unsafeAtomicAdd(sums64 + kAccFloats * id + k, (double)v[k]);
+            continue;
+        }
         unsafeAtomicAdd(dL_dmean2D + 2 * id, v[0]); unsafeAtomicAdd(dL_dmean2D + 2 * id + 1, v[1]);
         unsafeAtomicAdd(dL_dconic_opacity + 4 * id, v[2]); unsafeAtomicAdd(dL_dconic_opacity + 4 * id + 1, v[3]);
         unsafeAtomicAdd(dL_dconic_opacity + 4 * id + 2, v[4]); unsafeAtomicAdd(dL_dconic_opacity + 4 * id + 3, v[5]);
         unsafeAtomicAdd(dL_dcolors + 3 * id, v[6]); unsafeAtomicAdd(dL_dcolors + 3 * id + 1, v[7]); unsafeAtomicAdd(dL_dcolors + 3 * id + 2, v[8]);
+        if (dL_dcov2D) {
+            unsafeAtomicAdd(dL_dcov2D + 4 * id, v[9]); unsafeAtomicAdd(dL_dcov2D + 4 * id + 1, v[10]); unsafeAtomicAdd(dL_dcov2D + 4 * id + 2, v[11]);
+        }
     }
 }
 
@@ -193,12 +201,15 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     // One batch of up to 64 list entries, lane l holding the entry at 0-based list position idx_l (descending batches,
     // ascending lanes): as in the forward blend (blend_core.hpp) most records of a tile's list cannot light any of its
     // pixels; they are dropped here, one lane per record, instead of being walked by the whole wave.
-    // Which of a record's nine sums this lane files (wave_sum9 leaves them in lanes 0, 8, ..., 56 and 63), and where:
-    // one atomic instruction with nine lanes instead of nine instructions with one.
+    // Which of a record's twelve sums this lane files (wave_sum12 leaves them in lanes 0, 8, ..., 56 and 4, 20, 36, 52), and
+    // where: one atomic instruction with twelve lanes instead of twelve instructions with one.
     constexpr int kSumOfRow[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-    const int my_sum = lane == kWave - 1 ? 8 : ((lane & 7) == 0 ? kSumOfRow[lane >> 3] : -1);
-    float* direct_base = my_sum < 2 ? p.dL_dmean2D + my_sum : (my_sum < 6 ? p.dL_dconic_opacity + (my_sum - 2) : p.dL_dcolors + (my_sum - 6));
-    const uint32_t direct_stride = my_sum < 2 ? 2u : (my_sum < 6 ? 4u : 3u);
+    constexpr int kSumOfRow4[4] = {8, 10, 9, 11};
+    int my_sum = (lane & 7) == 0 ? kSumOfRow[lane >> 3] : ((lane & 15) == 4 ? kSumOfRow4[lane >> 4] : -1);
+    if (my_sum >= 9 && !p.dL_dcov2D && !p.sums64) my_sum = -1;
+    float* direct_base = my_sum < 2 ? p.dL_dmean2D + my_sum : (my_sum < 6 ? p.dL_dconic_opacity + (my_sum - 2) :
+                         (my_sum < 9 ? p.dL_dcolors + (my_sum - 6) : p.dL_dcov2D + (my_sum - 9)));
+    const uint32_t direct_stride = my_sum < 2 ? 2u : (my_sum < 6 ? 4u : (my_sum < 9 ? 3u : 4u));
     // `key` is what the record's sums are filed under: the Gaussian's index, or (block feed with room for per-entry
     // sums, see below) the record's entry number in the block lists.
     bool per_entry = false;
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             const float4 co = s_co[j];
             const float dx = xy.x - fx;
             float a_mx = 0.0f, a_my = 0.0f, a_A = 0.0f, a_B = 0.0f, a_C = 0.0f, a_op = 0.0f, a_r = 0.0f, a_g = 0.0f, a_b = 0.0f;
+            float a_m00 = 0.0f, a_m01 = 0.0f, a_m11 = 0.0f;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -247,15 +259,25 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
                 a_A += -0.5f * dx * dx * dpow;
                 a_B += -dx * dy * dpow;
                 a_C += -0.5f * dy * dy * dpow;
-                a_mx += (-co.x * dx - co.y * dy) * dpow;
-                a_my += (-co.z * dy - co.y * dx) * dpow;
+                // u = K d is the gradient of the power w.r.t. the centre (up to sign) AND what the covariance sees: the pixel's
+                // share of dL/dK is -0.5 dpow d d^T, so its share of dL/dcov2D = -K (dL/dK) K is 0.5 dpow u u^T — summed here,
+                // pixel by pixel, instead of being derived from the summed dL/dK afterwards: that product loses cond(K)^2 of
+                // the sums' digits, and the conic of a splat that fills the screen has a condition number of 1e6
+                const float ux = co.x * dx + co.y * dy, uy = co.y * dx + co.z * dy;
+                a_mx -= ux * dpow;
+                a_my -= uy * dpow;
+                const float hd = 0.5f * dpow;
+                a_m00 += hd * ux * ux; a_m01 += hd * ux * uy; a_m11 += hd * uy * uy;
             }
             if (__ballot(any) == 0ull) continue;
-            const float total = wave_sum9(a_mx, a_my, a_A, a_B, a_C, a_op, a_r, a_g, a_b);
+            const float total = wave_sum12(a_mx, a_my, a_A, a_B, a_C, a_op, a_r, a_g, a_b, a_m00, a_m01, a_m11);
             if (my_sum >= 0) {
                 const size_t key = s_id[j];
-                float* dst = per_entry ? p.feed.acc + 9 * key + my_sum : direct_base + direct_stride * key;
-                unsafeAtomicAdd(dst, total);
+                // (double sums: a record's twelve lie side by side, one 96-byte piece per atomic instruction; a Gaussian that
+                // fills the screen gets its sums from 8 160 tiles with terms of either sign: in float the order of arrival
+                // showed in the fourth digit of its gradients)
+                if (!per_entry && p.sums64) unsafeAtomicAdd(p.sums64 + kAccFloats * key + my_sum, (double)total);
+                else unsafeAtomicAdd(per_entry ? p.feed.acc + kAccFloats * key + my_sum : direct_base + direct_stride * key, total);
             }
         }
     };
@@ -355,6 +377,11 @@ struct PreprocessBackwardParams {
     const float* view;
     float tan_fovx, tan_fovy, focal;
     const float4* dL_dconic_opacity;
+    const float4* dL_dcov2D;        // (m00, m01, m11, 0) summed by the render backward, or null: derived from dL_dconic_opacity
+    // With sums64 (f64[12 N]) the render backward's sums arrive there instead: this kernel reads them, rounds them into the
+    // four float arrays (every Gaussian: zeros for the ones without a tile), and leaves the doubles zero for the next call.
+    double* sums64;
+    float2* out_mean2D; float4* out_conic_opacity; float* out_colors; float4* out_cov2D;
     const float* dL_dcolors;
     float* dL_dcov3D;       // f32[6 N]
     float* dL_dshs;         // f32[48 N] or null; only the DC triple of every Gaussian is written
@@ -427,78 +454,103 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     __shared__ float s_sh[INRIA ? 4 * kWave * kShRow : 1];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool valid = idx < p.n;
-    float out[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    float gmean[3] = {0.0f, 0.0f, 0.0f};
-    const bool visible = valid && p.radii[idx] > 0;
+    // (without dL_dcov3D the kernel only rounds the double sums into the float arrays: radii may then be missing)
+    const bool has_tile = valid && (p.radii == nullptr || p.radii[idx] > 0);
+    const bool visible = has_tile && p.dL_dcov3D != nullptr;
     // ---- loads ----
     float4 mean = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g = mean, sc = mean, rot = mean;
     float2 g2 = make_float2(0.0f, 0.0f), c3a = g2, c3b = g2, c3c = g2;
     float gc[3] = {0.0f, 0.0f, 0.0f};
+    double sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (mean2D 2, conic 3 + opacity, colour 3, cov2D 3), as summed
+    if (has_tile && p.sums64) {
+        const double2* sp = reinterpret_cast<const double2*>(p.sums64 + 12 * (size_t)idx);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double2 v2 = sp[k]; sum[2 * k] = v2.x; sum[2 * k + 1] = v2.y; }
+    }
     if (visible) {
         mean = p.means3D[idx];
         const float2* c3p = reinterpret_cast<const float2*>(p.cov3D + 6 * (size_t)idx);
         c3a = c3p[0]; c3b = c3p[1]; c3c = c3p[2];
-        g = p.dL_dconic_opacity[idx];
-        if (p.dL_dmeans3D) g2 = p.dL_dmean2D[idx];
-        if (p.dL_dscales) { sc = p.scales[idx]; rot = p.rotations[idx]; }
-        if (p.dL_dshs) {
-            const float* gcp = p.dL_dcolors + 3 * (size_t)idx;
-            gc[0] = gcp[0]; gc[1] = gcp[1]; gc[2] = gcp[2];
+        if (!p.sums64) {
+            g = p.dL_dconic_opacity[idx];
+            if (p.dL_dmeans3D) g2 = p.dL_dmean2D[idx];
+            if (p.dL_dshs) {
+                const float* gcp = p.dL_dcolors + 3 * (size_t)idx;
+                gc[0] = gcp[0]; gc[1] = gcp[1]; gc[2] = gcp[2];
+            }
+            if (p.dL_dcov2D) { const float4 gcv = p.dL_dcov2D[idx]; sum[9] = gcv.x; sum[10] = gcv.y; sum[11] = gcv.z; }
+            sum[0] = g2.x; sum[1] = g2.y; sum[2] = g.x; sum[3] = g.y; sum[4] = g.z; sum[5] = g.w; sum[6] = gc[0]; sum[7] = gc[1]; sum[8] = gc[2];
         }
+        if (p.dL_dscales) { sc = p.scales[idx]; rot = p.rotations[idx]; }
     }
+    if (p.sums64) { gc[0] = (float)sum[6]; gc[1] = (float)sum[7]; gc[2] = (float)sum[8]; }
+    const bool have_cov2D = p.sums64 != nullptr || p.dL_dcov2D != nullptr;
+    // The chain is N-sized and waits for memory: its arithmetic runs in double, so that what the render backward summed is
+    // not degraded further (the rotation gradient of a nearly round splat is a difference of nearly equal numbers).
+    typedef double R;
+    R out[6] = {0, 0, 0, 0, 0, 0};
+    R gmean[3] = {0, 0, 0};
     if (visible) {
-        const float* v = p.view;
-        // t, clamped as in computeCov2D (GSCuda.cu:201-210)
-        float tx = (v[0] * mean.x + v[4] * mean.y) + (v[8] * mean.z + v[12] * 1.0f);
-        float ty = (v[1] * mean.x + v[5] * mean.y) + (v[9] * mean.z + v[13] * 1.0f);
-        const float tz = (v[2] * mean.x + v[6] * mean.y) + (v[10] * mean.z + v[14] * 1.0f);
+        const float* vf = p.view;
+        R v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (R)vf[i];
+        // t, clamped as in computeCov2D (GSCuda.cu:201-210): the clamp DECISIONS are the forward's, in its float32 arithmetic
+        const float txf = (vf[0] * mean.x + vf[4] * mean.y) + (vf[8] * mean.z + vf[12] * 1.0f);
+        const float tyf = (vf[1] * mean.x + vf[5] * mean.y) + (vf[9] * mean.z + vf[13] * 1.0f);
+        const float tzf = (vf[2] * mean.x + vf[6] * mean.y) + (vf[10] * mean.z + vf[14] * 1.0f);
         const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
-        const float rx = tx / tz, ry = ty / tz;
-        const float cx = fminf(limx, fmaxf(-limx, rx)), cy = fminf(limy, fmaxf(-limy, ry));
-        tx = cx * tz;
-        ty = cy * tz;
+        const float rx = txf / tzf, ry = tyf / tzf;
+        const float cxf = fminf(limx, fmaxf(-limx, rx)), cyf = fminf(limy, fmaxf(-limy, ry));
+        const bool clx = rx != cxf, cly = ry != cyf;          // clamped: t.x (t.y) no longer moves the entry, t.z does
+        const R tz = (R)tzf, cx = (R)cxf, cy = (R)cyf;
+        const R tx = cx * tz, ty = cy * tz;
         // P = J W (2 x 3): cov2D = P Sigma P^T
-        const float fx = INRIA ? p.focal_x : p.focal, fy = INRIA ? p.focal_y : p.focal;
-        const float j00 = fx / tz, j11 = fy / tz, j02 = -fx * tx / (tz * tz), j12 = -fy * ty / (tz * tz);
-        float P[2][3];
+        const R fx = INRIA ? (R)p.focal_x : (R)p.focal, fy = INRIA ? (R)p.focal_y : (R)p.focal;
+        const R j00 = fx / tz, j11 = fy / tz, j02 = -fx * tx / (tz * tz), j12 = -fy * ty / (tz * tz);
+        R P[2][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             P[0][c] = j00 * v[4 * c + 0] + j02 * v[4 * c + 2];
             P[1][c] = j11 * v[4 * c + 1] + j12 * v[4 * c + 2];
         }
-        const float c3[6] = {c3a.x, c3a.y, c3b.x, c3b.y, c3c.x, c3c.y};
-        const float s[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
-        float ps[2][3];
+        const R c3[6] = {(R)c3a.x, (R)c3a.y, (R)c3b.x, (R)c3b.y, (R)c3c.x, (R)c3c.y};
+        const R s[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+        R ps[2][3];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) ps[r][c] = P[r][0] * s[0][c] + P[r][1] * s[1][c] + P[r][2] * s[2][c];
-        const float a = (ps[0][0] * P[0][0] + ps[0][1] * P[0][1] + ps[0][2] * P[0][2]) + 0.3f;
-        const float b = ps[0][0] * P[1][0] + ps[0][1] * P[1][1] + ps[0][2] * P[1][2];
-        const float cc = (ps[1][0] * P[1][0] + ps[1][1] * P[1][1] + ps[1][2] * P[1][2]) + 0.3f;
-        const float det = a * cc - b * b;
-        if (det != 0.0f) {
-            const float inv = 1.0f / det;
-            const float k00 = cc * inv, k01 = -b * inv, k11 = a * inv;         // K = cov2D^-1 = the conic
-            const float q00 = g.x, q01 = 0.5f * g.y, q11 = g.z;                // gradient w.r.t. the full symmetric K
-            // gM = -K gK K
-            const float r00 = k00 * q00 + k01 * q01, r01 = k00 * q01 + k01 * q11;
-            const float r10 = k01 * q00 + k11 * q01, r11 = k01 * q01 + k11 * q11;
-            const float m00 = -(r00 * k00 + r01 * k01), m01 = -(r00 * k01 + r01 * k11);
-            const float m11 = -(r10 * k01 + r11 * k11);
+        const R a = (ps[0][0] * P[0][0] + ps[0][1] * P[0][1] + ps[0][2] * P[0][2]) + 0.3;
+        const R b = ps[0][0] * P[1][0] + ps[0][1] * P[1][1] + ps[0][2] * P[1][2];
+        const R cc = (ps[1][0] * P[1][0] + ps[1][1] * P[1][1] + ps[1][2] * P[1][2]) + 0.3;
+        const R det = a * cc - b * b;
+        if (det != 0.0) {
+            // gM: gradient w.r.t. the full symmetric cov2D. Summed directly by the render backward (dL_dcov2D), or, without that
+            // array, -K gK K from the summed conic gradient (K = cov2D^-1: loses cond(K)^2 of the sums' digits)
+            R m00 = sum[9], m01 = sum[10], m11 = sum[11];
+            if (!have_cov2D) {
+                const R inv = 1.0 / det;
+                const R k00 = cc * inv, k01 = -b * inv, k11 = a * inv;
+                const R q00 = sum[2], q01 = 0.5 * sum[3], q11 = sum[4];      // gradient w.r.t. the full symmetric K
+                const R r00 = k00 * q00 + k01 * q01, r01 = k00 * q01 + k01 * q11;
+                const R r10 = k01 * q00 + k11 * q01, r11 = k01 * q01 + k11 * q11;
+                m00 = -(r00 * k00 + r01 * k01); m01 = -(r00 * k01 + r01 * k11);
+                m11 = -(r10 * k01 + r11 * k11);
+            }
             // gS = P^T gM P, stored entries: off-diagonals appear twice in Sigma
-            float gp[2][3];
+            R gp[2][3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 gp[0][c] = m00 * P[0][c] + m01 * P[1][c];
                 gp[1][c] = m01 * P[0][c] + m11 * P[1][c];
             }
             auto gs = [&](int r, int c) { return P[0][r] * gp[0][c] + P[1][r] * gp[1][c]; };
-            out[0] = gs(0, 0); out[1] = 2.0f * gs(0, 1); out[2] = 2.0f * gs(0, 2);
-            out[3] = gs(1, 1); out[4] = 2.0f * gs(1, 2); out[5] = gs(2, 2);
+            out[0] = gs(0, 0); out[1] = 2.0 * gs(0, 1); out[2] = 2.0 * gs(0, 2);
+            out[3] = gs(1, 1); out[4] = 2.0 * gs(1, 2); out[5] = gs(2, 2);
             if (p.dL_dmeans3D) {
                 // through the Jacobian J(t): cov2D = J Mw J^T with Mw = W Sigma W^T; gJ = 2 gcov J Mw
-                float ws[3][3], mw[3][3];
+                R ws[3][3], mw[3][3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -507,23 +559,22 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) mw[r][c] = ws[r][0] * v[0 + c] + ws[r][1] * v[4 + c] + ws[r][2] * v[8 + c];
-                const float J[2][3] = {{j00, 0.0f, j02}, {0.0f, j11, j12}};
-                float jm[2][3], gJ[2][3];
+                const R J[2][3] = {{j00, 0.0, j02}, {0.0, j11, j12}};
+                R jm[2][3], gJ[2][3];
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) jm[r][c] = J[r][0] * mw[0][c] + J[r][1] * mw[1][c] + J[r][2] * mw[2][c];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    gJ[0][c] = 2.0f * (m00 * jm[0][c] + m01 * jm[1][c]);
-                    gJ[1][c] = 2.0f * (m01 * jm[0][c] + m11 * jm[1][c]);
+                    gJ[0][c] = 2.0 * (m00 * jm[0][c] + m01 * jm[1][c]);
+                    gJ[1][c] = 2.0 * (m01 * jm[0][c] + m11 * jm[1][c]);
                 }
-                const float itz2 = 1.0f / (tz * tz);
-                const float g_tx = -gJ[0][2] * fx * itz2, g_ty = -gJ[1][2] * fy * itz2;
-                const float g_tz = -(gJ[0][0] * fx + gJ[1][1] * fy) * itz2 + (gJ[0][2] * fx * tx + gJ[1][2] * fy * ty) * (2.0f / (tz * tz * tz));
-                const bool clx = rx != cx, cly = ry != cy;          // clamped: t.x (t.y) no longer moves the entry, t.z does
-                const float gt0 = clx ? 0.0f : g_tx, gt1 = cly ? 0.0f : g_ty;
-                const float gt2 = g_tz + (clx ? g_tx * cx : 0.0f) + (cly ? g_ty * cy : 0.0f);
+                const R itz2 = 1.0 / (tz * tz);
+                const R g_tx = -gJ[0][2] * fx * itz2, g_ty = -gJ[1][2] * fy * itz2;
+                const R g_tz = -(gJ[0][0] * fx + gJ[1][1] * fy) * itz2 + (gJ[0][2] * fx * tx + gJ[1][2] * fy * ty) * (2.0 / (tz * tz * tz));
+                const R gt0 = clx ? 0.0 : g_tx, gt1 = cly ? 0.0 : g_ty;
+                const R gt2 = g_tz + (clx ? g_tx * cx : 0.0) + (cly ? g_ty * cy : 0.0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) gmean[j] = v[4 * j + 0] * gt0 + v[4 * j + 1] * gt1 + v[4 * j + 2] * gt2;
             }
@@ -531,16 +582,17 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
         if (p.dL_dmeans3D) {
             // pixel-space centre: pix = ((proj mean).x / ((proj mean).w + 0.001) * 0.5 + 0.5) * W (GSCuda.cu:302-305, :342)
             const float* pm = p.proj;
-            const float mw_ = INRIA ? 1.0f : mean.w;          // (the upstream projection takes the point as (x, y, z, 1))
-            const float hx = (pm[0] * mean.x + pm[4] * mean.y) + (pm[8] * mean.z + pm[12] * mw_);
-            const float hy = (pm[1] * mean.x + pm[5] * mean.y) + (pm[9] * mean.z + pm[13] * mw_);
-            const float wp = (INRIA ? p.w_eps : 0.001f) + ((pm[3] * mean.x + pm[7] * mean.y) + (pm[11] * mean.z + pm[15] * mw_));
-            const float iw = 1.0f / wp, iw2 = iw * iw;
+            const R mw_ = INRIA ? 1.0 : (R)mean.w;          // (the upstream projection takes the point as (x, y, z, 1))
+            const R mx = (R)mean.x, my = (R)mean.y, mz = (R)mean.z;
+            const R hx = ((R)pm[0] * mx + (R)pm[4] * my) + ((R)pm[8] * mz + (R)pm[12] * mw_);
+            const R hy = ((R)pm[1] * mx + (R)pm[5] * my) + ((R)pm[9] * mz + (R)pm[13] * mw_);
+            const R wp = (INRIA ? (R)p.w_eps : (R)0.001f) + (((R)pm[3] * mx + (R)pm[7] * my) + ((R)pm[11] * mz + (R)pm[15] * mw_));
+            const R iw = 1.0 / wp, iw2 = iw * iw;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float dx = 0.5f * (float)p.width * (pm[4 * j + 0] * iw - hx * pm[4 * j + 3] * iw2);
-                const float dy = 0.5f * (float)p.height * (pm[4 * j + 1] * iw - hy * pm[4 * j + 3] * iw2);
-                gmean[j] += dx * g2.x + dy * g2.y;
+                const R dx = 0.5 * (R)p.width * ((R)pm[4 * j + 0] * iw - hx * (R)pm[4 * j + 3] * iw2);
+                const R dy = 0.5 * (R)p.height * ((R)pm[4 * j + 1] * iw - hy * (R)pm[4 * j + 3] * iw2);
+                gmean[j] += dx * sum[0] + dy * sum[1];
             }
         }
     }
@@ -601,61 +653,59 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             }
         }
     }
-    float gsc[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    R gsc[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
     if (p.dL_dscales) {
         // Sigma = M M^T, M = R diag(mod s): gM = 2 gSigma M (off-diagonal stored gradients split over both entries)
+        const R gS[3][3] = {{out[0], 0.5 * out[1], 0.5 * out[2]}, {0.5 * out[1], out[3], 0.5 * out[4]}, {0.5 * out[2], 0.5 * out[4], out[5]}};
+        const R mod = (R)p.scale_modifier;
+        const R sv[3] = {mod * (R)sc.x, mod * (R)sc.y, mod * (R)sc.z};
         if (visible && INRIA) {
             // Sigma = M M^T, M = R(q) diag(mod s) with the RAW quaternion q = (r, x, y, z) (oracle: inria_cov3d_backward)
-            const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
-            const float R[3][3] = {{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
-                                   {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
-                                   {2.0f * (x * z - r * y), 2.0f * (y * z + r * x), 1.0f - 2.0f * (x * x + y * y)}};
-            const float sv[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
-            const float gS[3][3] = {{out[0], 0.5f * out[1], 0.5f * out[2]}, {0.5f * out[1], out[3], 0.5f * out[4]},
-                                    {0.5f * out[2], 0.5f * out[4], out[5]}};
-            float gR[3][3];
+            const R r = (R)rot.x, x = (R)rot.y, y = (R)rot.z, z = (R)rot.w;
+            const R Rm[3][3] = {{1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - r * z), 2.0 * (x * z + r * y)},
+                                {2.0 * (x * y + r * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z - r * x)},
+                                {2.0 * (x * z - r * y), 2.0 * (y * z + r * x), 1.0 - 2.0 * (x * x + y * y)}};
+            R gR[3][3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float gm[3];
+                R gm[3];
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) gm[rr] = 2.0f * (gS[rr][0] * R[0][c] + gS[rr][1] * R[1][c] + gS[rr][2] * R[2][c]) * sv[c];
-                gsc[c] = p.scale_modifier * (R[0][c] * gm[0] + R[1][c] * gm[1] + R[2][c] * gm[2]);
+                for (int rr = 0; rr < 3; ++rr) gm[rr] = 2.0 * (gS[rr][0] * Rm[0][c] + gS[rr][1] * Rm[1][c] + gS[rr][2] * Rm[2][c]) * sv[c];
+                gsc[c] = mod * (Rm[0][c] * gm[0] + Rm[1][c] * gm[1] + Rm[2][c] * gm[2]);
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) gR[rr][c] = gm[rr] * sv[c];
             }
-            gq[0] = 2.0f * (z * (gR[1][0] - gR[0][1]) + y * (gR[0][2] - gR[2][0]) + x * (gR[2][1] - gR[1][2]));
-            gq[1] = 2.0f * (y * (gR[0][1] + gR[1][0]) + z * (gR[0][2] + gR[2][0]) + r * (gR[2][1] - gR[1][2])) - 4.0f * x * (gR[1][1] + gR[2][2]);
-            gq[2] = 2.0f * (x * (gR[0][1] + gR[1][0]) + r * (gR[0][2] - gR[2][0]) + z * (gR[1][2] + gR[2][1])) - 4.0f * y * (gR[0][0] + gR[2][2]);
-            gq[3] = 2.0f * (r * (gR[1][0] - gR[0][1]) + x * (gR[0][2] + gR[2][0]) + y * (gR[1][2] + gR[2][1])) - 4.0f * z * (gR[0][0] + gR[1][1]);
+            gq[0] = 2.0 * (z * (gR[1][0] - gR[0][1]) + y * (gR[0][2] - gR[2][0]) + x * (gR[2][1] - gR[1][2]));
+            gq[1] = 2.0 * (y * (gR[0][1] + gR[1][0]) + z * (gR[0][2] + gR[2][0]) + r * (gR[2][1] - gR[1][2])) - 4.0 * x * (gR[1][1] + gR[2][2]);
+            gq[2] = 2.0 * (x * (gR[0][1] + gR[1][0]) + r * (gR[0][2] - gR[2][0]) + z * (gR[1][2] + gR[2][1])) - 4.0 * y * (gR[0][0] + gR[2][2]);
+            gq[3] = 2.0 * (r * (gR[1][0] - gR[0][1]) + x * (gR[0][2] + gR[2][0]) + y * (gR[1][2] + gR[2][1])) - 4.0 * z * (gR[0][0] + gR[1][1]);
         } else if (visible) {
-            const float nrm = sqrtf((rot.x * rot.x + rot.y * rot.y) + (rot.z * rot.z + rot.w * rot.w));
-            const float inv = 1.0f / nrm;
-            const float x = rot.x * inv, y = rot.y * inv, z = rot.z * inv, w = rot.w * inv;
-            const float R[3][3] = {{2.0f * (x * x + y * y) - 1.0f, 2.0f * (y * z - x * w), 2.0f * (y * w + x * z)},
-                                   {2.0f * (y * z + x * w), 2.0f * (x * x + z * z) - 1.0f, 2.0f * (z * w - x * y)},
-                                   {2.0f * (y * w - x * z), 2.0f * (z * w + x * y), 2.0f * (x * x + w * w) - 1.0f}};
-            const float sv[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
-            const float gS[3][3] = {{out[0], 0.5f * out[1], 0.5f * out[2]}, {0.5f * out[1], out[3], 0.5f * out[4]},
-                                    {0.5f * out[2], 0.5f * out[4], out[5]}};
-            float gM[3][3];
+            const R qx = (R)rot.x, qy = (R)rot.y, qz = (R)rot.z, qw = (R)rot.w;
+            const R nrm = sqrt((qx * qx + qy * qy) + (qz * qz + qw * qw));
+            const R inv = 1.0 / nrm;
+            const R x = qx * inv, y = qy * inv, z = qz * inv, w = qw * inv;
+            const R Rm[3][3] = {{2.0 * (x * x + y * y) - 1.0, 2.0 * (y * z - x * w), 2.0 * (y * w + x * z)},
+                                {2.0 * (y * z + x * w), 2.0 * (x * x + z * z) - 1.0, 2.0 * (z * w - x * y)},
+                                {2.0 * (y * w - x * z), 2.0 * (z * w + x * y), 2.0 * (x * x + w * w) - 1.0}};
+            R gM[3][3];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    gM[r][c] = 2.0f * (gS[r][0] * R[0][c] + gS[r][1] * R[1][c] + gS[r][2] * R[2][c]) * sv[c];
-            float gR[3][3];
+                    gM[r][c] = 2.0 * (gS[r][0] * Rm[0][c] + gS[r][1] * Rm[1][c] + gS[r][2] * Rm[2][c]) * sv[c];
+            R gR[3][3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                gsc[c] = p.scale_modifier * (R[0][c] * gM[0][c] + R[1][c] * gM[1][c] + R[2][c] * gM[2][c]);
+                gsc[c] = mod * (Rm[0][c] * gM[0][c] + Rm[1][c] * gM[1][c] + Rm[2][c] * gM[2][c]);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) gR[r][c] = gM[r][c] * sv[c];
             }
             // dR/dq for the normalised quaternion (x = real part), then through the normalisation
-            const float gx = 4.0f * x * (gR[0][0] + gR[1][1] + gR[2][2]) + 2.0f * (w * (gR[1][0] - gR[0][1]) + z * (gR[0][2] - gR[2][0]) + y * (gR[2][1] - gR[1][2]));
-            const float gy = 4.0f * y * gR[0][0] + 2.0f * (z * (gR[0][1] + gR[1][0]) + w * (gR[0][2] + gR[2][0]) + x * (gR[2][1] - gR[1][2]));
-            const float gz = 4.0f * z * gR[1][1] + 2.0f * (y * (gR[0][1] + gR[1][0]) + w * (gR[1][2] + gR[2][1]) + x * (gR[0][2] - gR[2][0]));
-            const float gw = 4.0f * w * gR[2][2] + 2.0f * (y * (gR[0][2] + gR[2][0]) + z * (gR[1][2] + gR[2][1]) + x * (gR[1][0] - gR[0][1]));
-            const float dot = x * gx + y * gy + z * gz + w * gw;
+            const R gx = 4.0 * x * (gR[0][0] + gR[1][1] + gR[2][2]) + 2.0 * (w * (gR[1][0] - gR[0][1]) + z * (gR[0][2] - gR[2][0]) + y * (gR[2][1] - gR[1][2]));
+            const R gy = 4.0 * y * gR[0][0] + 2.0 * (z * (gR[0][1] + gR[1][0]) + w * (gR[0][2] + gR[2][0]) + x * (gR[2][1] - gR[1][2]));
+            const R gz = 4.0 * z * gR[1][1] + 2.0 * (y * (gR[0][1] + gR[1][0]) + w * (gR[1][2] + gR[2][1]) + x * (gR[0][2] - gR[2][0]));
+            const R gw = 4.0 * w * gR[2][2] + 2.0 * (y * (gR[0][2] + gR[2][0]) + z * (gR[1][2] + gR[2][1]) + x * (gR[1][0] - gR[0][1]));
+            const R dot = x * gx + y * gy + z * gz + w * gw;
             gq[0] = (gx - x * dot) * inv; gq[1] = (gy - y * dot) * inv; gq[2] = (gz - z * dot) * inv; gq[3] = (gw - w * dot) * inv;
         }
     }
@@ -671,16 +721,33 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             }
         }
     }
-    if (valid) {
-        if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4(gmean[0], gmean[1], gmean[2], 0.0f);
+    if (valid && p.sums64) {
+        // the sums, rounded once, for every Gaussian (what the memsets + float atomics leave in the other mode)
+        p.out_mean2D[idx] = make_float2((float)sum[0], (float)sum[1]);
+        p.out_conic_opacity[idx] = make_float4((float)sum[2], (float)sum[3], (float)sum[4], (float)sum[5]);
+        float* oc = p.out_colors + 3 * (size_t)idx;
+        oc[0] = (float)sum[6]; oc[1] = (float)sum[7]; oc[2] = (float)sum[8];
+        if (p.out_cov2D) p.out_cov2D[idx] = make_float4((float)sum[9], (float)sum[10], (float)sum[11], 0.0f);
+        // (most Gaussians with a tile lie behind every pixel's last contributor and received nothing: no write for those)
+        bool touched = false;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) touched = touched || sum[k] != 0.0;
+        if (touched) {
+            double2* sp = reinterpret_cast<double2*>(p.sums64 + 12 * (size_t)idx);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sp[k] = make_double2(0.0, 0.0);
+        }
+    }
+    if (valid && p.dL_dcov3D) {
+        if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4((float)gmean[0], (float)gmean[1], (float)gmean[2], 0.0f);
         if (p.dL_dscales) {
-            p.dL_dscales[idx] = make_float4(gsc[0], gsc[1], gsc[2], 0.0f);
-            if (p.dL_drotations) p.dL_drotations[idx] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+            p.dL_dscales[idx] = make_float4((float)gsc[0], (float)gsc[1], (float)gsc[2], 0.0f);
+            if (p.dL_drotations) p.dL_drotations[idx] = make_float4((float)gq[0], (float)gq[1], (float)gq[2], (float)gq[3]);
         }
         float2* dst = reinterpret_cast<float2*>(p.dL_dcov3D + 6 * (size_t)idx);
-        dst[0] = make_float2(out[0], out[1]);
-        dst[1] = make_float2(out[2], out[3]);
-        dst[2] = make_float2(out[4], out[5]);
+        dst[0] = make_float2((float)out[0], (float)out[1]);
+        dst[1] = make_float2((float)out[2], (float)out[3]);
+        dst[2] = make_float2((float)out[4], (float)out[5]);
     }
     // (lanes past n stay to the end: the SH gradients above and the DC gradient below are written by the wave together)
     if (p.dL_dshs && !INRIA) {
@@ -781,9 +848,14 @@ static int backward_impl(gsr_backward_args* a) {
         GSR_HIP_TRY(hipStreamSynchronize(stream));
         if (first == GSR_LISTS_SKIPPED_STAMP) return GSR_ERR_INVALID_ARG;
     }
-    GSR_HIP_TRY(hipMemsetAsync(a->dL_dmean2D, 0, sizeof(float) * 2 * (size_t)n, stream));
-    GSR_HIP_TRY(hipMemsetAsync(a->dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)n, stream));
-    GSR_HIP_TRY(hipMemsetAsync(a->dL_dcolors, 0, sizeof(float) * 3 * (size_t)n, stream));
+    // (with sums_f64 the float arrays are written once, by the kernel that rounds the double sums: no clearing)
+    const bool wide = a->sums_f64 != nullptr;
+    if (!wide || nothing_rendered) {
+        GSR_HIP_TRY(hipMemsetAsync(a->dL_dmean2D, 0, sizeof(float) * 2 * (size_t)n, stream));
+        GSR_HIP_TRY(hipMemsetAsync(a->dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)n, stream));
+        GSR_HIP_TRY(hipMemsetAsync(a->dL_dcolors, 0, sizeof(float) * 3 * (size_t)n, stream));
+        if (a->dL_dcov2D) GSR_HIP_TRY(hipMemsetAsync(a->dL_dcov2D, 0, sizeof(float) * 4 * (size_t)n, stream));
+    }
     if (nothing_rendered) {
         // R == 0: no Gaussian reached a pixel (the forward call left even the tile ranges unwritten, GSCuda.cu:775-778)
         if (a->dL_dcov3D) GSR_HIP_TRY(hipMemsetAsync(a->dL_dcov3D, 0, sizeof(float) * 6 * (size_t)n, stream));
@@ -808,6 +880,8 @@ static int backward_impl(gsr_backward_args* a) {
     r.dL_dmean2D = a->dL_dmean2D;
     r.dL_dconic_opacity = a->dL_dconic_opacity;
     r.dL_dcolors = a->dL_dcolors;
+    r.dL_dcov2D = a->dL_dcov2D;
+    r.sums64 = a->sums_f64;
     r.dims = d;
     r.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
     // (all blocks of the frame, also in a sharded call: the blocks outside the band were not walked)
@@ -821,12 +895,12 @@ static int backward_impl(gsr_backward_args* a) {
         GSR_LAUNCH_CHECK("render_backward_kernel");
         if (from_blocks && feed.acc) {
             hipLaunchKernelGGL(flush_block_acc_kernel, dim3(acc_wgs), dim3(256), 0, stream, feed, a->dL_dmean2D, a->dL_dconic_opacity,
-                               a->dL_dcolors);
+                               a->dL_dcolors, a->dL_dcov2D, a->sums_f64);
             GSR_LAUNCH_CHECK("flush_block_acc_kernel");
         }
     }
     if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[1], stream));
-    if (a->dL_dcov3D) {
+    if (a->dL_dcov3D || wide) {
         PreprocessBackwardParams q;
         q.n = n;
         q.means3D = reinterpret_cast<const float4*>(a->means3D);
@@ -836,6 +910,12 @@ static int backward_impl(gsr_backward_args* a) {
         q.tan_fovx = a->tan_fovx; q.tan_fovy = a->tan_fovy;
         q.focal = (float)a->height / (2.0f * a->tan_fovy);
         q.dL_dconic_opacity = reinterpret_cast<const float4*>(a->dL_dconic_opacity);
+        q.dL_dcov2D = reinterpret_cast<const float4*>(a->dL_dcov2D);
+        q.sums64 = a->sums_f64;
+        q.out_mean2D = reinterpret_cast<float2*>(a->dL_dmean2D);
+        q.out_conic_opacity = reinterpret_cast<float4*>(a->dL_dconic_opacity);
+        q.out_colors = a->dL_dcolors;
+        q.out_cov2D = reinterpret_cast<float4*>(a->dL_dcov2D);
         q.dL_dcolors = a->dL_dcolors;
         q.dL_dcov3D = a->dL_dcov3D;
         q.dL_dshs = a->dL_dshs;

@@ -92,7 +92,9 @@ __device__ __forceinline__ float exp_ref(float x, const unsigned long long* tab)
     constexpr double kN = 32.0, kInvLn2N = 0x1.71547652b82fep+0 * kN, kShift = 0x1.8p+52;
     constexpr double kC0 = 0x1.c6af84b912394p-5 / kN / kN / kN, kC1 = 0x1.ebfce50fac4f3p-3 / kN / kN, kC2 = 0x1.62e42ff0c52d6p-1 / kN;
     // (below -104 the result is 0, as glibc's underflow path returns: exp(-104) already rounds to it)
-    const double z = kInvLn2N * (double)fmaxf(x, -104.0f);
+    float xc;
+    asm("v_max_f32 %0, %1, %2" : "=v"(xc) : "v"(x), "s"(-104.0f));       // (fmaxf would canonicalise x first: one more issue)
+    const double z = kInvLn2N * (double)xc;
     double kd = z + kShift;
     const uint32_t ki = (uint32_t)__double_as_longlong(kd);         // k: its low bits pick the table entry, the rest is the exponent
     kd -= kShift;
@@ -222,8 +224,8 @@ __device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_x
             // (finished pixels: their dy is NaN, and so is their power — they are no candidates)
             const f32x2 dy = pair == 0 ? dy01 : dy23;
             const f32x2 pw = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
-            // both strips' exponentials side by side (two independent chains of double operations: a deep tile's wave, alone on
-            // its SIMD at the end of the frame, waits for every result it cannot overlap)
+            // (the compiler sinks each into its strip's branch; forcing both up front, interleaved, measured slower on every
+            // frame: the loop is bound by instruction issue, not by the latency of the double chain)
             const float e0 = exp_ref(pw.x, exp_tab), e1 = exp_ref(pw.y, exp_tab);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -321,16 +323,18 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
         const float* c = f.colors + 3 * (size_t)b.id;
         s_xy[slot] = b.xy;
         // the filter's floor for this record, in units of log2: -ln(255 opacity) less the margins (1e-3 for the rounding of the
-        // exponential and the product; kFilterSlack for the filter's own evaluation of the power). Opacity <= 0: +inf, no
+        // exponential and the product, and the filter's own rounding). Opacity <= 0: +inf, no
         // candidate (alpha <= 0 fails the 1/255 test); NaN opacity: -inf (the reference's min(0.99, NaN) is 0.99: it counts).
+        // The filter's evaluation of the power differs from the reference's by the rounding of three terms that may cancel:
+        // a few 6e-8 of their magnitude, bounded here over the tile.
+        const float dxm = fmaxf(fabsf(b.xy.x - f.box.x_lo), fabsf(b.xy.x - f.box.x_hi)), dym = fmaxf(fabsf(b.xy.y - f.box.y_lo), fabsf(b.xy.y - f.box.y_hi));
+        const float terms = fabsf(b.co.x) * dxm * dxm + fabsf(b.co.z) * dym * dym + 2.0f * fabsf(b.co.y) * dxm * dym;
         const float p0 = -__logf(255.0f * b.co.w);
-        const float floor2 = b.co.w != b.co.w ? -__builtin_inff() : (b.co.w <= 0.0f ? __builtin_inff() : (p0 - 1e-3f - kFilterSlack) * kLog2e);
+        const float floor2 = b.co.w != b.co.w ? -__builtin_inff() : (b.co.w <= 0.0f ? __builtin_inff() : (p0 - 1e-3f - 1e-6f * terms) * kLog2e);
         // The filter's slack covers the rounding of power terms up to 4e6 (kFilterSlack / 6e-8). A record whose terms can be
         // larger somewhere on the tile — a screen-filling needle seen along its axis at 4K: conic entries up to 3.3, |d| in the
         // thousands — gets a zero filter conic and no floor: its filter value is 0 for every unfinished pixel (NaN for the
         // finished ones, as always), all of them are candidates, and the reference-order evaluation decides alone.
-        const float dxm = fmaxf(fabsf(b.xy.x - f.box.x_lo), fabsf(b.xy.x - f.box.x_hi)), dym = fmaxf(fabsf(b.xy.y - f.box.y_lo), fabsf(b.xy.y - f.box.y_hi));
-        const float terms = fabsf(b.co.x) * dxm * dxm + fabsf(b.co.z) * dym * dym + 2.0f * fabsf(b.co.y) * dxm * dym;
         const bool filtered = terms < 1.0e6f;                                   // (NaN: not filtered)
         s_co[slot] = filtered ? make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, floor2)
                               : make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());

@@ -69,7 +69,8 @@ int launch_duplicate(int n, const uint32_t* sorted_depth, const uint32_t* sorted
                      uint64_t* keys, uint32_t* values, uint32_t* hist_x, uint32_t* hist_y, hipStream_t stream);
 
 int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in,
-                      uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word = nullptr);
+                      uint32_t* values_out, size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word = nullptr,
+                      uint32_t error_value = 1u);
 size_t sort_temp_bytes(size_t n);
 struct SweepScratch;
 // The depth order's side list (radix_sort.hip, depth_side_kernel): the visible keys whose top byte is not main_top, when

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
                                                             uint32_t n_host, const uint32_t* __restrict__ n_dev, const DigitSpec spec,
                                                             const uint32_t* __restrict__ digit_hist,
                                                             unsigned long long* status, uint32_t* ticket,
-                                                            uint32_t* error_word) {
+                                                            uint32_t* error_word, uint32_t error_value) {
     // n_dev (may be null): the key count lives on the device — the pass was queued before the host knew it, with a
     // grid sized for an upper bound; workgroups whose ticket lies beyond the last tile leave at once.
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
             const uint32_t used = lb.consume(lane);
             if (lb.found) break;
             if (used == 0) {
-                if (++lb.spins > kSpinLimit) { s_fail = 1; *reinterpret_cast<volatile uint32_t*>(error_word) = 1u; break; }      // (may be host memory)
+                if (++lb.spins > kSpinLimit) { s_fail = 1; *reinterpret_cast<volatile uint32_t*>(error_word) = error_value; break; }      // (may be host memory)
                 __builtin_amdgcn_s_sleep(1);
             }
             lb.issue(status);
@@ -391,7 +391,7 @@ int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, ui
     }
 #define GSR_SWEEP(B, SECOND)                                                                                          \
     hipLaunchKernelGGL((onesweep_kernel<KeyT, B, SECOND>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, \
-                       keys_out, vals_out, vals2_in, vals2_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word)
+                       keys_out, vals_out, vals2_in, vals2_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word, sc.error_value)
     if (vals2_in) {
         // a second value per key: the depth passes only (u32 keys, 256 bins)
         if constexpr (sizeof(KeyT) == 4) {
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __
         out[4] = 0u;
         if (host_top) {
             host_top[0] = (uint32_t)c;
-            if (side) host_top[8] = side[2];
+            if (side) { host_top[8] = side[2]; host_top[10] = side[1]; }     // (keys below the main top byte; keys the compaction PUT on the side list)
         }
     }
 }
@@ -748,6 +748,7 @@ int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n
         spec.mode = kDigitBits; spec.shift = 8 * p; spec.nbins = 256; spec.grid_x = 1; spec.inv_grid_x = 1.0f;
         SweepScratch sc = sc4[p];
         sc.error_word = sc4[0].error_word;
+        sc.error_value = sc4[0].error_value;
         const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev, src_s, dst_s);
         if (rc != GSR_OK) return rc;
     }
@@ -760,7 +761,7 @@ size_t sort_temp_bytes(size_t n) {
 }
 
 int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in, uint32_t* values_out,
-                      size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word) {
+                      size_t n, int begin_bit, int end_bit, char* temp, hipStream_t stream, uint32_t* error_word, uint32_t error_value) {
     if (n == 0) return GSR_OK;
     if (n >= 0xFFFFFFFFull) return GSR_ERR_TOO_LARGE;
     if (end_bit > 64) end_bit = 64;
@@ -770,7 +771,7 @@ int launch_sort_pairs(const uint64_t* keys_in, uint64_t* keys_out, const uint32_
     uint64_t* tmp_k = reinterpret_cast<uint64_t*>(temp);
     uint32_t* tmp_v = reinterpret_cast<uint32_t*>(temp + align_up(n * sizeof(uint64_t), 128));
     SweepScratch sc = carve_sweep_scratch(temp + align_up(n * sizeof(uint64_t), 128) + align_up(n * sizeof(uint32_t), 128), n);
-    if (error_word) sc.error_word = error_word;          // (the caller's word: gsr_forward hands in this call's slot of pinned host memory, zeroed at the top of the call)
+    if (error_word) { sc.error_word = error_word; sc.error_value = error_value; }          // (the caller's word: gsr_forward hands in this call's slot of pinned host memory, zeroed at the top of the call)
     else GSR_HIP_TRY(hipMemsetAsync(sc.error_word, 0, sizeof(uint32_t), stream));
     int rc = histogram_bits_u64(keys_in, n, begin_bit, end_bit, sc.hist, stream);
     if (rc != GSR_OK) return rc;

@@ -23,7 +23,8 @@ struct DigitSpec {
 struct SweepScratch {
     unsigned long long* status;   // tiles x radix look-back words
     uint32_t* ticket;
-    uint32_t* error_word;         // set to 1 if a bounded spin ever gave up
+    uint32_t* error_word;         // set to error_value if a bounded spin ever gave up
+    uint32_t error_value = 1u;    // (gsr_forward: the call's serial, so that a late writer of an OLDER call cannot raise the flag of the slot's new owner)
     uint32_t* hist;               // 8 x 256 digit counts
 };
 

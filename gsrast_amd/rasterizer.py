@@ -101,7 +101,7 @@ class SplatRasterizer:
         assert self.means3D.shape == (self.num_gaussians, 4) and self.scales.shape == (self.num_gaussians, 4)
         assert self.rotations.shape == (self.num_gaussians, 4) and self.shs.shape == (self.num_gaussians, 48)
         self.use_rects = use_rects
-        self._colors_dc = None                       # colours precomputed from the DC triples, on first use
+        self._colors_dc, self._colors_key = None, None   # colours precomputed from the DC triples, on first use, per SH tensor state
         self.rects = (torch.zeros((self.num_gaussians, 2), dtype=torch.int32, device=self.device)
                       if use_rects else None)
 
@@ -172,6 +172,8 @@ class SplatRasterizer:
         _capi.check(rc, "gsr_forward")
         self.last_receipt = a.receipt.copy()
         self.last_colors_precomp = bool(colors_precomp)
+        # which colours THIS call composited (backward() reads the same ones): tied to the call's receipt, not to "the last call"
+        self._colors_of_call = (int(a.receipt.serial), self._colors_dc if colors_precomp else None)
         self.last_num_rendered = int(a.num_rendered)
         self.last_records_staged = int(a.records_staged)
         self.last_plan = _capi.PLAN_NAMES[int(a.plan_used) & 0xFF]
@@ -186,13 +188,14 @@ class SplatRasterizer:
 
     def precomputed_colors(self) -> torch.Tensor:
         """vec3[N] = 0.5 + 0.4 DC (gsr_colors_from_dc), computed on first use and kept for the scene."""
-        if self._colors_dc is None:
+        key = (self.shs.data_ptr(), self.shs._version)          # (callers may replace or write rast.shs between frames)
+        if self._colors_dc is None or self._colors_key != key:
             c = torch.empty((self.num_gaussians, 3), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 rc = self.lib.gsr_colors_from_dc(self.num_gaussians, self.shs.data_ptr(), c.data_ptr(),
                                                  torch.cuda.current_stream(self.device).cuda_stream)
             _capi.check(rc, "gsr_colors_from_dc")
-            self._colors_dc = c
+            self._colors_dc, self._colors_key = c, key
         return self._colors_dc
 
     def poll_async_error(self, receipt: "_capi.ForwardReceipt | None" = None) -> None:
@@ -237,14 +240,16 @@ class SplatRasterizer:
     # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
     def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
                  tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0, semantics: str = "gscuda",
-                 sh_degree: int = 3, receipt: "_capi.ForwardReceipt | None | bool" = None) -> dict:
+                 sh_degree: int = 3, receipt: "_capi.ForwardReceipt | None | bool" = None, wide_sums: bool = True) -> dict:
         """Gradients of sum(dL_dout * out_color) of the LAST draw() through gsr_backward; `semantics` / `sh_degree`
         must be those of that draw(). receipt: the gsr_forward_receipt of the draw() this is the backward of (default:
         this object's last draw(); any host thread may call); False = none, the reference's contract only (sorted lists
         in the binning chunk — refused after a draw(sorted_lists=False)). Returns device tensors dL_dmean2D [N,2], dL_dconic_opacity [N,4], dL_dcolors [N,3]
-        and, with with_cov3D, dL_dcov3D [N,6], dL_dshs [N,48] (gscuda: the DC triple only; inria: every coefficient
+        and, with with_cov3D, dL_dcov2D [N,4] (m00, m01, m11, 0), dL_dcov3D [N,6], dL_dshs [N,48] (gscuda: the DC triple only; inria: every coefficient
         up to sh_degree), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
-        The tensors are owned by this object and overwritten by the next call."""
+        wide_sums: accumulate the per-Gaussian sums in double (gsr_backward_args.sums_f64: 96 N bytes of scratch kept by this
+        object, zero between calls) — the gradients of screen-filling splats then no longer depend on the order in which the
+        tiles' atomics arrive. The tensors are owned by this object and overwritten by the next call."""
         assert semantics in ("gscuda", "inria")
         n, dev = self.num_gaussians, self.device
         g = dL_dout.to(device=dev, dtype=torch.float32).contiguous()
@@ -265,6 +270,7 @@ class SplatRasterizer:
                      "dL_dconic_opacity": torch.empty((n, 4), dtype=torch.float32, device=dev),
                      "dL_dcolors": torch.empty((n, 3), dtype=torch.float32, device=dev)}
             if with_cov3D:
+                cache["dL_dcov2D"] = torch.empty((n, 4), dtype=torch.float32, device=dev)     # (m00, m01, m11, 0): what the chain starts from
                 cache["dL_dcov3D"] = torch.empty((n, 6), dtype=torch.float32, device=dev)
                 cache["dL_dshs"] = torch.zeros((n, 48), dtype=torch.float32, device=dev)
                 for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
@@ -279,7 +285,10 @@ class SplatRasterizer:
         a.num_gaussians, a.width, a.height = n, self.width, self.height
         a.background = self.background.data_ptr()
         a.means2D, a.conic_opacity, a.cov3D = gst.means2D, gst.conic_opacity, gst.cov3D
-        a.colors = self._colors_dc.data_ptr() if getattr(self, "last_colors_precomp", False) else gst.rgb
+        serial, col = getattr(self, "_colors_of_call", (None, None))
+        if rcpt is not None and int(rcpt.serial) != serial:
+            col = None                               # a receipt of another call: that call's colours are its geomState.rgb
+        a.colors = col.data_ptr() if col is not None else gst.rgb
         a.radii = gst.internal_radii
         a.ranges, a.n_contrib, a.final_t = ist.ranges, ist.n_contrib, ist.accum_alpha
         a.point_list = bst.values
@@ -289,6 +298,11 @@ class SplatRasterizer:
         a.dL_dmean2D, a.dL_dconic_opacity = out["dL_dmean2D"].data_ptr(), out["dL_dconic_opacity"].data_ptr()
         a.dL_dcolors = out["dL_dcolors"].data_ptr()
         a.dL_dcov3D = out["dL_dcov3D"].data_ptr() if with_cov3D else None
+        a.dL_dcov2D = out["dL_dcov2D"].data_ptr() if with_cov3D else None
+        if wide_sums:
+            if getattr(self, "_sums_f64", None) is None or self._sums_f64.shape[0] != n:
+                self._sums_f64 = torch.zeros((n, 12), dtype=torch.float64, device=dev)      # (the library leaves it zero)
+            a.sums_f64 = self._sums_f64.data_ptr()
         a.dL_dshs = out["dL_dshs"].data_ptr() if with_cov3D else None
         if with_cov3D:
             a.proj_matrix, a.scales, a.rotations = self._proj.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr()

@@ -113,6 +113,8 @@ class RowBandExchange:
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.root = root
         self.bounds = uniform_bands(self.grid_y, self.world)
         self._ops_key, self._ops = None, []
@@ -122,7 +124,8 @@ class RowBandExchange:
         self.transport_note = ""
         want = os.environ.get("GSR_EXCHANGE", transport)
         assert want in ("auto", "torch", "rccl"), want
-        if want != "torch" and self.world > 1 and self.device.type == "cuda" and dist.get_backend() == "nccl":
+        # (composite backend strings — "cuda:nccl,cpu:gloo" — name nccl too)
+        if want != "torch" and self.world > 1 and self.device.type == "cuda" and "nccl" in str(dist.get_backend()):
             self._try_rccl(must=want == "rccl")
 
     # -- the library's own communicator -------------------------------------------------------------------------------
@@ -231,6 +234,8 @@ class RowBandExchange:
         ranks' bands have been received in place (on every rank, or on `root` only). The transfers are enqueued on the
         current stream for RCCL; the call returns once they are enqueued."""
         assert frame.is_contiguous() and tuple(frame.shape) == (3, self.height, self.width)
+        # (gsr_exchange_bands moves float32 words of a buffer on this rank's device: anything else would move the wrong bytes)
+        assert frame.dtype == torch.float32 and frame.device == self.device, (frame.dtype, frame.device, self.device)
         if self.world == 1:
             return frame
         if self._handle is not None:

@@ -34,7 +34,8 @@ enum {
     GSR_ERR_NO_DEVICE = 4,     /* no gfx950 device visible                                 */
     GSR_ERR_TOO_LARGE = 5,     /* sum of tiles touched >= 2^32 - 1: does not fit the reference's u32 offsets (checked
                                   on the un-wrapped 64-bit total before the binning chunk is requested) */
-    GSR_ERR_INTERNAL = 6       /* a bounded device-side wait expired (see gsr_poll_async_error) */
+    GSR_ERR_INTERNAL = 6,      /* a bounded device-side wait expired (see gsr_poll_async_error) */
+    GSR_ERR_STALE_RECEIPT = 7  /* gsr_poll_async_error: the receipt's error slot belongs to a later call (64 calls on): unknown */
 };
 
 /* Chunk allocator: replaces std::function<char*(size_t)> (GSCuda.cuh:103-105). Must
@@ -153,8 +154,9 @@ typedef struct gsr_forward_receipt {
     char*    geometry_chunk;       /* what the three allocator callbacks returned (binning: NULL if R == 0) */
     char*    image_chunk;
     char*    binning_chunk;
-    const volatile uint32_t* async_words;   /* host memory (pinned, never freed): {N-sized sort gave up, R-sized sort gave up,
-                                               serial of the call that owns the words, 0} — see gsr_poll_async_error */
+    const volatile uint32_t* async_words;   /* host memory (pinned, never freed): {N-sized sort gave up, R-sized sort gave up
+                                               (each: 0, or the serial of the call whose kernel gave up), serial of the call
+                                               that owns the words, 0} — see gsr_poll_async_error */
 } gsr_forward_receipt;
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
@@ -219,8 +221,9 @@ const char* gsr_last_hip_error(void);
  * GSR_ERR_INTERNAL if a radix-sort look-back wait expired during that call (the frame is then invalid). Mirrors the
  * reference caller polling the sticky error after its sync (CudaBuffer.hpp:8-12). Any thread may ask. The words a call
  * reports into are one of 64 slots per host thread and device, handed out in turn: asked about a call that lies more
- * than 63 calls back the answer is GSR_OK (its slot has a new owner; nothing is known any more). NULL or a receipt
- * without the magic: GSR_ERR_INVALID_ARG. */
+ * than 63 calls back the answer is GSR_ERR_STALE_RECEIPT (its slot has a new owner; nothing is known any more). A kernel
+ * that gives up writes its own call's serial, so a call still running on another stream when its slot comes round again
+ * cannot raise the new owner's flag. NULL or a receipt without the magic: GSR_ERR_INVALID_ARG. */
 int gsr_poll_async_error(const gsr_forward_receipt* receipt);
 
 /* getHigherMsb (GSCuda.cu:481-502): bits of the tile id that take part in the sort. */
@@ -263,6 +266,7 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
  *   dL_dmean2D        vec2[N]  w.r.t. the pixel-space centre (no NDC factor)
  *   dL_dconic_opacity vec4[N]  w.r.t. (A, B, C) of power = -0.5 (A dx^2 + C dy^2) - B dx dy, and opacity
  *   dL_dcolors        vec3[N]
+ *   dL_dcov2D         vec4[N]  w.r.t. the 2-D covariance, (m00, m01, m11, 0) (optional; what the chain below should start from)
  *   dL_dcov3D         f32[6N]  w.r.t. the six stored covariance numbers (optional: NULL skips the chain)
  *   dL_dshs           f32[48N] colour = 0.5 + 0.4 DC: the DC triple of every Gaussian, = 0.4 dL_dcolors, and zeros in the 13
  *                              floats behind it (one whole 64-byte write per Gaussian; floats 16..47 are not touched);
@@ -303,6 +307,16 @@ typedef struct gsr_backward_args {
     float* dL_dcolors;
     float* dL_dcov3D;              /* or NULL */
     float* dL_dshs;                /* or NULL */
+    float* dL_dcov2D;              /* vec4[N] (m00, m01, m11, 0): w.r.t. the full symmetric 2-D covariance (a, b; b, c) of
+                                      GSCuda.cu:226-230, summed pixel by pixel by the render backward; or NULL. The chain to
+                                      dL_dcov3D and beyond starts from it when given — without it the chain derives it as
+                                      -K (dL/dK) K from dL_dconic_opacity, which loses cond(K)^2 of the sums' digits (a splat
+                                      that fills the screen: 1e6) */
+    double* sums_f64;              /* f64[12 N] scratch or NULL. ZERO on entry, left zero on return. With it the twelve sums of a
+                                      Gaussian (the four arrays above) are accumulated in double — a splat that fills the screen
+                                      collects terms of either sign from 8 160 tiles, and in float their order of arrival shows
+                                      in the fourth digit of its gradients, differently every run — and rounded to float once;
+                                      the float arrays need not be cleared by anybody then */
     /* chain down to the inputs (all optional; need dL_dcov3D) */
     const float* proj_matrix;      /* inputs of the forward call */
     const float* scales;

@@ -112,15 +112,21 @@ def blend_backward(means2D, conic_opacity, colors, ranges, point_list, n_contrib
     return {"dL_dmean2D": d_mean, "dL_dconic": d_conic, "dL_dopacity": d_op, "dL_dcolor": d_col}
 
 
-def blend_tile_backward(xy, co, col, tx, ty, width, height, background, dL_dout_tile, t_cutoff=0.001):
+def blend_tile_backward(xy, co, col, tx, ty, width, height, background, dL_dout_tile, t_cutoff=0.001, f32_forward=False):
     """One 16 x 16 tile, vectorised [L records x 256 pixels], float64: the forward loop of `blend_forward` and the
     gradients of `blend_backward` restricted to this tile's pixels. Used at frame sizes where the per-pixel
     Python loops above would take hours; tests/test_backward_oracle.py checks it against them.
 
     xy [L,2], co [L,4], col [L,3]: the records of the tile's list, front to back (a prefix that reaches the last
     contributor of every pixel is enough). dL_dout_tile [3,16,16] (entries outside the image are ignored).
-    Returns dict: per-record sums d_mean [L,2], d_conic [L,3], d_op [L], d_col [L,3]; per pixel out [3,16,16],
-    final_t [16,16], n_contrib [16,16] (pixels outside the image: 0)."""
+    Returns dict: per-record sums d_mean [L,2], d_conic [L,3], d_cov [L,3] (w.r.t. the full symmetric 2-D covariance: m00, m01,
+    m11 — every pixel's share of dL/dK is -0.5 dLp d d^T, so its share of -K (dL/dK) K is 0.5 dLp u u^T with u = K d),
+    d_op [L], d_col [L,3]; per pixel out [3,16,16],
+    final_t [16,16], n_contrib [16,16] (pixels outside the image: 0).
+    f32_forward: power, exp (libm's expf), alpha and the transmittance product are evaluated in float32 in the forward's
+    operation order (GSCuda.cu:634-657) — the function the HIP backward differentiates, decisions included: with terms of
+    1e3 in the power of a screen-filling splat a float64 forward is another function at the 1e-4 level — and the gradient
+    sums over them in float64: what remains against the HIP backward is the backward's own arithmetic."""
     xy = np.asarray(xy, np.float64).reshape(-1, 2)
     co = np.asarray(co, np.float64).reshape(-1, 4)
     col = np.asarray(col, np.float64).reshape(-1, 3)
@@ -133,20 +139,34 @@ def blend_tile_backward(xy, co, col, tx, ty, width, height, background, dL_dout_
     gp = np.asarray(dL_dout_tile, np.float64).reshape(3, -1) * inside[None, :]
     if L == 0:
         out = np.where(inside[None, :], bg[:, None], 0.0)
-        return {"d_mean": np.zeros((0, 2)), "d_conic": np.zeros((0, 3)), "d_op": np.zeros(0), "d_col": np.zeros((0, 3)),
+        return {"d_mean": np.zeros((0, 2)), "d_conic": np.zeros((0, 3)), "d_cov": np.zeros((0, 3)), "d_op": np.zeros(0), "d_col": np.zeros((0, 3)),
                 "out": out.reshape(3, TILE, TILE), "final_t": inside.astype(np.float64).reshape(TILE, TILE),
                 "n_contrib": np.zeros((TILE, TILE), np.int64)}
     dx = xy[:, 0:1] - px[None, :]
     dy = xy[:, 1:2] - py[None, :]
     A, B, Cc, op = co[:, 0:1], co[:, 1:2], co[:, 2:3], co[:, 3:4]
-    power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
-    with np.errstate(over="ignore"):
-        G = np.exp(np.minimum(power, 0.0))
-    raw = op * G
-    alpha = np.minimum(0.99, raw)
-    valid = (power <= 0.0) & (alpha >= 1.0 / 255.0) & inside[None, :]
-    a_eff = np.where(valid, alpha, 0.0)
-    t_after = np.cumprod(1.0 - a_eff, axis=0)                       # transmittance behind record k (no termination yet)
+    if f32_forward:
+        from oracle import cpu_oracle
+        f = np.float32
+        dx32, dy32 = f(xy[:, 0:1]) - f(px[None, :]), f(xy[:, 1:2]) - f(py[None, :])
+        A32, B32, C32, op32 = f(A), f(B), f(Cc), f(op)
+        power = f(-0.5) * ((A32 * dx32) * dx32 + (C32 * dy32) * dy32) - (B32 * dx32) * dy32
+        G = cpu_oracle.expf(np.minimum(power, f(0.0))).reshape(power.shape)
+        raw = op32 * G
+        alpha = np.minimum(f(0.99), raw)
+        valid = (power <= 0.0) & (alpha >= f(1.0 / 255.0)) & inside[None, :]
+        a_eff = np.where(valid, alpha, f(0.0))
+        t_after = np.cumprod(f(1.0) - a_eff, axis=0, dtype=np.float32).astype(np.float64)
+        power, G, raw, alpha, a_eff = (v.astype(np.float64) for v in (power, G, raw, alpha, a_eff))
+    else:
+        power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+        with np.errstate(over="ignore"):
+            G = np.exp(np.minimum(power, 0.0))
+        raw = op * G
+        alpha = np.minimum(0.99, raw)
+        valid = (power <= 0.0) & (alpha >= 1.0 / 255.0) & inside[None, :]
+        a_eff = np.where(valid, alpha, 0.0)
+        t_after = np.cumprod(1.0 - a_eff, axis=0)                   # transmittance behind record k (no termination yet)
     t_before = np.vstack([np.ones((1, px.size)), t_after[:-1]])
     stop = valid & (t_after < t_cutoff)                             # GSCuda.cu:653: this record ends the pixel
     has_stop = stop.any(axis=0)
@@ -169,7 +189,9 @@ def blend_tile_backward(xy, co, col, tx, ty, width, height, background, dL_dout_
     dLp = op * G * dLa
     d_conic = np.stack([(-0.5 * dx * dx * dLp).sum(1), (-dx * dy * dLp).sum(1), (-0.5 * dy * dy * dLp).sum(1)], 1)
     d_mean = np.stack([((-A * dx - B * dy) * dLp).sum(1), ((-Cc * dy - B * dx) * dLp).sum(1)], 1)
-    return {"d_mean": d_mean, "d_conic": d_conic, "d_op": d_op, "d_col": d_col,
+    ux, uy = A * dx + B * dy, B * dx + Cc * dy
+    d_cov = np.stack([(0.5 * ux * ux * dLp).sum(1), (0.5 * ux * uy * dLp).sum(1), (0.5 * uy * uy * dLp).sum(1)], 1)
+    return {"d_mean": d_mean, "d_conic": d_conic, "d_cov": d_cov, "d_op": d_op, "d_col": d_col,
             "out": np.where(inside[None, :], out, 0.0).reshape(3, TILE, TILE),
             "final_t": np.where(inside, final_t, 0.0).reshape(TILE, TILE), "n_contrib": n_contrib.reshape(TILE, TILE)}
 
@@ -203,16 +225,23 @@ def cov2d_conic(c3, mean3, view, focal, tan_fovx, tan_fovy):
     return np.array([c / det, -b / det, a / det])
 
 
-def conic_backward(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic):
-    """dL/d(6 covariance numbers) from dL/d(A, B, C)."""
+def _gcov(K, dL_dconic, dL_dcov2D):
+    """Gradient w.r.t. the full symmetric cov2D: given directly as (m00, m01, m11), or -K gK K from dL/d(A, B, C)."""
+    if dL_dcov2D is not None:
+        m00, m01, m11 = (float(v) for v in dL_dcov2D[:3])
+        return np.array([[m00, m01], [m01, m11]])
+    gA, gB, gC = dL_dconic
+    return -K @ np.array([[gA, 0.5 * gB], [0.5 * gB, gC]]) @ K        # d(M^-1) = -M^-1 dM M^-1
+
+
+def conic_backward(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic, dL_dcov2D=None):
+    """dL/d(6 covariance numbers) from dL/d(A, B, C) — or from dL/dcov2D (m00, m01, m11) when that is given."""
     P = _jw(mean3, view, focal, tan_fovx, tan_fovy)
     cov = P @ _sigma(c3) @ P.T
     a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
     det = a * c - b * b
     K = np.array([[c, -b], [-b, a]]) / det
-    gA, gB, gC = dL_dconic
-    gK = np.array([[gA, 0.5 * gB], [0.5 * gB, gC]])        # gradient w.r.t. the full symmetric matrix entries
-    gM = -K @ gK @ K                                        # d(M^-1) = -M^-1 dM M^-1
+    gM = _gcov(K, dL_dconic, dL_dcov2D)
     gS = P.T @ gM @ P                                       # w.r.t. the full 3 x 3 Sigma entries
     return np.array([gS[0, 0], 2.0 * gS[0, 1], 2.0 * gS[0, 2], gS[1, 1], 2.0 * gS[1, 2], gS[2, 2]])
 
@@ -294,7 +323,7 @@ def cov3d_backward(scale, rot, mod, g6):
     return g_scale, (gq_hat - qh * (qh @ gq_hat)) / n
 
 
-def conic_backward_mean(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic):
+def conic_backward_mean(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic, dL_dcov2D=None):
     """dL/dmean3 through the dependence of cov2D on the view-space position t (the Jacobian J)."""
     v = np.asarray(view, np.float64)
     t = np.array([v[0] * mean3[0] + v[4] * mean3[1] + v[8] * mean3[2] + v[12],
@@ -311,8 +340,7 @@ def conic_backward_mean(c3, mean3, view, focal, tan_fovx, tan_fovy, dL_dconic):
     a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
     det = a * c - b * b
     K = np.array([[c, -b], [-b, a]]) / det
-    gA, gB, gC = dL_dconic
-    gcov = -K @ np.array([[gA, 0.5 * gB], [0.5 * gB, gC]]) @ K
+    gcov = _gcov(K, dL_dconic, dL_dcov2D)
     gJ = 2.0 * gcov @ J @ Mw
     g_tx = gJ[0, 2] * (-focal / (tz * tz))
     g_ty = gJ[1, 2] * (-focal / (tz * tz))
@@ -441,7 +469,7 @@ def inria_cov2d_conic(c3, mean3, view, fx, fy, tan_fovx, tan_fovy):
     return np.array([c / det, -b / det, a / det])
 
 
-def inria_conic_backward(c3, mean3, view, fx, fy, tan_fovx, tan_fovy, dL_dconic):
+def inria_conic_backward(c3, mean3, view, fx, fy, tan_fovx, tan_fovy, dL_dconic, dL_dcov2D=None):
     """(dL/d(6 covariance numbers), dL/dmean3 through the Jacobian's dependence on the view-space position)."""
     J, W, (tx, ty, tz), (clx, cly, cx, cy) = _inria_jw(mean3, view, fx, fy, tan_fovx, tan_fovy)
     P = J @ W
@@ -450,8 +478,7 @@ def inria_conic_backward(c3, mean3, view, fx, fy, tan_fovx, tan_fovy, dL_dconic)
     a, b, c = cov[0, 0] + 0.3, cov[0, 1], cov[1, 1] + 0.3
     det = a * c - b * b
     K = np.array([[c, -b], [-b, a]]) / det
-    gA, gB, gC = dL_dconic
-    gcov = -K @ np.array([[gA, 0.5 * gB], [0.5 * gB, gC]]) @ K
+    gcov = _gcov(K, dL_dconic, dL_dcov2D)
     gS = P.T @ gcov @ P
     g6 = np.array([gS[0, 0], 2.0 * gS[0, 1], 2.0 * gS[0, 2], gS[1, 1], 2.0 * gS[1, 2], gS[2, 2]])
     gJ = 2.0 * gcov @ J @ Mw

@@ -15,6 +15,7 @@ r = SplatRasterizer(W, H); r.configure_from_scene(sc)
 r.draw(cam)
 rg = r.map_image_state()["ranges"].to(torch.int64)
 row_cost = (rg[:, 1] - rg[:, 0]).clamp(min=0).view(gy, gx).sum(1).cpu().numpy().astype(np.float64)
+proj = {"uniform_ms": {}, "recut_ms": {}}
 print("#", label, f"{W}x{H}; {gy} tile rows; times in ms; 'uniform' = even split of the tile rows, 'recut' = split by instances per tile row")
 for world in (1, 2, 4, 8):
     for kind in (("uniform",) if world == 1 else ("uniform", "recut")):
@@ -30,3 +31,13 @@ for world in (1, 2, 4, 8):
             worst = max(worst, dt)
             print(f"ranks={world} {kind} band={rows} R={r.last_num_rendered} plan={r.last_plan} frame={dt:.3f}", {k: round(v, 3) for k, v in r.last_stage_ms.items() if v})
         print(f"ranks={world} {kind}: slowest band {worst:.3f} ms (+ one exchange of the row bands per frame)")
+        proj[kind + "_ms"][str(world)] = round(worst, 4)
+        if world == 1:
+            proj["recut_ms"]["1"] = round(worst, 4)
+# what bench.py reports as config.projected_ms beside a measured N-GPU number (profiles/band_projection.json, keyed by resolution)
+import json
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "band_projection.json")
+allp = json.load(open(path)) if os.path.exists(path) else {}
+allp[f"{W}x{H}"] = proj
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(allp, open(path, "w"), indent=1)

@@ -124,6 +124,13 @@ def test_vectorised_tile_backward_matches_the_per_pixel_loops():
                 np.add.at(acc["dL_dconic"], ids, r["d_conic"])
                 np.add.at(acc["dL_dopacity"], ids, r["d_op"])
                 np.add.at(acc["dL_dcolor"], ids, r["d_col"])
+                # the gradient w.r.t. the 2-D covariance, summed pixel by pixel as 0.5 dLp u u^T (what the HIP render backward
+                # does), is -K (dL/dK) K of the summed conic gradient, K the conic as a full symmetric matrix
+                for j in range(len(ids)):
+                    K = np.array([[co[ids[j], 0], co[ids[j], 1]], [co[ids[j], 1], co[ids[j], 2]]])
+                    gK = np.array([[r["d_conic"][j, 0], 0.5 * r["d_conic"][j, 1]], [0.5 * r["d_conic"][j, 1], r["d_conic"][j, 2]]])
+                    m = -K @ gK @ K
+                    assert np.abs(r["d_cov"][j] - np.array([m[0, 0], m[0, 1], m[1, 1]])).max() <= 1e-9 * max(1e-6, np.abs(m).max()), (tx, ty, j)
                 assert np.abs(r["out"][:, : y1 - ty * 16, : x1 - tx * 16] - out[:, ty * 16:y1, tx * 16:x1]).max() <= 1e-12
                 assert np.array_equal(r["n_contrib"][: y1 - ty * 16, : x1 - tx * 16], nc[ty * 16:y1, tx * 16:x1])
                 assert np.abs(r["final_t"][: y1 - ty * 16, : x1 - tx * 16] - ft[ty * 16:y1, tx * 16:x1]).max() <= 1e-12

@@ -138,14 +138,21 @@ def test_poll_async_error_wants_a_receipt():
     L = _capi.lib()
     assert L.gsr_poll_async_error(None) == _capi.GSR_ERR_INVALID_ARG
     assert L.gsr_poll_async_error(C.byref(_capi.ForwardReceipt())) == _capi.GSR_ERR_INVALID_ARG
-    # a receipt whose slot has a new owner (other serial) says nothing: GSR_OK; the owner's words are reported
-    words = (C.c_uint32 * 4)(1, 0, 7, 0)
+    # a kernel that gives up writes its call's serial: words {N-sized sort, R-sized sort, owner, 0}
+    words = (C.c_uint32 * 4)(7, 0, 7, 0)
     r = _capi.ForwardReceipt()
     r.magic, r.serial, r.async_words = _capi.GSR_RECEIPT_MAGIC, 6, C.addressof(words)
-    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_OK
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_ERR_STALE_RECEIPT      # the slot has a new owner: unknown, said so
     r.serial = 7
     assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_ERR_INTERNAL
-    words[0] = 0
+    words[0] = 6                                                                  # a late writer of the slot's PREVIOUS owner
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_OK                     # ... does not raise the new owner's flag
+    r.serial = 6
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_ERR_INTERNAL           # ... and is still reported to whoever holds its receipt
+    words[0], words[1] = 0, 7
+    r.serial = 7
+    assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_ERR_INTERNAL
+    words[1] = 0
     assert L.gsr_poll_async_error(C.byref(r)) == _capi.GSR_OK
 
 

@@ -336,7 +336,7 @@ def test_backward_without_a_fitting_receipt_is_refused_never_garbage():
         with pytest.raises(_capi.GsrError) as e:
             ra.backward(dl, with_cov3D=False, receipt=bad)
         assert e.value.code == _capi.GSR_ERR_INVALID_ARG, field
-    # polling: NULL and a receipt without the magic are refused; a valid one is answered from any call distance
+    # polling: NULL and a receipt without the magic are refused; a receipt whose slot has been handed on says so
     L = _capi.lib()
     assert L.gsr_poll_async_error(None) == _capi.GSR_ERR_INVALID_ARG
     assert L.gsr_poll_async_error(C.byref(_capi.ForwardReceipt())) == _capi.GSR_ERR_INVALID_ARG
@@ -344,7 +344,7 @@ def test_backward_without_a_fitting_receipt_is_refused_never_garbage():
     for _ in range(70):                               # more calls than there are error-word slots
         ra.draw(cam_a, plan="blocks", sync=False)
     torch.cuda.synchronize()
-    assert L.gsr_poll_async_error(C.byref(old)) == _capi.GSR_OK
+    assert L.gsr_poll_async_error(C.byref(old)) == _capi.GSR_ERR_STALE_RECEIPT    # (64 slots: nothing is known about that call any more)
     assert L.gsr_poll_async_error(C.byref(ra.last_receipt)) == _capi.GSR_OK
     assert ra.last_receipt.serial >= old.serial + 70       # (the serial counts every call of this thread on this device)
 

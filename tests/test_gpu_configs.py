@@ -220,10 +220,12 @@ def _tile_rects(means2D, ext, gx, gy):
     return x0, y0, x1, y1
 
 
-def _oracle_gradients(r, dL, bg, tiles, targets, max_depth):
+def _oracle_gradients(r, dL, bg, tiles, targets, max_depth, bad_pixels=None, f32_forward=False):
     """Float64 gradients (oracle/backward_np.blend_tile_backward) of the Gaussians `targets`, summed over `tiles`
     (which must contain every tile those Gaussians touch). Returns (dict of [len(targets), d] arrays, pixels whose
-    last contributor differs from the GPU's)."""
+    last contributor differs from the GPU's). bad_pixels (a list, optional): receives (y, x) of every pixel on which the
+    float64 forward and the GPU's float32 forward disagree — another last contributor, or another transmittance (a record
+    at alpha = 1/255 taken by one of them only)."""
     import torch
     from oracle import backward_np as B
     W, H = r.width, r.height
@@ -232,9 +234,10 @@ def _oracle_gradients(r, dL, bg, tiles, targets, max_depth):
     ranges = r.map_image_state()["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
     ncontrib = r.map_image_state()["nContrib"]
     plist = r.map_binning_state()["values"]
+    final_t = r.map_image_state()["finalT"]
     row_of = np.full(r.num_gaussians, -1, np.int64)
     row_of[targets] = np.arange(len(targets))
-    sums = {"dL_dmean2D": np.zeros((len(targets), 2)), "dL_dconic": np.zeros((len(targets), 3)),
+    sums = {"dL_dmean2D": np.zeros((len(targets), 2)), "dL_dconic": np.zeros((len(targets), 3)), "dL_dcov2D": np.zeros((len(targets), 3)),
             "dL_dopacity": np.zeros((len(targets), 1)), "dL_dcolors": np.zeros((len(targets), 3))}
     mismatch = 0
     for tx, ty in tiles:
@@ -248,15 +251,21 @@ def _oracle_gradients(r, dL, bg, tiles, targets, max_depth):
         tile_g = np.zeros((3, 16, 16))
         tile_g[:, : yb - ya, : xb - xa] = dL[:, ya:yb, xa:xb].cpu().numpy()
         res = B.blend_tile_backward(geo["means2D"][ids].cpu().numpy(), geo["conicOpacity"][ids].cpu().numpy(),
-                                    geo["rgb"][ids].cpu().numpy(), tx, ty, W, H, bg, tile_g)
-        bad = int((res["n_contrib"][: yb - ya, : xb - xa] != nc_tile.cpu().numpy()).sum())
+                                    geo["rgb"][ids].cpu().numpy(), tx, ty, W, H, bg, tile_g, f32_forward=f32_forward)
+        differs = res["n_contrib"][: yb - ya, : xb - xa] != nc_tile.cpu().numpy()
+        bad = int(differs.sum())
         mismatch += bad
+        if bad_pixels is not None:
+            ft = final_t[ya:yb, xa:xb].cpu().numpy().astype(np.float64)
+            differs = differs | (np.abs(res["final_t"][: yb - ya, : xb - xa] - ft) > 1e-5 + 1e-3 * ft)
+            bad_pixels.extend((ya + int(y), xa + int(x)) for y, x in zip(*np.nonzero(differs)))
         if bad == 0:       # float32 chain of up to 10 000 records against float64: sanity only (parity is the C++ oracle's job)
-            assert np.abs(res["out"][:, : yb - ya, : xb - xa] - r.out_color[:, ya:yb, xa:xb].cpu().numpy()).max() <= 1e-3
+            assert np.abs(res["out"][:, : yb - ya, : xb - xa] - r.out_color[:, ya:yb, xa:xb].cpu().numpy()).max() <= 3e-3
         rows = row_of[ids.cpu().numpy()]
         hit = rows >= 0
         np.add.at(sums["dL_dmean2D"], rows[hit], res["d_mean"][hit])
         np.add.at(sums["dL_dconic"], rows[hit], res["d_conic"][hit])
+        np.add.at(sums["dL_dcov2D"], rows[hit], res["d_cov"][hit])
         np.add.at(sums["dL_dopacity"], rows[hit], res["d_op"][hit][:, None])
         np.add.at(sums["dL_dcolors"], rows[hit], res["d_col"][hit])
     return sums, mismatch
@@ -267,6 +276,7 @@ def _compare_gradients(got_dev, targets, exp, allowed_outliers, what):
     idx = torch.from_numpy(np.asarray(targets)).to(got_dev["dL_dcolors"].device)
     got = {"dL_dmean2D": got_dev["dL_dmean2D"][idx].cpu().numpy(),
            "dL_dconic": got_dev["dL_dconic_opacity"][idx][:, :3].cpu().numpy(),
+           "dL_dcov2D": got_dev["dL_dcov2D"][idx][:, :3].cpu().numpy(),
            "dL_dopacity": got_dev["dL_dconic_opacity"][idx][:, 3:4].cpu().numpy(),
            "dL_dcolors": got_dev["dL_dcolors"][idx].cpu().numpy()}
     for k in exp:
@@ -281,7 +291,7 @@ def _compare_gradients(got_dev, targets, exp, allowed_outliers, what):
 
 
 def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_tiles_each=64, max_union=700, max_pick=120,
-                max_depth=6000):
+                max_depth=6000, most_tiles=0):
     # max_depth: the oracle holds [records x 256] float64 arrays per tile; tiles whose deepest pixel walks more are passed over
     """forward + backward at one camera; returns the number of Gaussians that received colour gradient."""
     import torch
@@ -356,9 +366,47 @@ def _check_pose(r, scene, cam, bg, seed, min_with_gradient, n_windows=40, max_ti
         sel = torch.from_numpy(keep).to("cuda:0")
         host_scene = scenes.scene_rows(scene, sel)
         full = {k: got_dev[k][sel].cpu().numpy() for k in
-                ("dL_dconic_opacity", "dL_dmean2D", "dL_dcov3D", "dL_dmeans3D", "dL_dscales", "dL_drotations")}
+                ("dL_dconic_opacity", "dL_dmean2D", "dL_dcov2D", "dL_dcov3D", "dL_dmeans3D", "dL_dscales", "dL_drotations")}
         mags = check_backward_chain(full, {"cov3D": geo["cov3D"][sel].cpu().numpy()}, host_scene, cam, W, H, np.arange(keep.size))
         assert all(m > 0 for m in mags)
+    # (3) the splats that HURT: the Gaussians with gradient that touch the most tiles — screen-filling, a few centimetres from
+    # the camera, conics with a condition number of 1e6. Every tile of the frame is evaluated by the float64 oracle (frames of
+    # shallow tiles only: `most_tiles` is set for the pose inside the cloud) and the chain is checked END TO END against the
+    # oracle's own sums, at 1e-3 of each Gaussian's own largest component.
+    if most_tiles:
+        assert not deep.any()
+        gid = torch.nonzero(with_grad).flatten()
+        big = gid[torch.argsort(tt[gid], descending=True)][:most_tiles].cpu().numpy()
+        big = np.asarray(sorted(int(i) for i in big))
+        all_tiles = [(tx, ty) for ty in range(gy) for tx in range(gx)]
+        bad_px = []
+        # (the oracle's forward in float32, as the HIP forward computes it: the backward of one and the same function)
+        exp3, mismatch3 = _oracle_gradients(r, dL, bg, all_tiles, big, max_depth, bad_pixels=bad_px, f32_forward=True)
+        assert len(bad_px) <= 8, len(bad_px)
+        if bad_px:
+            # The two forwards disagree on a few pixels that sit on a hard threshold; a Gaussian whose sum over two million
+            # pixels nearly cancels sees such a pixel in its third digit. Those pixels are taken out of the loss on BOTH sides:
+            # what is compared is the backward of one and the same forward.
+            dL = dL.clone()
+            ys, xs = (torch.tensor(v, device=dL.device) for v in zip(*bad_px))
+            sub = sorted({(x // 16, y // 16) for y, x in bad_px})
+            before, _ = _oracle_gradients(r, dL, bg, sub, big, max_depth, f32_forward=True)
+            dL[:, ys, xs] = 0.0
+            after, _ = _oracle_gradients(r, dL, bg, sub, big, max_depth, f32_forward=True)
+            exp3 = {k: exp3[k] - before[k] + after[k] for k in exp3}
+            got_dev = r.backward(dL)
+        sel = torch.from_numpy(big).to("cuda:0")
+        got3 = {k: got_dev[k][sel].cpu().numpy() for k in
+                ("dL_dconic_opacity", "dL_dmean2D", "dL_dcov2D", "dL_dcov3D", "dL_dmeans3D", "dL_dscales", "dL_drotations")}
+        for k, idx3 in (("dL_dcov2D", slice(0, 3)), ("dL_dmean2D", slice(0, 2))):
+            e, gv = exp3[k], got3[k][:, idx3]
+            err = np.abs(gv - e).max(1) / np.maximum(np.abs(e).max(1), 1e-30)
+            print(f"[backward] {most_tiles} Gaussians with the most tiles ({int(tt[sel].min())}-{int(tt[sel].max())} tiles): {k} worst relative error {err.max():.2e}")
+            assert (err <= 1e-3).all(), (k, float(err.max()))
+        up = {"dL_dconic_opacity": np.concatenate([exp3["dL_dconic"], exp3["dL_dopacity"]], 1), "dL_dmean2D": exp3["dL_dmean2D"],
+              "dL_dcov2D": exp3["dL_dcov2D"]}
+        check_backward_chain(got3, {"cov3D": geo["cov3D"][sel].cpu().numpy()}, scenes.scene_rows(scene, sel), cam, W, H,
+                             np.arange(big.size), upstream=up, tol_scale=1.0 / 3.0)      # 0.7e-3 / 1e-3 of the Gaussian's own largest component
     return int(with_grad.sum()), int(keep.size)
 
 
@@ -376,7 +424,8 @@ def test_config5_garden_1080p_forward_backward_fullsize():
     # tile, so about a thousand Gaussians receive gradient at all
     cam = camera.default_camera(W, H, near=0.001 * span, far=span)
     # (those are large: the ones checked in full touch up to 1 200 tiles each)
-    n_grad, n_checked = _check_pose(r, scene, cam, bg, seed=7, min_with_gradient=0, max_tiles_each=1200, max_union=1500, max_pick=40)
+    n_grad, n_checked = _check_pose(r, scene, cam, bg, seed=7, min_with_gradient=0, max_tiles_each=1200, max_union=1500, max_pick=40,
+                                    most_tiles=20)
     assert r.last_num_rendered > 200_000_000 and n_grad > 500 and n_checked >= 5, (n_grad, n_checked)
     # a pose outside the cloud: small splats, deep lists, most visible Gaussians receive gradient
     cam2 = camera.default_camera(W, H, near=0.001 * span, far=span, position=(0.0, 0.0, -14.0))
