@@ -307,28 +307,28 @@ struct StagedRecords {
     unsigned long long exp_tab[32];   // exp_ref's table (exp_table_init at the top of the kernel)
 };
 
-__device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, StagedRecords& st,
-                                                    const RecordBatch& b, unsigned long long& staged) {
+// Stages the survivors of one batch (the footprint test, one lane per record) compacted into `st`; returns their number.
+// *before_boundary (optional): how many of them lie in front of the batch's first multiple-of-256 list position.
+__device__ __forceinline__ uint32_t stage_batch(const TileFeed& f, StagedRecords& st, const RecordBatch& b, uint32_t* before_boundary = nullptr) {
     float2* const s_xy = st.xy;
     float4* const s_co = st.co;
     float4* const s_rgb = st.rgb;
     float4* const s_raw = st.raw;
     const bool present = b.present();
-    const uint32_t rank = b.rank(), pos = b.pos, count = b.count();
+    const uint32_t rank = b.rank(), pos = b.pos;
     const bool keep = present && !record_misses_tile(b.xy, b.co, f.box);
     const unsigned long long m2 = __ballot(keep);
-    const uint32_t kept = (uint32_t)__popcll(m2);
     if (keep) {
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
         const float* c = f.colors + 3 * (size_t)b.id;
         s_xy[slot] = b.xy;
-        // the filter's floor for this record, in units of log2: -ln(255 opacity) less the margins (1e-3 for the rounding of the
-        // exponential and the product, and the filter's own rounding). Opacity <= 0: +inf, no
-        // candidate (alpha <= 0 fails the 1/255 test); NaN opacity: -inf (the reference's min(0.99, NaN) is 0.99: it counts).
         // The filter's evaluation of the power differs from the reference's by the rounding of three terms that may cancel:
         // a few 6e-8 of their magnitude, bounded here over the tile.
         const float dxm = fmaxf(fabsf(b.xy.x - f.box.x_lo), fabsf(b.xy.x - f.box.x_hi)), dym = fmaxf(fabsf(b.xy.y - f.box.y_lo), fabsf(b.xy.y - f.box.y_hi));
         const float terms = fabsf(b.co.x) * dxm * dxm + fabsf(b.co.z) * dym * dym + 2.0f * fabsf(b.co.y) * dxm * dym;
+        // the filter's floor for this record, in units of log2: -ln(255 opacity) less the margins (1e-3 for the rounding of the
+        // exponential and the product, and the filter's own rounding). Opacity <= 0: +inf, no
+        // candidate (alpha <= 0 fails the 1/255 test); NaN opacity: -inf (the reference's min(0.99, NaN) is 0.99: it counts).
         const float p0 = -__logf(255.0f * b.co.w);
         const float floor2 = b.co.w != b.co.w ? -__builtin_inff() : (b.co.w <= 0.0f ? __builtin_inff() : (p0 - 1e-3f - 1e-6f * terms) * kLog2e);
         // The filter's slack covers the rounding of power terms up to 4e6 (kFilterSlack / 6e-8). A record whose terms can be
@@ -341,19 +341,30 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
         s_raw[slot] = b.co;
         s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
     }
+    if (before_boundary) {
+        const uint32_t boundary = (pos + (uint32_t)kBatch - 1u) & ~((uint32_t)kBatch - 1u);   // first multiple of 256 >= pos
+        *before_boundary = (uint32_t)__popcll(__ballot(keep && rank < boundary - pos));
+    }
+    return (uint32_t)__popcll(m2);
+}
+
+__device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, StagedRecords& st,
+                                                    const RecordBatch& b, unsigned long long& staged) {
+    uint32_t before = 0;
+    const uint32_t kept = stage_batch(f, st, b, &before);
+    const uint32_t pos = b.pos, count = b.count();
     // wave-private LDS: the writes above and the reads of composite_staged are ordered inside the wave
     bool all_done = false;
     uint32_t first = 0;
     const uint32_t boundary = (pos + (uint32_t)kBatch - 1u) & ~((uint32_t)kBatch - 1u);   // first multiple of 256 >= pos
     if (boundary < pos + count) {
         // records in front of the boundary first; then the reference would test "whole tile done" and stage the next 256
-        const uint32_t before = (uint32_t)__popcll(__ballot(keep && rank < boundary - pos));
-        if (before) all_done = composite_staged(s, s_xy, s_co, s_rgb, s_raw, before, f.t_cutoff, st.exp_tab);
+        if (before) all_done = composite_staged(s, st.xy, st.co, st.rgb, st.raw, before, f.t_cutoff, st.exp_tab);
         if (all_done) return true;
         staged += min((uint32_t)kBatch, f.total - boundary);
         first = before;
     }
-    if (kept > first) all_done = composite_staged(s, s_xy + first, s_co + first, s_rgb + first, s_raw + first, kept - first, f.t_cutoff, st.exp_tab);
+    if (kept > first) all_done = composite_staged(s, st.xy + first, st.co + first, st.rgb + first, st.raw + first, kept - first, f.t_cutoff, st.exp_tab);
     return all_done;
 }
 

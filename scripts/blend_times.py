@@ -20,7 +20,9 @@ def t(title, cam, **kw):
         r.draw(cam, profile=True, **kw)
         ms += r.last_stage_ms["blend"] / 10
         tot += sum(r.last_stage_ms.values()) / 10
-    print(f"  blend {ms:.4f} ms  (all stages {tot:.3f})  {title}")
+    st = r.map_image_state()
+    digest = (int(r.out_color.view(torch.int32).to(torch.int64).sum()), int(st["nContrib"].to(torch.int64).sum()), int(st["finalT"].view(torch.int32).to(torch.int64).sum()))
+    print(f"  blend {ms:.4f} ms  (all stages {tot:.3f})  {title}  plan={r.last_plan}{'+lists' if r.last_blend_from_lists else ''} digest={digest}")
 cams = {p: camera.default_camera(1920, 1080, near=near, far=far, position=(0.0, 0.0, p)) for p in (-5.0, -14.0, -30.0, -50.0)}
 for p, c in cams.items():
     t(f"eye (0,0,{p:g})", c)
