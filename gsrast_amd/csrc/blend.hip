@@ -12,8 +12,6 @@
 // Differences that do not change any pixel: a record no lane of the wave can see (power > 0 or below the
 // 1/255 cut for every lane) is skipped after the power evaluation by one ballot.
 
-#include <stdlib.h>
-
 #include <algorithm>
 #include <type_traits>
 
@@ -131,75 +129,6 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
 }
 
-// ---- four waves per tile with ONE walk of the list -------------------------------------------------------------------
-// The reference's own shape (GSCuda.cu:595-614): a 256-lane workgroup per tile, every lane fetching one of the 256 records of
-// a round; here wave w fetches and footprint-tests list positions [256 r + 64 w, 256 r + 64 w + 64) of round r into the
-// workgroup's LDS (the survivors compacted, per batch), one barrier, and each wave then composites the round's four batches
-// in list order on ITS 16 x 4 strip of the tile. The walk is shared, the compositing divided by four: a deep tile — the
-// frames of small splats end on a few of them, each a lone wave bound by its own instruction stream — finishes in about a
-// quarter of the time. (The four-waves-per-tile mode of blend_wave_kernel repeats the whole walk in every wave.) The round of
-// 256 is the reference's: "whole tile done" is tested at its top, so the staged-record count R_f is the reference's too.
-constexpr int kCoopWaves = 4;
-__global__ __launch_bounds__(kCoopWaves* kWave) void blend_coop_kernel(const BlendParams p) {
-    __shared__ StagedRecords s_staged[kCoopWaves];
-    __shared__ uint32_t s_kept[kCoopWaves];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    exp_table_init(s_staged[wave].exp_tab, lane);
-    const int tile_local = tile_of_workgroup((int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
-    if (tile_local < 0) return;
-    const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
-    const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
-    TileLanes s;
-    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height, wave);
-    const uint2 range = p.ranges[tile];
-    const uint32_t total = range.y - range.x;          // unsigned wrap as in the reference
-    unsigned long long staged = 0;
-    bool mine_done = tile_lanes_all_done(s);
-
-    TileFeed feed;
-    feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
-    feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);        // the whole tile: the survivors serve all four strips
-    feed.total = total; feed.t_cutoff = p.t_cutoff;
-    auto next_batch = [&](uint32_t pos) {
-        RecordBatch nb;
-        nb.valid = pos < total;
-        if (nb.valid) {
-            const uint32_t cnt = min((uint32_t)kWave, total - pos);
-            nb.mask = cnt == kWave ? ~0ull : ((1ull << cnt) - 1ull);
-            nb.pos = pos;
-            if ((uint32_t)lane < cnt) nb.id = p.point_list[range.x + pos + (uint32_t)lane];
-        }
-        return nb;
-    };
-    // this wave's batch of round r starts at list position 256 r + 64 w; ids are fetched two rounds ahead, records one
-    const uint32_t first = (uint32_t)(wave * kWave);
-    RecordBatch b0 = next_batch(first);
-    fetch_records(b0, feed);
-    RecordBatch b1 = next_batch(first + (uint32_t)kBatch);
-    for (uint32_t round = 0; ; ++round) {
-        if (__syncthreads_and(mine_done ? 1 : 0)) break;            // GSCuda.cu:595-599 (and: the staging area is free again)
-        const uint32_t round_pos = round * (uint32_t)kBatch;
-        if (round_pos >= total) break;
-        if (wave == 0) staged += min((uint32_t)kBatch, total - round_pos);
-        fetch_records(b1, feed);
-        RecordBatch b2 = next_batch(first + (round + 2u) * (uint32_t)kBatch);
-        s_kept[wave] = b0.valid ? stage_batch(feed, s_staged[wave], b0) : 0u;
-        __syncthreads();
-        if (!mine_done) {
-#pragma unroll 1
-            for (int q = 0; q < kCoopWaves && !mine_done; ++q) {
-                const uint32_t kept = s_kept[q];
-                if (kept) mine_done = composite_staged(s, s_staged[q].xy, s_staged[q].co, s_staged[q].rgb, s_staged[q].raw, kept,
-                                                       feed.t_cutoff, s_staged[wave].exp_tab);
-            }
-        }
-        b0 = b1;
-        b1 = b2;
-    }
-    tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
-    if (p.staged_counter && threadIdx.x == 0) atomicAdd(p.staged_counter, staged);
-}
-
 // Stage entry point for the tests: the footprint test of blend_core.hpp on n (record, tile) pairs.
 __global__ __launch_bounds__(256) void footprint_test_kernel(int n, const float2* __restrict__ xy, const float4* __restrict__ co,
                                                              const int2* __restrict__ tile, int width, int height,
@@ -259,12 +188,6 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     // (not when the staged records are counted: that count is per tile, the reference's "whole tile done" test)
     p.nonempty = staged_counter ? nullptr : nonempty_tiles;
     p.base_workgroups = patch_workgroups(d.grid_x, d.row_end - d.row_begin);
-    static const char* mode_env = getenv("GSR_BLEND_MODE");
-    if (mode_env && mode_env[0] == 'c') {
-        hipLaunchKernelGGL(blend_coop_kernel, dim3((unsigned)p.base_workgroups), dim3(kCoopWaves * kWave), 0, stream, p);
-        GSR_LAUNCH_CHECK("blend_coop_kernel");
-        return GSR_OK;
-    }
     hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups * (p.nonempty ? 4 : 1))), dim3(kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;
