@@ -1,0 +1,146 @@
+"""Turns gpurun_out/r04/ (scripts/profile_r04.sh, run on the GPU box) into the summaries committed under profiles/.
+Usage: python scripts/collect_profiles_r04.py"""
+import glob
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_stats_table as kst
+
+SRC, DST = "gpurun_out/r04", "profiles"
+
+
+def bench_line(path):
+    try:
+        lines = [ln for ln in open(path) if ln.startswith('{"metric')]
+        return json.loads(lines[-1]) if lines else None
+    except OSError:
+        return None
+
+
+def stats_file(name):
+    f = glob.glob(f"{SRC}/trace_{name}/**/*kernel_stats.csv", recursive=True)
+    return f[0] if f else None
+
+
+def write_trace(name, cmd):
+    import csv
+    f = stats_file(name)
+    if not f:
+        print("missing trace", name)
+        return {}
+    line = bench_line(f"{SRC}/trace_{name}.log")
+    # (the scene generator's torch kernels — 50 M scene built on the device — are not the library's)
+    rows = [r for r in csv.DictReader(open(f)) if "at::native" not in r["Name"] and not r["Name"].startswith("void at::")]
+    with open(f"{DST}/r04_{name}_kernel_stats.txt", "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {cmd}\n# bench line of the same run:\n{json.dumps(line)}\n")
+        o.write("# kernel  calls  average / min / max microseconds  share of device time\n")
+        for r in rows[:28]:
+            o.write(f"{kst.short(r['Name']):44s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs']) / 1e3:9.1f} "
+                    f"min_us={float(r['MinNs']) / 1e3:9.1f} max_us={float(r['MaxNs']) / 1e3:9.1f}  {float(r['Percentage']):5.1f} %\n")
+    return {kst.short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+
+
+def pmc_values(name):
+    vals = {}
+    try:
+        for ln in open(f"{SRC}/pmc_{name}.txt"):
+            k = ln.split()[0] if ln.split() else ""
+            for n, v in re.findall(r"(\w+)=([0-9.e+-]+)", ln):
+                try:
+                    vals.setdefault(k, {})[n] = float(v)
+                except ValueError:
+                    pass
+    except OSError:
+        print("missing pmc", name)
+    return vals
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    write_trace("head", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras   (the headline frame)")
+    write_trace("head_precomp", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras --colors-precomp   (the headline frame, colours passed as colorsPrecomp)")
+    write_trace("outside", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --pose 0,0,-14")
+    write_trace("far", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --pose 0,0,-30")
+    write_trace("bound", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --opacity-scale 0.1")
+    write_trace("stress50M", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --scene stress --splats 50000000")
+    write_trace("stress50M_precomp", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --colors-precomp")
+    write_trace("4k", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --width 3840 --height 2160")
+    with open(f"{DST}/r04_pmc.txt", "w") as o:
+        o.write("# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras [frame]\n"
+                "# one run per counter set; per-kernel averages over dispatches. FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE\n"
+                "# tallies a 128-B request of a wide coalesced read at 64 B (MI355X_MICROARCH.md, HBM): doubled before it is compared with bytes.\n"
+                "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs.\n")
+        for name, what in (("head_sq", "headline frame"), ("head_lds", "headline frame"), ("head_fetch", "headline frame"),
+                           ("head_write", "headline frame"), ("precomp_fetch", "headline frame, --colors-precomp"),
+                           ("precomp_write", "headline frame, --colors-precomp"), ("bound_sq", "opacities x 0.1"),
+                           ("outside_sq", "pose (0,0,-14)"), ("far_sq", "pose (0,0,-30)"),
+                           ("stress_fetch", "50 M stress scene"), ("stress_write", "50 M stress scene"),
+                           ("stress_precomp_fetch", "50 M stress scene, --colors-precomp"),
+                           ("stress_precomp_write", "50 M stress scene, --colors-precomp")):
+            o.write(f"## {name}: {what}\n")
+            try:
+                o.write(open(f"{SRC}/pmc_{name}.txt").read())
+            except OSError:
+                o.write("(missing)\n")
+    fetch, write, sq = pmc_values("head_fetch"), pmc_values("head_write"), pmc_values("head_sq")
+
+    def traffic(k):
+        if k in fetch and k in write and "FETCH_SIZE" in fetch[k] and "WRITE_SIZE" in write[k]:
+            return int((2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024)
+        return None
+
+    def clock(v):       # effective clock from GRBM_GUI_ACTIVE (sum over 8 XCDs) and the dispatch's duration
+        return None
+
+    out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r04_pmc.txt): (2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes, "
+                       "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; blend_insts: SQ_INSTS_VALU / SQ_INSTS_SALU per "
+                       "launch of the blend kernel on the same frame. Workload: the bench.py default frame (N=5834784, 1920x1080).",
+           "blocks": {}, "sort": {}}
+    for stage, kern in (("duplicate", "block_emit_kernel"), ("preprocess", "preprocess_kernel"), ("blend", "blend_blocks_kernel")):
+        t = traffic(kern)
+        if t is not None:
+            out["blocks"][stage] = t
+    # the preprocess kernel's traffic with the colours precomputed, bench frame and 50 M
+    for key, fn, wn in (("preprocess_colors_precomp", "precomp_fetch", "precomp_write"), ("preprocess_50M", "stress_fetch", "stress_write"),
+                        ("preprocess_50M_colors_precomp", "stress_precomp_fetch", "stress_precomp_write")):
+        f2, w2 = pmc_values(fn).get("preprocess_kernel", {}), pmc_values(wn).get("preprocess_kernel", {})
+        if "FETCH_SIZE" in f2 and "WRITE_SIZE" in w2:
+            out["blocks"][key] = int((2 * f2["FETCH_SIZE"] + w2["WRITE_SIZE"]) * 1024)
+    old = json.load(open(f"{DST}/pmc_traffic_r01.json"))
+    out["sort"] = old.get("sort", {})
+    out["sort_note"] = "sort-plan figures are round 1's (profiles/r01_final_pmc.txt): that plan's kernels other than the blend are unchanged"
+    b = sq.get("blend_blocks_kernel", {})
+    if "SQ_INSTS_VALU" in b:
+        out["blend_insts"] = {"SQ_INSTS_VALU": b["SQ_INSTS_VALU"], "SQ_INSTS_SALU": b["SQ_INSTS_SALU"],
+                              "SQ_WAVE_CYCLES": b.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": b.get("SQ_WAIT_ANY"),
+                              "SQ_ACTIVE_INST_ANY": b.get("SQ_ACTIVE_INST_ANY"), "clock_ghz": 2.4,
+                              "source": "profiles/r04_pmc.txt, set head_sq"}
+    for name in ("bound_sq", "outside_sq", "far_sq"):
+        pv = pmc_values(name)
+        # (sparse frames blend from the sorted lists: blend_wave_kernel)
+        v = pv.get("blend_blocks_kernel") or pv.get("blend_wave_kernel") or {}
+        if v:
+            v = dict(v, kernel="blend_blocks_kernel" if "blend_blocks_kernel" in pv else "blend_wave_kernel")
+            out[f"blend_insts_{name.split('_')[0]}"] = v
+    json.dump(out, open(f"{DST}/pmc_traffic_r04.json", "w"), indent=1)
+    import shutil
+    if os.path.exists(f"{SRC}/band_projection.json"):
+        shutil.copy(f"{SRC}/band_projection.json", f"{DST}/band_projection.json")
+    for txt in ("band_timings", "band_timings_4k", "parity", "soak"):
+        if os.path.exists(f"{SRC}/{txt}.txt"):
+            shutil.copy(f"{SRC}/{txt}.txt", f"{DST}/r04_{txt}.txt")
+    for name in ("bench_default", "bench_backward", "bench_backward_outside", "bench_backward_nolists", "bench_4k", "bench_stress50M",
+                 "bench_stress50M_precomp", "bench_stress50M_inria_sh3", "bench_forced_dist_1rank"):
+        d = bench_line(f"{SRC}/{name}.json")
+        if d is None:
+            print(name, "missing")
+            continue
+        open(f"{DST}/r04_{name}.json", "w").write(json.dumps(d, indent=1))
+        print(name, d["ms_per_step"], {k: v for k, v in d["stage_ms"].items() if v}, "roofline", d["roofline"]["frac"])
+
+
+if __name__ == "__main__":
+    main()
