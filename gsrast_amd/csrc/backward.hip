@@ -918,7 +918,7 @@ static int backward_impl(gsr_backward_args* a) {
         q.out_cov2D = reinterpret_cast<float4*>(a->dL_dcov2D);
         q.dL_dcolors = a->dL_dcolors;
         q.dL_dcov3D = a->dL_dcov3D;
-        q.dL_dshs = a->dL_dshs;
+        q.dL_dshs = a->dL_dcov3D ? a->dL_dshs : nullptr;       // (without the chain the kernel only rounds the double sums)
         q.proj = a->proj_matrix;
         q.scales = reinterpret_cast<const float4*>(a->scales);
         q.rotations = reinterpret_cast<const float4*>(a->rotations);

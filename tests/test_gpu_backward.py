@@ -349,6 +349,39 @@ def test_backward_without_a_fitting_receipt_is_refused_never_garbage():
     assert ra.last_receipt.serial >= old.serial + 70       # (the serial counts every call of this thread on this device)
 
 
+def test_double_sums_are_reproducible_and_agree_with_the_float_sums():
+    """gsr_backward_args.sums_f64: the twelve per-Gaussian sums accumulated in double and rounded once. Two runs give the same
+    bits (float atomics arrive in another order every run: their sums differ in the last places), with and without the chain
+    behind them; the scratch is left zero; and the float mode agrees to the accuracy float sums have."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 640, 360
+    scene = scenes.garden_like_scene(60_000, seed=31)
+    scene["means3D"][:, :3] *= 0.3
+    scene["scales"][:200, :3] *= 30.0                            # a few splats that fill the frame: thousands of terms per sum
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    r.draw(camera.default_camera(w, h, near=0.05, far=50.0))
+    dL = torch.randn((3, h, w), generator=torch.Generator().manual_seed(5)).cuda()
+    a = {k: v.clone() for k, v in r.backward(dL, wide_sums=True).items()}
+    assert float(r._sums_f64.abs().max()) == 0.0                 # left zero for the next call
+    b = {k: v.clone() for k, v in r.backward(dL, wide_sums=True).items()}
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    base = {k: v.clone() for k, v in r.backward(dL, wide_sums=True, with_cov3D=False).items()}
+    assert float(r._sums_f64.abs().max()) == 0.0
+    for k in ("dL_dmean2D", "dL_dconic_opacity", "dL_dcolors"):
+        assert torch.equal(base[k], a[k]), k                     # the same sums whether or not the chain runs behind them
+    f = r.backward(dL, wide_sums=False)
+    for k in a:
+        scale = float(a[k].abs().max())
+        assert scale > 0 and float((f[k] - a[k]).abs().max()) <= 2e-4 * scale, (k, float((f[k] - a[k]).abs().max()), scale)
+    culled = r.map_geometry_state()["radii"] <= 0
+    for k in a:
+        assert bool((a[k][culled] == 0).all()), k
+
+
 def test_backward_of_a_frame_without_instances_is_all_zero():
     """R == 0: the forward call leaves even the tile ranges unwritten (GSCuda.cu:775-778); with its receipt gsr_backward
     returns zero gradients instead of walking whatever an earlier frame left in the chunks."""
