@@ -238,6 +238,7 @@ class Runner:
         self.grid_x, self.grid_y = (W + 15) // 16, (H + 15) // 16
         self.dl_dout = None
         self.bw_ms = [0.0, 0.0]
+        self.bw_outputs = None              # gsr_backward's optional outputs: None = every array
         self.split_ms = [0.0, 0.0]          # sharded runs: device time of the render and of the band exchange (HIP events, profiled frames)
 
     def step(self, cam, profile=False, **kw):
@@ -252,7 +253,7 @@ class Runner:
             ev[1].record()
         if self.dl_dout is not None:
             rast.backward(self.dl_dout, profile=profile, semantics=kw.get("semantics", "gscuda"), sh_degree=kw.get("sh_degree", 3),
-                          wide_sums=os.environ.get("GSR_BW_WIDE_SUMS", "1") != "0")
+                          wide_sums=os.environ.get("GSR_BW_WIDE_SUMS", "1") != "0", outputs=self.bw_outputs)
             if profile:
                 self.bw_ms[0] += rast.last_backward_ms[0]
                 self.bw_ms[1] += rast.last_backward_ms[1]
@@ -544,6 +545,14 @@ def main() -> int:
             run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
             e = run.measure(cam, **short, **draw_kw)
             extras["forward_backward"] = brief(e, n_splats, "BASELINE config 5: forward + backward (all gradients down to the inputs) on the headline frame")
+            # (every output of gsr_backward is optional: the chain is bound by what it writes, 150-odd bytes per Gaussian in all)
+            run.bw_outputs = ("dL_dmean2D", "dL_dconic_opacity", "dL_dshs", "dL_dmeans3D", "dL_dscales", "dL_drotations")
+            e = run.measure(cam, **short, **draw_kw)
+            extras["forward_backward_inputs"] = brief(e, n_splats, "the same, only the gradients of the inputs asked for (means3D, scales, rotations, opacity = dL_dconic_opacity.w, SH) and dL_dmean2D; dL_dcolors / dL_dcov2D / dL_dcov3D not written")
+            run.bw_outputs = ("dL_dmean2D", "dL_dcov3D", "dL_dshs")
+            e = run.measure(cam, **short, **draw_kw)
+            extras["forward_backward_config5"] = brief(e, n_splats, "the same, exactly the outputs BASELINE config 5 names: dL_dmean2D, dL_dcov3D, dL_dshs")
+            run.bw_outputs = None
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["forward_backward_no_sorted_lists"] = brief(e, n_splats, "the same with GSR_FLAG_NO_SORTED_LISTS: the backward reads the tile lists from the block lists")
             run.dl_dout = None

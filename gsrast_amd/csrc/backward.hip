@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     __shared__ float2 s_xy[kWave];
     __shared__ float4 s_co[kWave];
     __shared__ float4 s_rgb[kWave];
+    __shared__ float s_floor[kWave];
     __shared__ unsigned long long s_exp[32];
     exp_table_init(s_exp, (int)threadIdx.x);       // (wave-private LDS: ordered inside the wave)
 
@@ -224,6 +225,10 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             s_co[slot] = co_l;
             const float* col = p.colors + 3 * (size_t)id;
             s_rgb[slot] = make_float4(col[0], col[1], col[2], __uint_as_float(idx_l));
+            // A pixel can pass alpha >= 1/255 only where power >= -ln(255 opacity) (less a margin for the rounding of the
+            // logarithm, the exponential and the product; NaN opacity: the reference's min(0.99, NaN) is 0.99, it counts)
+            const float op = co_l.w;
+            s_floor[slot] = op != op ? -__builtin_inff() : (op <= 0.0f ? __builtin_inff() : -__logf(255.0f * op) - 1e-3f);
         }
         // wave-private LDS: the writes above and the reads below are ordered inside the wave
         for (int j = (int)__popcll(kept_mask) - 1; j >= 0; --j) {
@@ -234,42 +239,58 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
             float a_mx = 0.0f, a_my = 0.0f, a_A = 0.0f, a_B = 0.0f, a_C = 0.0f, a_op = 0.0f, a_r = 0.0f, a_g = 0.0f, a_b = 0.0f;
             float a_m00 = 0.0f, a_m01 = 0.0f, a_m11 = 0.0f;
             bool any = false;
+            // The reference's three per-pixel tests (GSCuda.cu:636-655) decide, as in the forward, with the forward's own
+            // arithmetic; what they guard runs for the whole strip without branches — a lane that fails them adds zeros
+            // (w = 0, dpow = 0) and keeps its T — behind three wave-uniform skips ("no pixel of the strip has the record in
+            // its list", "the record is too faint to count anywhere on the strip": before the exponential, "no pixel passes
+            // the tests"). Per-lane branches cost this loop more than the work they skipped: twelve accumulators to merge at
+            // every level of nesting (0.314 -> 0.238 ms on the bench frame, 1.36 -> 0.91 ms from (0,0,-30)). The sums take
+            // explicit fused multiply-adds (no reference order to keep here), the transmittance its reciprocal in one
+            // instruction (1 ulp).
+            const float4 col = s_rgb[j];
+            const float hxx = -0.5f * dx * dx, flo = s_floor[j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (idx0 >= last[k]) continue;                   // behind this pixel's last contributor
+                // (the tests as lane masks in scalar registers, as in the forward blend)
+                const unsigned long long inlist = __ballot(idx0 < last[k]);      // else: behind this pixel's last contributor
+                if (inlist == 0ull) continue;
                 const float dy = xy.y - fy[k];
                 const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-                if (power > 0.0f) continue;
+                const unsigned long long cand = inlist & ~__ballot(power > 0.0f) & __ballot(power >= flo);
+                if (cand == 0ull) continue;                      // the record does not reach this strip
                 const float G = exp_ref(power, s_exp);           // the forward's exp: same contributing set
                 const float raw = co.w * G;
                 const float alpha = fminf(0.99f, raw);
-                if (alpha < 1.0f / 255.0f) continue;
-                const float4 col = s_rgb[j];
-                const float inv = 1.0f / (1.0f - alpha);
-                T[k] = T[k] * inv;                               // transmittance in front of this record
-                const float cg = col.x * g0[k] + col.y * g1[k] + col.z * g2[k];
-                const float w = alpha * T[k];
-                a_r += w * g0[k]; a_g += w * g1[k]; a_b += w * g2[k];
-                const float dL_dalpha = T[k] * cg - S[k] * inv;
-                S[k] += cg * w;
+                const unsigned long long act_mask = cand & ~__ballot(alpha < 1.0f / 255.0f);
+                if (act_mask == 0ull) continue;
+                const bool act = __builtin_amdgcn_inverse_ballot_w64(act_mask);
                 any = true;
-                if (raw > 0.99f) continue;                       // clamped: alpha does not move with the parameters
-                a_op += G * dL_dalpha;
-                const float dpow = raw * dL_dalpha;
-                a_A += -0.5f * dx * dx * dpow;
-                a_B += -dx * dy * dpow;
-                a_C += -0.5f * dy * dy * dpow;
+                const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float Tn = T[k] * inv;                     // transmittance in front of this record
+                T[k] = act ? Tn : T[k];
+                const float cg = __builtin_fmaf(col.x, g0[k], __builtin_fmaf(col.y, g1[k], col.z * g2[k]));
+                const float w = act ? alpha * Tn : 0.0f;
+                a_r = __builtin_fmaf(w, g0[k], a_r); a_g = __builtin_fmaf(w, g1[k], a_g); a_b = __builtin_fmaf(w, g2[k], a_b);
+                const float dL_dalpha = __builtin_fmaf(Tn, cg, -(S[k] * inv));
+                S[k] = __builtin_fmaf(cg, w, S[k]);
+                const bool live = __builtin_amdgcn_inverse_ballot_w64(act_mask & ~__ballot(raw > 0.99f));   // clamped: alpha does not move with the parameters
+                const float gop = live ? G * dL_dalpha : 0.0f;
+                const float dpow = live ? raw * dL_dalpha : 0.0f;
+                a_op += gop;
+                a_A = __builtin_fmaf(hxx, dpow, a_A);
+                a_B = __builtin_fmaf(-(dx * dy), dpow, a_B);
+                a_C = __builtin_fmaf(-0.5f * dy * dy, dpow, a_C);
                 // u = K d is the gradient of the power w.r.t. the centre (up to sign) AND what the covariance sees: the pixel's
                 // share of dL/dK is -0.5 dpow d d^T, so its share of dL/dcov2D = -K (dL/dK) K is 0.5 dpow u u^T — summed here,
                 // pixel by pixel, instead of being derived from the summed dL/dK afterwards: that product loses cond(K)^2 of
                 // the sums' digits, and the conic of a splat that fills the screen has a condition number of 1e6
-                const float ux = co.x * dx + co.y * dy, uy = co.y * dx + co.z * dy;
-                a_mx -= ux * dpow;
-                a_my -= uy * dpow;
-                const float hd = 0.5f * dpow;
-                a_m00 += hd * ux * ux; a_m01 += hd * ux * uy; a_m11 += hd * uy * uy;
+                const float ux = __builtin_fmaf(co.x, dx, co.y * dy), uy = __builtin_fmaf(co.y, dx, co.z * dy);
+                a_mx = __builtin_fmaf(-ux, dpow, a_mx);
+                a_my = __builtin_fmaf(-uy, dpow, a_my);
+                const float hux = 0.5f * dpow * ux, huy = 0.5f * dpow * uy;      // (the masked factor first: 0 x finite)
+                a_m00 = __builtin_fmaf(hux, ux, a_m00); a_m01 = __builtin_fmaf(hux, uy, a_m01); a_m11 = __builtin_fmaf(huy, uy, a_m11);
             }
-            if (__ballot(any) == 0ull) continue;
+            if (!any) continue;
             const float total = wave_sum12(a_mx, a_my, a_A, a_B, a_C, a_op, a_r, a_g, a_b, a_m00, a_m01, a_m11);
             if (my_sum >= 0) {
                 const size_t key = s_id[j];
@@ -383,7 +404,8 @@ struct PreprocessBackwardParams {
     double* sums64;
     float2* out_mean2D; float4* out_conic_opacity; float* out_colors; float4* out_cov2D;
     const float* dL_dcolors;
-    float* dL_dcov3D;       // f32[6 N]
+    int chain;              // run the covariance / colour chain (else: only round the double sums)
+    float* dL_dcov3D;       // f32[6 N] or null
     float* dL_dshs;         // f32[48 N] or null; only the DC triple of every Gaussian is written
     // chain down to the inputs (each output optional)
     const float* proj;
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     const bool valid = idx < p.n;
     // (without dL_dcov3D the kernel only rounds the double sums into the float arrays: radii may then be missing)
     const bool has_tile = valid && (p.radii == nullptr || p.radii[idx] > 0);
-    const bool visible = has_tile && p.dL_dcov3D != nullptr;
+    const bool visible = has_tile && p.chain != 0;
     // ---- loads ----
     float4 mean = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g = mean, sc = mean, rot = mean;
     float2 g2 = make_float2(0.0f, 0.0f), c3a = g2, c3b = g2, c3c = g2;
@@ -723,10 +745,12 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
     }
     if (valid && p.sums64) {
         // the sums, rounded once, for every Gaussian (what the memsets + float atomics leave in the other mode)
-        p.out_mean2D[idx] = make_float2((float)sum[0], (float)sum[1]);
-        p.out_conic_opacity[idx] = make_float4((float)sum[2], (float)sum[3], (float)sum[4], (float)sum[5]);
-        float* oc = p.out_colors + 3 * (size_t)idx;
-        oc[0] = (float)sum[6]; oc[1] = (float)sum[7]; oc[2] = (float)sum[8];
+        if (p.out_mean2D) p.out_mean2D[idx] = make_float2((float)sum[0], (float)sum[1]);
+        if (p.out_conic_opacity) p.out_conic_opacity[idx] = make_float4((float)sum[2], (float)sum[3], (float)sum[4], (float)sum[5]);
+        if (p.out_colors) {
+            float* oc = p.out_colors + 3 * (size_t)idx;
+            oc[0] = (float)sum[6]; oc[1] = (float)sum[7]; oc[2] = (float)sum[8];
+        }
         if (p.out_cov2D) p.out_cov2D[idx] = make_float4((float)sum[9], (float)sum[10], (float)sum[11], 0.0f);
         // (most Gaussians with a tile lie behind every pixel's last contributor and received nothing: no write for those)
         bool touched = false;
@@ -738,16 +762,18 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
             for (int k = 0; k < 6; ++k) sp[k] = make_double2(0.0, 0.0);
         }
     }
-    if (valid && p.dL_dcov3D) {
+    if (valid && p.chain) {
         if (p.dL_dmeans3D) p.dL_dmeans3D[idx] = make_float4((float)gmean[0], (float)gmean[1], (float)gmean[2], 0.0f);
         if (p.dL_dscales) {
             p.dL_dscales[idx] = make_float4((float)gsc[0], (float)gsc[1], (float)gsc[2], 0.0f);
             if (p.dL_drotations) p.dL_drotations[idx] = make_float4((float)gq[0], (float)gq[1], (float)gq[2], (float)gq[3]);
         }
-        float2* dst = reinterpret_cast<float2*>(p.dL_dcov3D + 6 * (size_t)idx);
-        dst[0] = make_float2((float)out[0], (float)out[1]);
-        dst[1] = make_float2((float)out[2], (float)out[3]);
-        dst[2] = make_float2((float)out[4], (float)out[5]);
+        if (p.dL_dcov3D) {
+            float2* dst = reinterpret_cast<float2*>(p.dL_dcov3D + 6 * (size_t)idx);
+            dst[0] = make_float2((float)out[0], (float)out[1]);
+            dst[1] = make_float2((float)out[2], (float)out[3]);
+            dst[2] = make_float2((float)out[4], (float)out[5]);
+        }
     }
     // (lanes past n stay to the end: the SH gradients above and the DC gradient below are written by the wave together)
     if (p.dL_dshs && !INRIA) {
@@ -800,11 +826,15 @@ static int backward_impl(gsr_backward_args* a) {
     a->stage_ms[0] = a->stage_ms[1] = 0.0f;
     const int n = a->num_gaussians;
     if (n <= 0 || a->width <= 0 || a->height <= 0 || !a->background || !a->means2D || !a->conic_opacity || !a->colors ||
-        !a->ranges || !a->n_contrib || !a->final_t || !a->dL_dout_color || !a->dL_dmean2D ||
-        !a->dL_dconic_opacity || !a->dL_dcolors)
+        !a->ranges || !a->n_contrib || !a->final_t || !a->dL_dout_color)
         return GSR_ERR_INVALID_ARG;
-    if (a->dL_dcov3D && (!a->cov3D || !a->means3D || !a->view_matrix || !a->radii)) return GSR_ERR_INVALID_ARG;
-    if ((a->dL_dmeans3D || a->dL_dscales || a->dL_drotations) && !a->dL_dcov3D) return GSR_ERR_INVALID_ARG;
+    // (the float arrays of the sums are where the sums are kept unless sums_f64 keeps them: optional outputs then)
+    const bool wide = a->sums_f64 != nullptr;
+    if (!wide && (!a->dL_dmean2D || !a->dL_dconic_opacity || !a->dL_dcolors)) return GSR_ERR_INVALID_ARG;
+    // the chain runs for whichever of its outputs is asked for; without sums_f64 it starts from dL_dcov3D's presence as before
+    const bool chain = a->dL_dcov3D || (wide && (a->dL_dmeans3D || a->dL_dscales || a->dL_dshs));
+    if (chain && (!a->cov3D || !a->means3D || !a->view_matrix || !a->radii)) return GSR_ERR_INVALID_ARG;
+    if ((a->dL_dmeans3D || a->dL_dscales || a->dL_drotations) && !chain) return GSR_ERR_INVALID_ARG;
     if (a->dL_dmeans3D && !a->proj_matrix) return GSR_ERR_INVALID_ARG;
     if ((a->dL_dscales || a->dL_drotations) && (!a->scales || !a->rotations || !a->dL_dscales)) return GSR_ERR_INVALID_ARG;
     const bool inria = (a->flags & GSR_FLAG_SEMANTICS_INRIA) != 0;
@@ -849,11 +879,10 @@ static int backward_impl(gsr_backward_args* a) {
         if (first == GSR_LISTS_SKIPPED_STAMP) return GSR_ERR_INVALID_ARG;
     }
     // (with sums_f64 the float arrays are written once, by the kernel that rounds the double sums: no clearing)
-    const bool wide = a->sums_f64 != nullptr;
     if (!wide || nothing_rendered) {
-        GSR_HIP_TRY(hipMemsetAsync(a->dL_dmean2D, 0, sizeof(float) * 2 * (size_t)n, stream));
-        GSR_HIP_TRY(hipMemsetAsync(a->dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)n, stream));
-        GSR_HIP_TRY(hipMemsetAsync(a->dL_dcolors, 0, sizeof(float) * 3 * (size_t)n, stream));
+        if (a->dL_dmean2D) GSR_HIP_TRY(hipMemsetAsync(a->dL_dmean2D, 0, sizeof(float) * 2 * (size_t)n, stream));
+        if (a->dL_dconic_opacity) GSR_HIP_TRY(hipMemsetAsync(a->dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)n, stream));
+        if (a->dL_dcolors) GSR_HIP_TRY(hipMemsetAsync(a->dL_dcolors, 0, sizeof(float) * 3 * (size_t)n, stream));
         if (a->dL_dcov2D) GSR_HIP_TRY(hipMemsetAsync(a->dL_dcov2D, 0, sizeof(float) * 4 * (size_t)n, stream));
     }
     if (nothing_rendered) {
@@ -900,7 +929,7 @@ static int backward_impl(gsr_backward_args* a) {
         }
     }
     if (profile) GSR_HIP_TRY(hipEventRecord(g_bw_ev[1], stream));
-    if (a->dL_dcov3D || wide) {
+    if (chain || wide) {
         PreprocessBackwardParams q;
         q.n = n;
         q.means3D = reinterpret_cast<const float4*>(a->means3D);
@@ -918,7 +947,8 @@ static int backward_impl(gsr_backward_args* a) {
         q.out_cov2D = reinterpret_cast<float4*>(a->dL_dcov2D);
         q.dL_dcolors = a->dL_dcolors;
         q.dL_dcov3D = a->dL_dcov3D;
-        q.dL_dshs = a->dL_dcov3D ? a->dL_dshs : nullptr;       // (without the chain the kernel only rounds the double sums)
+        q.chain = chain ? 1 : 0;                               // (without the chain the kernel only rounds the double sums)
+        q.dL_dshs = chain ? a->dL_dshs : nullptr;
         q.proj = a->proj_matrix;
         q.scales = reinterpret_cast<const float4*>(a->scales);
         q.rotations = reinterpret_cast<const float4*>(a->rotations);

@@ -240,7 +240,8 @@ class SplatRasterizer:
     # -- backward pass (BASELINE config 5; no counterpart in the reference) ------------------
     def backward(self, dL_dout: torch.Tensor, *, profile: bool = False, with_cov3D: bool = True,
                  tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0, semantics: str = "gscuda",
-                 sh_degree: int = 3, receipt: "_capi.ForwardReceipt | None | bool" = None, wide_sums: bool = True) -> dict:
+                 sh_degree: int = 3, receipt: "_capi.ForwardReceipt | None | bool" = None, wide_sums: bool = True,
+                 outputs: "tuple[str, ...] | None" = None) -> dict:
         """Gradients of sum(dL_dout * out_color) of the LAST draw() through gsr_backward; `semantics` / `sh_degree`
         must be those of that draw(). receipt: the gsr_forward_receipt of the draw() this is the backward of (default:
         this object's last draw(); any host thread may call); False = none, the reference's contract only (sorted lists
@@ -249,7 +250,9 @@ class SplatRasterizer:
         up to sh_degree), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
         wide_sums: accumulate the per-Gaussian sums in double (gsr_backward_args.sums_f64: 96 N bytes of scratch kept by this
         object, zero between calls) — the gradients of screen-filling splats then no longer depend on the order in which the
-        tiles' atomics arrive. The tensors are owned by this object and overwritten by the next call."""
+        tiles' atomics arrive. outputs (needs wide_sums): the names to compute, e.g. BASELINE config 5's ("dL_dmean2D",
+        "dL_dcov3D", "dL_dshs"); the others are neither computed nor written (the chain is bound by its writes) and
+        absent from the result. The tensors are owned by this object and overwritten by the next call."""
         assert semantics in ("gscuda", "inria")
         n, dev = self.num_gaussians, self.device
         g = dL_dout.to(device=dev, dtype=torch.float32).contiguous()
@@ -295,20 +298,24 @@ class SplatRasterizer:
         a.means3D, a.view_matrix = self.means3D.data_ptr(), self._view.data_ptr()
         a.tan_fovx, a.tan_fovy = self._tan
         a.dL_dout_color = g.data_ptr()
-        a.dL_dmean2D, a.dL_dconic_opacity = out["dL_dmean2D"].data_ptr(), out["dL_dconic_opacity"].data_ptr()
-        a.dL_dcolors = out["dL_dcolors"].data_ptr()
-        a.dL_dcov3D = out["dL_dcov3D"].data_ptr() if with_cov3D else None
-        a.dL_dcov2D = out["dL_dcov2D"].data_ptr() if with_cov3D else None
+        if outputs is not None:
+            assert wide_sums and set(outputs) <= set(cache), (outputs, sorted(cache))
+            out = {k: cache[k] for k in outputs}
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        a.dL_dmean2D, a.dL_dconic_opacity = ptr("dL_dmean2D"), ptr("dL_dconic_opacity")
+        a.dL_dcolors = ptr("dL_dcolors")
+        a.dL_dcov3D = ptr("dL_dcov3D")
+        a.dL_dcov2D = ptr("dL_dcov2D")
         if wide_sums:
             if getattr(self, "_sums_f64", None) is None or self._sums_f64.shape[0] != n:
                 self._sums_f64 = torch.zeros((n, 12), dtype=torch.float64, device=dev)      # (the library leaves it zero)
             a.sums_f64 = self._sums_f64.data_ptr()
-        a.dL_dshs = out["dL_dshs"].data_ptr() if with_cov3D else None
+        a.dL_dshs = ptr("dL_dshs")
         if with_cov3D:
             a.proj_matrix, a.scales, a.rotations = self._proj.data_ptr(), self.scales.data_ptr(), self.rotations.data_ptr()
             a.scale_modifier = scale_modifier
-            a.dL_dmeans3D, a.dL_dscales = out["dL_dmeans3D"].data_ptr(), out["dL_dscales"].data_ptr()
-            a.dL_drotations = out["dL_drotations"].data_ptr()
+            a.dL_dmeans3D, a.dL_dscales = ptr("dL_dmeans3D"), ptr("dL_dscales")
+            a.dL_drotations = ptr("dL_drotations")
         a.stream = torch.cuda.current_stream(dev).cuda_stream
         if tile_rows is not None:
             a.tile_row_begin, a.tile_row_end = int(tile_rows[0]), int(tile_rows[1])

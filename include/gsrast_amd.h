@@ -267,13 +267,17 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
  *   dL_dconic_opacity vec4[N]  w.r.t. (A, B, C) of power = -0.5 (A dx^2 + C dy^2) - B dx dy, and opacity
  *   dL_dcolors        vec3[N]
  *   dL_dcov2D         vec4[N]  w.r.t. the 2-D covariance, (m00, m01, m11, 0) (optional; what the chain below should start from)
- *   dL_dcov3D         f32[6N]  w.r.t. the six stored covariance numbers (optional: NULL skips the chain)
+ *   dL_dcov3D         f32[6N]  w.r.t. the six stored covariance numbers (optional; without sums_f64, NULL skips the chain)
  *   dL_dshs           f32[48N] colour = 0.5 + 0.4 DC: the DC triple of every Gaussian, = 0.4 dL_dcolors, and zeros in the 13
  *                              floats behind it (one whole 64-byte write per Gaussian; floats 16..47 are not touched);
  *                              optional — a caller that scales dL_dcolors itself saves 0.18 ms of strided writes per frame
  *   dL_dmeans3D       vec4[N]  (x, y, z, 0) through the pixel-space centre and through the Jacobian of cov2D; optional
  *   dL_dscales        vec4[N]  (x, y, z, 0);  dL_drotations vec4[N] w.r.t. the quaternion as given; optional
- *                              (both need dL_dcov3D; not available when the forward call took cov3D_precomp)
+ *                              (not available when the forward call took cov3D_precomp)
+ * Every output is optional once sums_f64 is given (the sums then live there and the float arrays are only copies): a NULL
+ * output is not computed where that saves work and never written. The chain writes 150-odd bytes per Gaussian when all are
+ * asked for; BASELINE config 5's set (dL_dmean2D, dL_dcov3D, dL_dshs) is 96 of them. Without sums_f64 the three arrays of the
+ * sums are required, and dL_dmeans3D / dL_dscales / dL_drotations need dL_dcov3D.
  * Hard tests of the forward (power > 0, alpha < 1/255, transmittance cut-off) select a branch; where
  * alpha is clamped to 0.99 its derivative w.r.t. the Gaussian's parameters is zero. The state pointers are
  * those of the forward call's chunks (gsr_*_from_chunk): it must have run on the same inputs, same size.
@@ -290,19 +294,19 @@ typedef struct gsr_backward_args {
     const float* means2D;          /* geometry chunk */
     const float* conic_opacity;
     const float* colors;           /* geometry rgb, or the colors_precomp the forward call was given */
-    const float* cov3D;            /* geometry cov3D, or the cov3D_precomp given (only with dL_dcov3D) */
-    const int32_t* radii;          /* internal_radii or the radii buffer given (only with dL_dcov3D) */
+    const float* cov3D;            /* geometry cov3D, or the cov3D_precomp given (only for the chain) */
+    const int32_t* radii;          /* internal_radii or the radii buffer given (only for the chain) */
     const uint32_t* ranges;        /* image chunk */
     const uint32_t* n_contrib;
     const float* final_t;          /* accum_alpha */
     const uint32_t* point_list;    /* binning chunk: values (with a receipt: must be the values array of ITS binning chunk) */
-    /* inputs of the forward call that the covariance chain needs again (only with dL_dcov3D) */
+    /* inputs of the forward call that the covariance chain needs again */
     const float* means3D;
     const float* view_matrix;
     float tan_fovx, tan_fovy;
     const float* dL_dout_color;    /* device f32[3 W H], planar like out_color */
     /* outputs (device) */
-    float* dL_dmean2D;
+    float* dL_dmean2D;             /* these three: required without sums_f64, optional with it */
     float* dL_dconic_opacity;
     float* dL_dcolors;
     float* dL_dcov3D;              /* or NULL */
@@ -317,7 +321,7 @@ typedef struct gsr_backward_args {
                                       collects terms of either sign from 8 160 tiles, and in float their order of arrival shows
                                       in the fourth digit of its gradients, differently every run — and rounded to float once;
                                       the float arrays need not be cleared by anybody then */
-    /* chain down to the inputs (all optional; need dL_dcov3D) */
+    /* chain down to the inputs (all optional; without sums_f64 they need dL_dcov3D) */
     const float* proj_matrix;      /* inputs of the forward call */
     const float* scales;
     const float* rotations;

@@ -382,6 +382,51 @@ def test_double_sums_are_reproducible_and_agree_with_the_float_sums():
         assert bool((a[k][culled] == 0).all()), k
 
 
+def test_optional_outputs_give_the_same_numbers_and_leave_the_others_alone():
+    """With sums_f64 every output of gsr_backward is optional (the chain is bound by what it writes): a subset gives the bits
+    the full call gives for its members, the arrays not asked for are not written, the scratch is left zero — for the set
+    BASELINE config 5 names, for the gradients of the inputs alone, and for one array on its own; and the same subset
+    without sums_f64 is refused where the float arrays of the sums would be missing."""
+    import ctypes as C
+    import torch
+    from gsrast_amd import _capi, camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 640, 360
+    scene = scenes.garden_like_scene(50_000, seed=33)
+    scene["means3D"][:, :3] *= 0.3
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    r.draw(camera.default_camera(w, h, near=0.05, far=50.0))
+    dL = torch.randn((3, h, w), generator=torch.Generator().manual_seed(6)).cuda()
+    full = {k: v.clone() for k, v in r.backward(dL).items()}
+    assert all(float(v.abs().max()) > 0 for v in full.values())
+    cache = r._bw_out_by_semantics["gscuda"]
+    for subset in (("dL_dmean2D", "dL_dcov3D", "dL_dshs"),
+                   ("dL_dmean2D", "dL_dconic_opacity", "dL_dshs", "dL_dmeans3D", "dL_dscales", "dL_drotations"),
+                   ("dL_dmeans3D",), ("dL_dcolors",), ("dL_dshs",)):
+        for k, v in cache.items():
+            if k != "dL_dshs":
+                v.fill_(7.0)                                   # (dL_dshs: floats 16..47 are the caller's zeros)
+        got = r.backward(dL, outputs=subset)
+        assert set(got) == set(subset)
+        for k in subset:
+            assert torch.equal(got[k], full[k]), (subset, k)
+        for k, v in cache.items():
+            if k not in subset and k != "dL_dshs":
+                assert bool((v == 7.0).all()), (subset, k)     # not asked for: not written
+        assert float(r._sums_f64.abs().max()) == 0.0
+    with pytest.raises(AssertionError):
+        r.backward(dL, outputs=("dL_dcov3D",), wide_sums=False)
+    # the C ABI itself: without sums_f64 the three arrays of the sums are required
+    a = _capi.BackwardArgs()
+    a.struct_size = C.sizeof(_capi.BackwardArgs)
+    a.num_gaussians, a.width, a.height = r.num_gaussians, w, h
+    for name in ("background", "means2D", "conic_opacity", "colors", "ranges", "n_contrib", "final_t", "dL_dout_color", "point_list"):
+        setattr(a, name, dL.data_ptr())                        # (refused before anything is read)
+    a.dL_dcov3D = cache["dL_dcov3D"].data_ptr()
+    assert r.lib.gsr_backward(C.byref(a)) == _capi.GSR_ERR_INVALID_ARG
+
+
 def test_backward_of_a_frame_without_instances_is_all_zero():
     """R == 0: the forward call leaves even the tile ranges unwritten (GSCuda.cu:775-778); with its receipt gsr_backward
     returns zero gradients instead of walking whatever an earlier frame left in the chunks."""
