@@ -251,56 +251,71 @@ __device__ __forceinline__ UnitInfo locate_unit(uint32_t u, const BlockMeta& met
     return ui;
 }
 
-// lane `lane_select` of lo / hi := the two halves of a 64-bit wave-uniform mask. (One scalar operand
-// per VALU instruction on gfx950: with the value in an SGPR the lane select has to sit in M0.)
-__device__ __forceinline__ void writelane_mask(uint32_t& lo, uint32_t& hi, unsigned long long mask, uint32_t lane_select) {
-    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0\n\t"
-        : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "s"(lane_select));
-}
-
-
-// Coverage masks of one unit, transposed. Lane = entry: per batch of 64 entries, 16 ballots give, for
-// each of the 8 tile columns and 8 tile rows of the block, which entries cover it; v_writelane files
-// them so that lane w of m_lo/m_hi[k] holds the 64-entry mask of batch w (k = column 0..7 | 8 + row).
-// Coverage of tile (c, r) by batch w is then m[c] & m[8 + r]: a rectangle is a column range x a row range.
-__device__ __forceinline__ void build_unit_masks(const uint32_t* __restrict__ ent_rd32, uint32_t e0, uint32_t e1, uint32_t bx0,
-                                                 uint32_t by0, uint32_t (&m_lo)[16], uint32_t (&m_hi)[16]) {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
+// Coverage masks of one unit, transposed: for each of the 8 tile columns and 8 tile rows of the block (k = column 0..7 |
+// 8 + row) and each batch w of 64 entries, the 64-bit mask of the batch's entries that cover it. Coverage of tile (c, r)
+// by batch w is then m[c][w] & m[8 + r][w]: a rectangle is a column range x a row range.
+// Lane = entry on the way in: every entry's 16 coverage bits go to LDS as a half-word. Lane = (batch w, half h) on the way
+// out: it reads the 32 half-words of its half batch as 16 dwords and transposes them in its registers — a packed pair of
+// 16 x 16 bit-matrix transposes, four rounds of eight masked swaps — into the 16 half masks it owns. (Sixteen ballots per
+// batch, each filed with two v_writelane, were 2 000 vector instructions per unit; this is 200, on all 64 lanes.)
+// The entries of a half batch are stored so that dword i pairs entry i (low half-word) with entry i + 16: then dword k
+// after the transpose IS the 32-bit mask of column / row k, entry i at bit i.
+__device__ __forceinline__ void transpose_16x16_pairs(uint32_t (&d)[16]) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m_lo[k] = m_hi[k] = 0u;
-    // all of the unit's rectangles are fetched up front: one memory round trip, not one per batch
-    const uint32_t nbatch = (e1 - e0 + kWave - 1) / kWave;
-    uint32_t rects[kBatches];
+    for (int round = 0; round < 4; ++round) {
+        const int sh = 8 >> round;
+        const uint32_t m = round == 0 ? 0x00FF00FFu : (round == 1 ? 0x0F0F0F0Fu : (round == 2 ? 0x33333333u : 0x55555555u));
 #pragma unroll
-    for (int w = 0; w < kBatches; ++w) {
-        const uint32_t i = e0 + (uint32_t)w * kWave + lane;
-        rects[w] = (i < e1) ? ent_rd32[2 * (size_t)i] : 0u;
-    }
-#pragma unroll
-    for (int w = 0; w < kBatches; ++w) {
-        if ((uint32_t)w >= nbatch) continue;
-        const uint32_t rect = rects[w];
-        const uint32_t x0 = rect & 0xFFu, rw = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, rh = rect >> 24;
-        const uint32_t cx0 = max(x0, bx0) - bx0, cx1 = min(x0 + rw, bx0 + kBW) - bx0;
-        const uint32_t cy0 = max(y0, by0) - by0, cy1 = min(y0 + rh, by0 + kBH) - by0;
-        // bits 0..7: tile columns covered, bits 8..15: tile rows covered (0 for lanes past the end)
-        uint32_t bits = (((1u << (cx1 - cx0)) - 1u) << cx0) | (((1u << (cy1 - cy0)) - 1u) << (cy0 + 8u));
-        bits = rect ? bits : 0u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const unsigned long long m = __ballot((bits >> k) & 1u);
-            writelane_mask(m_lo[k], m_hi[k], m, w);
+        for (int i = 0; i < 16; ++i) {
+            if (i & sh) continue;
+            const uint32_t t = ((d[i] >> sh) ^ d[i + sh]) & m;
+            d[i + sh] ^= t;
+            d[i] ^= t << sh;
         }
     }
 }
 
+// Sums of 32 per-lane values over the 64 lanes, all at once: lane l returns the total of x[l >> 1]. Every fold halves the
+// registers while it halves the lanes a value lives in: v_permlane32_swap / v_permlane16_swap (gfx950) for the lane bits 5
+// and 4, then a select and one DPP add per pair of registers (row_ror:8, row_half_mirror, two quad permutations). 70
+// instructions where 32 separate prefix sums with their read-backs took 400. (No carries between packed fields expected.)
+__device__ __forceinline__ uint32_t wave_sums_of_32(uint32_t (&x)[32]) {
+    const int lane = threadIdx.x & (kWave - 1);
+#define GSR_DPP_U(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xf, 0xf, false))
+    uint32_t y[16], z[8], u[4], v[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {               // lanes 0-31: x[i] (lanes l and l + 32 added); lanes 32-63: x[i + 16]
+        const auto r = __builtin_amdgcn_permlane32_swap(x[i], x[i + 16], false, false);
+        y[i] = r[0] + r[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                // rows of 16 lanes: x[i], x[i + 8], x[i + 16], x[i + 24]
+        const auto r = __builtin_amdgcn_permlane16_swap(y[i], y[i + 8], false, false);
+        z[i] = r[0] + r[1];
+    }
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (b3 ? z[i + 4] : z[i]) + GSR_DPP_U(b3 ? z[i] : z[i + 4], 0x128);     // row_ror:8
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = (b2 ? u[i + 2] : u[i]) + GSR_DPP_U(b2 ? u[i] : u[i + 2], 0x141);     // row_half_mirror
+    uint32_t w = (b1 ? v[1] : v[0]) + GSR_DPP_U(b1 ? v[0] : v[1], 0x4E);                                    // quad_perm [2,3,0,1]
+    w += GSR_DPP_U(w, 0xB1);                                                                                 // quad_perm [1,0,3,2]
+#undef GSR_DPP_U
+    return w;
+}
+
 // Per unit: the transposed coverage masks (kept for the emission kernel, 4 KB per unit) and, from
-// their bit counts, the keys per tile of the block. Persistent waves, units from a ticket counter.
+// their bit counts, the keys per tile of the block.
 __global__ __launch_bounds__(256) void unit_masks_kernel(BlockMeta meta, int nb, int nbx, const uint64_t* __restrict__ ent_rd,
                                                          uint2* __restrict__ unit_masks, uint32_t* __restrict__ cnt) {
-    const int lane = threadIdx.x & (kWave - 1);
+    __shared__ uint16_t s_bits[256 / kWave][kUnit];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t total = meta.unit_start()[meta.nbp];
     const uint32_t* ent_rd32 = reinterpret_cast<const uint32_t*>(ent_rd);
+    // where this lane's entry of a batch goes (see above), and which half batch it owns on the way out
+    const uint32_t q = (uint32_t)lane & 31u;
+    uint16_t* const put = s_bits[wave] + (((uint32_t)lane & 32u) | ((q & 15u) << 1) | (q >> 4));
+    const uint4* const take = reinterpret_cast<const uint4*>(s_bits[wave] + 64u * q + ((uint32_t)lane & 32u));
     // units cost the same here (<= 2048 entries each): dealt round-robin, no work queue (thousands of
     // waves taking tickets from one counter serialise on it for longer than the kernel's own work)
     const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
@@ -308,26 +323,46 @@ __global__ __launch_bounds__(256) void unit_masks_kernel(BlockMeta meta, int nb,
         const UnitInfo ui = locate_unit(u, meta, nb, nbx);
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e0);
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ui.e1);
-        uint32_t m_lo[16], m_hi[16];
-        build_unit_masks(ent_rd32, e0, e1, ui.bx * kBW, ui.by * kBH, m_lo, m_hi);
-        if (lane < kBatches) {
-            uint2* dst = unit_masks + (size_t)u * 16 * kBatches + lane;
+        const uint32_t bx0 = ui.bx * kBW, by0 = ui.by * kBH;
+        // all of the unit's rectangles are fetched up front: one memory round trip, not one per batch
+        uint32_t rects[kBatches];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) dst[k * kBatches] = make_uint2(m_lo[k], m_hi[k]);
+        for (int w = 0; w < kBatches; ++w) {
+            const uint32_t i = e0 + (uint32_t)w * kWave + (uint32_t)lane;
+            rects[w] = (i < e1) ? ent_rd32[2 * (size_t)i] : 0u;
         }
-        // keys per tile = bits of (column mask & row mask) summed over the batches (lanes); two tiles of
-        // one tile row share a 32-lane DPP prefix, 16 bits each (<= 2048 keys per tile and unit)
-        uint32_t out = 0;
+#pragma unroll
+        for (int w = 0; w < kBatches; ++w) {
+            const uint32_t rect = rects[w];
+            const uint32_t x0 = rect & 0xFFu, rw = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, rh = rect >> 24;
+            const uint32_t cx0 = max(x0, bx0) - bx0, cx1 = min(x0 + rw, bx0 + kBW) - bx0;
+            const uint32_t cy0 = max(y0, by0) - by0, cy1 = min(y0 + rh, by0 + kBH) - by0;
+            // bits 0..7: tile columns covered, bits 8..15: tile rows covered (0 for lanes past the end)
+            const uint32_t bits = (((1u << (cx1 - cx0)) - 1u) << cx0) | (((1u << (cy1 - cy0)) - 1u) << (cy0 + 8u));
+            put[w * kWave] = (uint16_t)(rect ? bits : 0u);
+        }
+        // (wave-private LDS: the writes above and the reads below are ordered inside the wave)
+        uint32_t d[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = take[i];
+            d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+        }
+        transpose_16x16_pairs(d);
+        // lane (w, h) holds half h of the 64-bit mask of batch w: the uint2 of (k, w) is written by two lanes
+        uint32_t* dst = reinterpret_cast<uint32_t*>(unit_masks + (size_t)u * 16 * kBatches) + 2u * q + ((uint32_t)lane >> 5);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dst[k * 2 * kBatches] = d[k];
+        // keys per tile = bits of (column mask & row mask) summed over the half batches (lanes); the two tiles 2 p, 2 p + 1
+        // of a tile row share a sum, 16 bits each (<= 2048 keys per tile and unit)
+        uint32_t x[32];
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
             const int c0 = (2 * p) & 7, r = 8 + ((2 * p) >> 3);
-            const uint32_t k0 = (uint32_t)__popc(m_lo[c0] & m_lo[r]) + (uint32_t)__popc(m_hi[c0] & m_hi[r]);
-            const uint32_t k1 = (uint32_t)__popc(m_lo[c0 + 1] & m_lo[r]) + (uint32_t)__popc(m_hi[c0 + 1] & m_hi[r]);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)prefix32_inclusive(k0 | (k1 << 16)), 31);
-            out = (lane == 2 * p) ? (tot & 0xFFFFu) : out;
-            out = (lane == 2 * p + 1) ? (tot >> 16) : out;
+            x[p] = (uint32_t)__popc(d[c0] & d[r]) | ((uint32_t)__popc(d[c0 + 1] & d[r]) << 16);
         }
-        cnt[(size_t)u * 64 + lane] = out;
+        const uint32_t pair = wave_sums_of_32(x);      // lane l: tiles 2 (l >> 1), 2 (l >> 1) + 1 = l & ~1, l | 1
+        cnt[(size_t)u * 64 + lane] = (lane & 1) ? (pair >> 16) : (pair & 0xFFFFu);
     }
 }
 
