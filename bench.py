@@ -299,6 +299,7 @@ class Runner:
             self.step(cam, **kw)
         self.sync_all()
         out["elapsed"] = time.perf_counter() - t0
+        out["tiles_reordered"] = bool(rast.last_tiles_reordered)
         # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
         # every stage cost a few tens of microseconds per frame, which the timed frames do not pay).
         prof_steps = max(5, min(steps, 20))
@@ -501,7 +502,8 @@ def main() -> int:
                      and not args.overlap and not args.no_sorted_lists and not args.colors_precomp)
     extras = {}
     if not args.no_extras and default_frame:
-        short = dict(steps=max(5, min(args.steps, 15)), warmup=3)
+        # (6 warm-up frames: the library notices within five that a new viewpoint ends on a few slow tiles — GSR_FLAG_NO_TILE_HISTORY)
+        short = dict(steps=max(5, min(args.steps, 15)), warmup=6)
         if not distributed:
             # (a) the same scene from outside the cloud (">= 1 in-scene pose" besides the default one)
             cam_out = camera.default_camera(W, H, near=near, far=far, position=(0.0, 0.0, -14.0))
@@ -625,6 +627,7 @@ def main() -> int:
                        "band_exchange": ({"transport": run.exch.transport, "gather": args.gather, "note": run.exch.transport_note}
                                          if distributed else None),
                        "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
+                       "slow_tiles_first": m.get("tiles_reordered", False),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
@@ -675,7 +678,7 @@ def brief(e, n_splats, what):
     return {"what": what, "ms_per_step": round(e["ms_per_step"], 4), "fps": round(1e3 / e["ms_per_step"], 2),
             "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
             "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],
-            "blend_from_sorted_lists": e["blend_from_lists"],
+            "blend_from_sorted_lists": e["blend_from_lists"], "slow_tiles_first": e.get("tiles_reordered", False),
             "sorted_lists_written": e["lists_written"], "stage_ms": {k: round(v, 4) for k, v in e["stage_ms"].items() if v > 0}}
 
 

@@ -118,7 +118,7 @@ constexpr uint32_t kAsyncSlots = 64;       // error-word slots handed out in tur
 constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned block
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
-    uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
+    uint32_t* host = nullptr;          // [0..2] tile_order_kernel's statistics {fresh, longest tile, mean}, [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
                                        // byte, [12] side keys as the scan counted them, [13] as the compaction listed them (all written by the
                                        // kernels that compute them), [8..9] staged count;
                                        // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
@@ -151,6 +151,23 @@ struct Readback {
             staged_host = reinterpret_cast<unsigned long long*>(host + 8);
         }
         if (!ev_r) GSR_HIP_TRY(hipEventCreateWithFlags(&ev_r, hipEventDisableTiming));
+        return GSR_OK;
+    }
+    // longest tiles first (TileOrder, blend_core.hpp): what the tiles of this thread's last call on this device took, and
+    // the order this call's blend takes them in
+    uint32_t* tile_ticks = nullptr;
+    uint32_t* tile_order = nullptr;
+    int hist_dims[4] = {0, 0, 0, 0};          // width, height, tile rows [begin, end) the ticks belong to
+    bool hist_wanted = false;                 // the last statistics say the frame ends on a few slow tiles
+    uint32_t hist_calls = 0;                  // calls since the ticks were last cleared
+    hipEvent_t ev_hist_join = nullptr;
+    int ensure_history() {
+        { const int rc = ensure_side(); if (rc != GSR_OK) return rc; }
+        if (!tile_ticks) {
+            GSR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tile_ticks), sizeof(uint32_t) * kTileOrderMax));
+            GSR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tile_order), sizeof(uint32_t) * kTileOrderMax));
+            GSR_HIP_TRY(hipEventCreateWithFlags(&ev_hist_join, hipEventDisableTiming));
+        }
         return GSR_OK;
     }
     int ensure_staged() {
@@ -417,6 +434,33 @@ int gsr_forward(gsr_forward_args* a) {
     for (bool& r : g_rb.recorded) r = false;
     for (int s = 0; s < GSR_NUM_STAGES; ++s) g_rb.begin_of[s] = 2 * s;
 
+    // Longest tiles first (TileOrder, blend_core.hpp): the order of this call's blend workgroups is sorted from the ticks of
+    // the last call while the preprocess runs, on the library's second stream. A call of another size starts from zeros
+    // (= patch order).
+    static const bool history_env = [] { const char* e = getenv("GSR_TILE_HISTORY"); return !(e && e[0] == '0'); }();
+    const bool history = history_env && !(a->flags & GSR_FLAG_NO_TILE_HISTORY) && tile_order_workgroups(d) <= kTileOrderMax &&
+                         d.grid_x * d.grid_y <= kTileOrderMax;
+    // The order costs a launch on the second stream and the host a few microseconds, and it pays on frames that END on a
+    // few slow tiles: it is sorted when the last statistics (host words 0-2, left by tile_order_kernel: fresh, the longest
+    // tile and the mean) say the longest tile takes 2.5 times what the tiles would take spread evenly over the chip's
+    // 5 120 wave slots — and every fourth call, to have fresh statistics (a camera that leaves the cloud is noticed within
+    // five frames). The ticks are recorded by every call.
+    bool order_now = false;
+    if (history) {
+        GSR_STEP(g_rb.ensure_history());
+        const int dims_now[4] = {a->width, a->height, d.row_begin, d.row_end};
+        if (memcmp(dims_now, g_rb.hist_dims, sizeof(dims_now)) != 0) {
+            GSR_HIP_TRY(hipMemsetAsync(g_rb.tile_ticks, 0, sizeof(uint32_t) * (size_t)(d.grid_x * d.grid_y), stream));
+            memcpy(g_rb.hist_dims, dims_now, sizeof(dims_now));
+            g_rb.hist_wanted = false; g_rb.hist_calls = 0; g_rb.host[0] = 0;
+        }
+        if (g_rb.host[0] != 0u) {
+            const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
+            g_rb.hist_wanted = 2ull * 5120ull * g_rb.host[1] > 5ull * tiles * g_rb.host[2];
+            g_rb.host[0] = 0;
+        }
+        order_now = g_rb.hist_wanted || (g_rb.hist_calls++ % 4u) == 1u;       // (call 0 has no ticks yet)
+    }
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (inria)
@@ -469,6 +513,13 @@ int gsr_forward(gsr_forward_args* a) {
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
     GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
                              xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
+    if (order_now) {
+        // (behind the same event — it follows the last call's blend in stream order — and queued while the host would
+        // only wait: nothing is added to the caller's stream, and by the time the blend is launched the order is there)
+        GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_r, 0));
+        GSR_STEP(launch_tile_order(d, g_rb.tile_ticks, g_rb.tile_order, g_rb.host_dev, g_rb.side));
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_hist_join, g_rb.side));
+    }
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
     // the binning chunk by the wrapped count while the emission writes per true count. Refused before anything
@@ -634,15 +685,23 @@ int gsr_forward(gsr_forward_args* a) {
     }
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     hipStream_t blend_stream = forked ? g_rb.side : stream;
+    // (the order: long since sorted — the blend's stream is made to wait only if it is not)
+    if (order_now && hipEventQuery(g_rb.ev_hist_join) != hipSuccess) {
+        (void)hipGetLastError();                              // ("not ready" is no error of this call)
+        GSR_HIP_TRY(hipStreamWaitEvent(blend_stream, g_rb.ev_hist_join, 0));
+    }
+    const uint32_t* const t_order = order_now ? g_rb.tile_order : nullptr;
+    if (order_now) a->plan_used |= GSR_PLAN_TILES_REORDERED;
+    uint32_t* const t_ticks = history ? g_rb.tile_ticks : nullptr;
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)
         GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
                                      colors, geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color,
-                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, blend_stream));
+                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, blend_stream, t_order, t_ticks));
     else
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                              t_cutoff, blend_stream, gs.sort_info + 4, R));                         // :804-810
+                              t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks));       // :804-810
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));

@@ -409,6 +409,28 @@ __device__ __forceinline__ void set_tile_priority(uint32_t remaining) {
 // 0.116 ms, from outside the cloud 0.668 -> 0.663 ms, the blend-bound frame 2.06 -> 1.95 ms. Larger patches trade the short
 // frames for the long ones (4 x 4: 0.116 -> 0.121 ms and 2.03 -> 1.79 ms; 8 x 4: 0.117 -> 0.120 ms and 2.06 -> 1.73 ms).
 constexpr int kPatchW = 4, kPatchH = 2, kPatchTiles = kPatchW * kPatchH;
+
+// Longest tiles first. A frame's blend lasts as long as its slowest tiles, one wave each; which ones those are nobody knows
+// in advance (not the length of the list: the pixels of an opaque centre saturate early) — except from the frame before: a
+// camera moves little between two frames. Every tile's wave leaves how long it ran (`ticks`, quantised, library-owned memory
+// that outlives the call); in the next call of the same size tile_order_kernel puts the workgroup numbers of the slow ones
+// in front of the patch order above, longest first (`order`), beside the depth sort on a second stream, and the blend's
+// workgroup i takes the tile of workgroup order[i]. The image does not depend on it (every tile is composited
+// as before, only sooner or later); a first frame, a new size or stale ticks give some other valid order — all ticks equal:
+// the patch order itself. Measured with the tiles ordered by their own frame's times (`profiles/r04_blend_tile_times.txt`):
+// blend 0.470 -> 0.431 ms from (0,0,-14), 0.609 -> 0.532 from (0,0,-30), 0.212 -> 0.164 from (0,0,-9) on the sort plan,
+// 3.24 -> 3.01 with faint splats; a random order costs 5-28 % (the neighbours' records in the XCD's L2).
+struct TileOrder {
+    const uint32_t* order = nullptr;   // [workgroups of one wave per tile] or null: patch order
+    uint32_t* ticks = nullptr;         // [tiles of the frame] (units of 10 ns) or null: nothing recorded
+};
+// ~6 % steps (4 mantissa bits): tiles that took about as long keep their patch order among themselves
+__device__ __forceinline__ uint32_t quantise_ticks(uint32_t t) {
+    if (t < 16u) return t;
+    const uint32_t e = 31u - (uint32_t)__clz((int)t);           // >= 4
+    return min(511u, ((e - 3u) << 4) | ((t >> (e - 4u)) & 15u));
+}
+__device__ __forceinline__ uint32_t tile_clock() { return (uint32_t)wall_clock64(); }     // 100 MHz
 // workgroups to launch for a band of `rows` tile rows (the patch grid is padded to whole groups of eight patches)
 __host__ __device__ inline int patch_workgroups(int grid_x, int rows) {
     const int patches = ((grid_x + kPatchW - 1) / kPatchW) * ((rows + kPatchH - 1) / kPatchH);

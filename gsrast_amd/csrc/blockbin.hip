@@ -683,13 +683,16 @@ struct BlockBlendParams {
     FrameDims dims;
     int num_tiles;
     int waves_per_tile;          // 1, or 4 (one 16 x 4 strip per wave) when the call has few tiles
+    TileOrder history;           // longest tiles first (blend_core.hpp)
 };
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_blocks_kernel(const BlockBlendParams p) {
     __shared__ StagedRecords s_staged;
     exp_table_init(s_staged.exp_tab, (int)threadIdx.x);      // (wave-private LDS: ordered inside the wave)
+    const uint32_t clock_begin = tile_clock();
     const int wpt = p.waves_per_tile;
-    const int tile_local = tile_of_workgroup((int)blockIdx.x / wpt, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    const int wg = (int)blockIdx.x / wpt;
+    const int tile_local = tile_of_workgroup(p.history.order ? (int)p.history.order[wg] : wg, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
     if (tile_local < 0) return;
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
@@ -761,6 +764,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void
     // for that part of the list only)
     const uint32_t units = it_u - u0 + (it_loaded ? 1u : 0u);
     if (lane == 0 && units != 0u) atomicMax(&p.meta.walked()[b], units);
+    if (p.history.ticks && lane == 0 && (int)blockIdx.x % wpt == 0) p.history.ticks[tile] = tile_clock() - clock_begin;
 }
 
 }  // namespace
@@ -901,9 +905,11 @@ int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo
 int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
                         const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
-                        unsigned long long* staged_counter, float t_cutoff, hipStream_t stream) {
+                        unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
+                        const uint32_t* tile_order, uint32_t* tile_ticks) {
     const PlanTables t = plan_tables(n, d.grid_x, d.grid_y, r_total, geo_scratch, bin_scratch);
     BlockBlendParams p;
+    p.history.order = tile_order; p.history.ticks = tile_ticks;
     p.meta = t.meta;
     p.nbx = t.nbx;
     p.unit_masks = t.unit_masks;

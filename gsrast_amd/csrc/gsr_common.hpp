@@ -124,7 +124,8 @@ int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo
 int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
                         const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
-                        unsigned long long* staged_counter, float t_cutoff, hipStream_t stream);
+                        unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
+                        const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr);
 
 // nonempty (may be null): device word, zero before the launch; receives the number of tiles that got a list
 int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream,
@@ -134,7 +135,12 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
-                 const uint32_t* nonempty_tiles = nullptr, uint32_t num_rendered = 0);      // (both: see blend.hip, four waves per tile)
+                 const uint32_t* nonempty_tiles = nullptr, uint32_t num_rendered = 0,       // (both: see blend.hip, four waves per tile)
+                 const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr);      // (longest tiles first: TileOrder, blend_core.hpp)
+// Longest tiles first: the order of this call's blend workgroups from the ticks the tiles of the call before left.
+constexpr int kTileOrderMax = 32768;      // workgroups (one per tile, patch grid padded) up to which the order is kept: 128 KB of LDS for its sort
+int tile_order_workgroups(const FrameDims& d);
+int launch_tile_order(const FrameDims& d, const uint32_t* ticks, uint32_t* order, uint32_t* stats, hipStream_t stream);
 
 int launch_exp_test(int n, const float* in, float* out, hipStream_t stream);
 int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,

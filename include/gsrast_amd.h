@@ -128,10 +128,22 @@ enum {
  * Pixels, ranges, finalT, nContrib and numRendered are unchanged. Ignored under the other plans, whose blend
  * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
 #define GSR_FLAG_NO_SORTED_LISTS 0x40u
+/* The blend starts the tiles that took longest in the calling thread's PREVIOUS call of the same size on this device first
+ * (a frame lasts as long as its slowest tiles, and a camera moves little between two frames): every tile's wave leaves how
+ * long it ran in a small buffer the library owns, and the next call sorts its workgroups by it beside the preprocess, on a
+ * stream of the library's. Outputs do not depend on it — the same tiles are composited the same way, sooner or later —
+ * and a first call, a new size or another scene simply find an order that helps less. The order is only made when the
+ * statistics of the calls before say the frame ends on a few slow tiles (the camera outside the cloud: blend 0.61 -> 0.53
+ * ms from (0,0,-30) on the bench scene), and every fourth call to keep them fresh. This flag switches all of it off: the
+ * call then neither reads nor writes that buffer and uses no second stream for it (the environment variable
+ * GSR_TILE_HISTORY=0 does the same for every call of the process). */
+#define GSR_FLAG_NO_TILE_HISTORY 0x80u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
        GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer
-                                            than 48 instances per visible Gaussian), not the block lists */ };
+                                            than 48 instances per visible Gaussian), not the block lists */,
+       GSR_PLAN_TILES_REORDERED = 0x400 /* or-ed in: the blend started the slow tiles of the call before first
+                                           (see GSR_FLAG_NO_TILE_HISTORY; informational) */ };
 
 /* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
  * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this

@@ -1,0 +1,92 @@
+"""GPU: the blend starts the slow tiles of the call before first (GSR_FLAG_NO_TILE_HISTORY, csrc/blend_core.hpp TileOrder).
+Only WHEN a tile is composited may depend on it: every output must be the bits a call without the history gives, with fresh,
+stale and foreign ticks, on a band of tile rows, after a change of size, and with the tiles' pixels filled with garbage
+beforehand (a tile the order left out would otherwise show the previous frame's correct pixels)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(r):
+    st = r.map_image_state()
+    return r.out_color.clone(), st["finalT"].clone(), st["nContrib"].clone()
+
+
+def _draw_poisoned(r, cam, **kw):
+    r.out_color.fill_(float("nan"))
+    st = r.map_image_state()
+    st["finalT"].fill_(-7.0)
+    st["nContrib"].fill_(-7)
+    r.draw(cam, **kw)
+    return _state(r)
+
+
+def _same(a, b):
+    import torch
+    return all(torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
+               for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("plan", ["sort", "blocks"])
+def test_reordered_tiles_give_the_same_frame(plan):
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 640, 368
+    scene = scenes.garden_like_scene(120_000, seed=71)
+    scene["means3D"][:, :3] *= 0.35
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    cams = [camera.default_camera(w, h, near=0.05, far=60.0, position=p) for p in ((0.0, 0.0, -6.0), (0.3, -0.2, -3.0), (0.0, 0.0, -12.0))]
+    r.draw(cams[0], plan=plan, tile_history=False)                 # (the chunks exist from here on)
+    refs = [_draw_poisoned(r, c, plan=plan, tile_history=False) for c in cams]
+    assert not r.last_tiles_reordered
+    assert all(bool(torch.isfinite(ref[0]).all()) for ref in refs)
+    reordered = 0
+    # fresh ticks (same camera several times), then stale ones (the camera jumps), then a band of tile rows
+    for c, ref in ((0, refs[0]),) * 7 + ((1, refs[1]),) * 3 + ((2, refs[2]),) * 6 + ((0, refs[0]),) * 2:
+        got = _draw_poisoned(r, cams[c], plan=plan)
+        reordered += int(r.last_tiles_reordered)
+        assert _same(got, ref), (plan, c)
+    # (a frame of 920 tiles cannot fill 5 120 wave slots: its longest tile always counts as slow, the order is in use)
+    assert reordered >= 8, reordered
+    rows = (5, 17)
+    band_ref = r.draw(cams[0], plan=plan, tile_rows=rows, tile_history=False).clone()
+    for _ in range(6):
+        r.out_color.fill_(float("nan"))
+        band = r.draw(cams[0], plan=plan, tile_rows=rows)
+        assert torch.equal(band[:, 16 * rows[0]:16 * rows[1]].view(torch.int32), band_ref[:, 16 * rows[0]:16 * rows[1]].view(torch.int32))
+    # another size in between (its own ticks; the first object's are cleared when it comes back)
+    r2 = SplatRasterizer(320, 208, background=(0.0, 0.0, 0.0))
+    r2.configure_from_scene(scene)
+    cam2 = camera.default_camera(320, 208, near=0.05, far=60.0, position=(0.0, 0.0, -6.0))
+    r2.draw(cam2, tile_history=False)
+    ref2 = _draw_poisoned(r2, cam2, tile_history=False)
+    for _ in range(5):
+        assert _same(_draw_poisoned(r2, cam2), ref2)
+        assert _same(_draw_poisoned(r, cams[0], plan=plan), refs[0])
+
+
+def test_backward_after_a_reordered_frame_is_unchanged():
+    """gsr_backward reads what the forward call left (finalT, nContrib, the lists): none of it depends on the order of the tiles."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 480, 272
+    scene = scenes.garden_like_scene(60_000, seed=72)
+    scene["means3D"][:, :3] *= 0.3
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    cam = camera.default_camera(w, h, near=0.05, far=50.0)
+    dL = torch.randn((3, h, w), generator=torch.Generator().manual_seed(9)).cuda()
+    r.draw(cam, tile_history=False)
+    ref = {k: v.clone() for k, v in r.backward(dL).items()}
+    seen = False
+    for _ in range(6):
+        r.draw(cam)
+        seen = seen or r.last_tiles_reordered
+        got = r.backward(dL)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+    assert seen
