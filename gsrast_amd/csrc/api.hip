@@ -441,7 +441,7 @@ int gsr_forward(gsr_forward_args* a) {
     const bool history = history_env && !(a->flags & GSR_FLAG_NO_TILE_HISTORY) && tile_order_workgroups(d) <= kTileOrderMax &&
                          d.grid_x * d.grid_y <= kTileOrderMax;
     // The order costs a launch on the second stream and the host a few microseconds, and it pays on frames that END on a
-    // few slow tiles: it is sorted when the last statistics (host words 0-2, left by tile_order_kernel: fresh, the longest
+    // few slow tiles and on light frames: it is sorted when the last statistics (host words 0-2, left by tile_order_kernel: fresh, the longest
     // tile and the mean) say the longest tile takes 2.5 times what the tiles would take spread evenly over the chip's
     // 5 120 wave slots — and every fourth call, to have fresh statistics (a camera that leaves the cloud is noticed within
     // five frames). The ticks are recorded by every call.
@@ -456,7 +456,8 @@ int gsr_forward(gsr_forward_args* a) {
         }
         if (g_rb.host[0] != 0u) {
             const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
-            g_rb.hist_wanted = 2ull * 5120ull * g_rb.host[1] > 5ull * tiles * g_rb.host[2];
+            g_rb.hist_wanted = 2ull * 5120ull * g_rb.host[1] > 5ull * tiles * g_rb.host[2] ||
+                               (g_rb.host[2] != 0u && tiles * g_rb.host[2] < kLightFrameTicks);      // (or a light frame: tile_order_kernel)
             g_rb.host[0] = 0;
         }
         order_now = g_rb.hist_wanted || (g_rb.hist_calls++ % 4u) == 1u;       // (call 0 has no ticks yet)

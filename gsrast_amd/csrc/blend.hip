@@ -135,10 +135,12 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
 
 // Workgroup numbers of the patch order, the SLOW tiles of the frame before first — those that took more than twice the
 // mean, longest first — and everybody else behind them in patch order: one workgroup, a bitonic sort of (class, workgroup)
-// in LDS. (All tiles sorted by their time, or the slow ones from 0.5 to 1.5 times the mean, measured on ten frames: the
-// frames that end on a few slow tiles gain more — bench frame 0.136 -> 0.112 ms, (0,0,-9) 0.221 -> 0.162 — but frames
-// whose tiles all take long lose 6-19 %: neighbours no longer run together on one XCD's L2. From twice the mean nobody
-// loses.) The padding of the patch grid sorts to the end. `stats` (pinned host words): the longest tile and the mean.
+// in LDS. All tiles sorted by their time (or the slow ones counted from 0.5 to 1.5 times the mean), measured on ten frames:
+// the frames of short lists gain more — bench frame 0.136 -> 0.112 ms, (0,0,-9) 0.221 -> 0.162, (0,0,-14) 0.46 -> 0.42 —
+// but the frames whose tiles all take long lose 6-19 % ((0,0,-20), faint splats, 4K from outside): neighbours no longer run
+// together on one XCD's L2. What separates the two groups on every frame measured is the tile time per wave slot (78-243
+// us against 313-2 131 us): below 250 us the frame is sorted whole, above it only the tiles beyond twice the mean move —
+// there nobody loses. The padding of the patch grid sorts to the end. `stats` (pinned host words): the longest tile, the mean.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ticks, uint32_t* __restrict__ order,
                                                           int workgroups, int padded, int grid_x, int row_begin, int rows,
                                                           uint32_t* __restrict__ stats) {
@@ -157,7 +159,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
     atomicAdd(&s_cnt, cnt);
     atomicMax(&s_max, mx);
     __syncthreads();
-    const unsigned long long slow_from = 2ull * s_sum / max(s_cnt, 1u);
+    // (a LIGHT frame — less than 250 us of tile time per wave slot — is sorted whole: its lists are short, it lasts as long as
+    // its longest tiles whatever the neighbours do; see kLightFrameTicks)
+    const unsigned long long slow_from = s_sum < kLightFrameTicks ? 0ull : 2ull * s_sum / max(s_cnt, 1u);
     // what the host decides on whether the next calls need an order at all: {longest tile, mean, fresh}
     if (stats && threadIdx.x == 0) { stats[1] = s_max; stats[2] = (uint32_t)(s_sum / max(s_cnt, 1u)); __threadfence_system(); stats[0] = 1u; }
     for (int i = threadIdx.x; i < padded; i += 1024) {

@@ -139,6 +139,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr);      // (longest tiles first: TileOrder, blend_core.hpp)
 // Longest tiles first: the order of this call's blend workgroups from the ticks the tiles of the call before left.
 constexpr int kTileOrderMax = 32768;      // workgroups (one per tile, patch grid padded) up to which the order is kept: 128 KB of LDS for its sort
+constexpr unsigned long long kLightFrameTicks = 25000ull * 5120ull;   // 250 us (in 10 ns) per wave slot of the chip, summed over the tiles
 int tile_order_workgroups(const FrameDims& d);
 int launch_tile_order(const FrameDims& d, const uint32_t* ticks, uint32_t* order, uint32_t* stats, hipStream_t stream);
 
