@@ -158,6 +158,7 @@ struct Readback {
     uint32_t* tile_ticks = nullptr;
     uint32_t* tile_order = nullptr;
     int hist_dims[4] = {0, 0, 0, 0};          // width, height, tile rows [begin, end) the ticks belong to
+    uint32_t order_serial = 0;                // the call whose blend took tile_order (0: none)
     bool hist_wanted = false;                 // the last statistics say the frame ends on a few slow tiles
     uint32_t hist_calls = 0;                  // calls since the ticks were last cleared
     hipEvent_t ev_hist_join = nullptr;
@@ -193,6 +194,13 @@ int current_readback(Readback*& out) {
 }
 
 }  // namespace
+
+const uint32_t* tile_order_of_call(uint32_t serial, int width, int height, int row_begin, int row_end) {
+    Readback* rb = nullptr;
+    if (current_readback(rb) != GSR_OK || !rb->tile_order || serial == 0u || rb->order_serial != serial) return nullptr;
+    const int dims[4] = {width, height, row_begin, row_end};
+    return memcmp(dims, rb->hist_dims, sizeof(dims)) == 0 ? rb->tile_order : nullptr;
+}
 
 // What a gsr_backward call may read of the forward call that issued `r` (see gsr_backward_args.receipt): derived from
 // the receipt and the chunk layouts alone — no state of this library is consulted, so any host thread may ask, after any
@@ -693,6 +701,7 @@ int gsr_forward(gsr_forward_args* a) {
     }
     const uint32_t* const t_order = order_now ? g_rb.tile_order : nullptr;
     if (order_now) a->plan_used |= GSR_PLAN_TILES_REORDERED;
+    g_rb.order_serial = order_now ? serial : 0u;
     uint32_t* const t_ticks = history ? g_rb.tile_ticks : nullptr;
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)

@@ -41,6 +41,7 @@ struct RenderBackwardParams {
     double* sums64;             // f64[12 N] or null: the twelve sums of every Gaussian, accumulated in double instead of in the four arrays above
     FrameDims dims;
     int num_tiles;
+    const uint32_t* tile_order;  // the forward blend's workgroup order (slow tiles first), or null: patch order
 };
 
 // Sums of TWELVE per-lane values over the 64 lanes in about half the steps of twelve separate reductions: v_permlane32_swap
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) void render_backward_kernel(const RenderBackwar
     exp_table_init(s_exp, (int)threadIdx.x);       // (wave-private LDS: ordered inside the wave)
 
     // (tiles dealt to the XCDs in patches, as in the forward blend: blend_core.hpp)
-    const int tile_local = tile_of_workgroup((int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    const int tile_local = tile_of_workgroup(p.tile_order ? (int)p.tile_order[blockIdx.x] : (int)blockIdx.x, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
     if (tile_local < 0) return;
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
@@ -913,6 +914,8 @@ static int backward_impl(gsr_backward_args* a) {
     r.sums64 = a->sums_f64;
     r.dims = d;
     r.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
+    // (the tiles that were slow in the forward blend are the slow ones here: they go first, as they did there)
+    r.tile_order = have_receipt ? tile_order_of_call(a->receipt.serial, a->width, a->height, d.row_begin, d.row_end) : nullptr;
     // (all blocks of the frame, also in a sharded call: the blocks outside the band were not walked)
     const unsigned acc_wgs = (unsigned)(((d.grid_x + kBW - 1) / kBW) * ((d.grid_y + kBH - 1) / kBH)) * kAccParts;
     if (r.num_tiles > 0) {
