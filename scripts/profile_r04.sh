@@ -10,7 +10,7 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r04
 mkdir -p $OUT
 HEAD="--steps 20 --warmup 5 --no-cpu-baseline --no-extras"
-SHORT="--steps 5 --warmup 2 --no-cpu-baseline --no-extras"
+SHORT="--steps 5 --warmup 8 --no-cpu-baseline --no-extras"   # (8: the tile order has settled, GSR_FLAG_NO_TILE_HISTORY)
 PART=${PART:-a}
 
 trace() {   # <name> <bench args...>
@@ -58,14 +58,14 @@ if [ "$PART" = "b" ]; then
 fi
 if [ "$PART" = "c" ]; then
   # 5. the other configurations (bench lines only)
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --backward > $OUT/bench_backward.json 2>/dev/null
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --backward --pose 0,0,-14 > $OUT/bench_backward_outside.json 2>/dev/null
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --backward --no-sorted-lists > $OUT/bench_backward_nolists.json 2>/dev/null
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --width 3840 --height 2160 > $OUT/bench_4k.json 2>/dev/null
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --scene stress --splats 50000000 > $OUT/bench_stress50M.json 2>/dev/null
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --colors-precomp > $OUT/bench_stress50M_precomp.json 2>/dev/null
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --semantics inria --sh-degree 3 > $OUT/bench_stress50M_inria_sh3.json 2>/dev/null
-  GSR_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_forced_dist_1rank.json 2>/dev/null
+  python3 bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-extras --backward > $OUT/bench_backward.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --backward --pose 0,0,-14 > $OUT/bench_backward_outside.json 2>/dev/null
+  python3 bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-extras --backward --no-sorted-lists > $OUT/bench_backward_nolists.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --width 3840 --height 2160 > $OUT/bench_4k.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --scene stress --splats 50000000 > $OUT/bench_stress50M.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --colors-precomp > $OUT/bench_stress50M_precomp.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --semantics inria --sh-degree 3 > $OUT/bench_stress50M_inria_sh3.json 2>/dev/null
+  GSR_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline > $OUT/bench_forced_dist_1rank.json 2>/dev/null
   rm -f gpurun_out/band_projection.json
   python3 scripts/band_timings.py 1920 1080 > $OUT/band_timings.txt 2>/dev/null
   python3 scripts/band_timings.py 3840 2160 > $OUT/band_timings_4k.txt 2>/dev/null
