@@ -75,8 +75,9 @@ def parse_args():
     p.add_argument("--backward", action="store_true",
                    help="BASELINE config 5: a step is forward + backward (gsr_backward with a fixed dL_dout); single GPU")
     p.add_argument("--overlap", action="store_true",
-                   help="GSR_FLAG_OVERLAP_EMIT: block plan's blend on a second stream beside the emission (shorter frames, "
-                        "but per-kernel times are then those of kernels sharing the chip)")
+                   help="GSR_FLAG_OVERLAP_EMIT: force the block plan's blend onto a second stream beside the emission (default: the library decides per call)")
+    p.add_argument("--serial-emit", action="store_true",
+                   help="GSR_FLAG_SERIAL_EMIT: never beside each other (per-kernel times are then those of the kernels alone)")
     p.add_argument("--no-sorted-lists", action="store_true", help="GSR_FLAG_NO_SORTED_LISTS for the headline frame (forward-only callers)")
     p.add_argument("--colors-precomp", action="store_true",
                    help="pass the colours as the reference's colorsPrecomp argument (GSCuda.cuh:111), computed once per scene by "
@@ -300,6 +301,7 @@ class Runner:
         self.sync_all()
         out["elapsed"] = time.perf_counter() - t0
         out["tiles_reordered"] = bool(rast.last_tiles_reordered)
+        out["emit_overlapped"] = bool(rast.last_emit_overlapped)
         # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
         # every stage cost a few tens of microseconds per frame, which the timed frames do not pay).
         prof_steps = max(5, min(steps, 20))
@@ -492,7 +494,8 @@ def main() -> int:
     if args.backward:
         assert not distributed, "--backward is a single-GPU configuration"
         run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
-    draw_kw = dict(plan=args.plan, overlap_emit=args.overlap, semantics=args.semantics, sh_degree=args.sh_degree,
+    draw_kw = dict(plan=args.plan, overlap_emit=True if args.overlap else (False if args.serial_emit else None),
+                   semantics=args.semantics, sh_degree=args.sh_degree,
                    sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp)
     m = run.measure(cam, args.steps, args.warmup, **draw_kw)
 
@@ -516,11 +519,11 @@ def main() -> int:
             # (b) forward-only callers: GSR_FLAG_NO_SORTED_LISTS on the headline frame
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["no_sorted_lists"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_SORTED_LISTS (block plan: the 12 R bytes of sorted keys / values are not written)")
-            # (b'') GSR_FLAG_OVERLAP_EMIT on the headline frame: the blend on a second stream beside the emission
-            e = run.measure(cam, **short, **{**draw_kw, "overlap_emit": True})
-            extras["overlap_emit"] = brief(e, n_splats, "headline frame with GSR_FLAG_OVERLAP_EMIT: the blend (vector-issue-bound) runs on a second stream beside "
-                                                        "the emission (HBM-write-bound); same outputs. Each kernel runs longer while they share the chip, so the "
-                                                        "headline and its per-kernel roofline figures are taken WITHOUT the flag")
+            # (b'') GSR_FLAG_SERIAL_EMIT on the headline frame: the kernels one after the other, their times those of kernels alone
+            e = run.measure(cam, **short, **{**draw_kw, "overlap_emit": False})
+            extras["serial_emit"] = brief(e, n_splats, "headline frame with GSR_FLAG_SERIAL_EMIT: by default the library runs the blend (vector-issue-bound) on a second "
+                                                       "stream beside the emission (HBM-write-bound) where it expects the blend to be the shorter of the two; same "
+                                                       "outputs. Each kernel runs longer while they share the chip: these are the kernels ALONE")
             # (b') the caller-side route the reference's signature offers around the 192-byte-stride DC read: colorsPrecomp
             e = run.measure(cam, **short, **{**draw_kw, "colors_precomp": True})
             b = brief(e, n_splats, "headline frame with the colours passed as colorsPrecomp (GSCuda.cuh:111; computed once per scene, "
@@ -627,7 +630,7 @@ def main() -> int:
                        "band_exchange": ({"transport": run.exch.transport, "gather": args.gather, "note": run.exch.transport_note}
                                          if distributed else None),
                        "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
-                       "slow_tiles_first": m.get("tiles_reordered", False),
+                       "slow_tiles_first": m.get("tiles_reordered", False), "emit_overlapped": m.get("emit_overlapped", False),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
@@ -638,7 +641,9 @@ def main() -> int:
             "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {m['prof_steps']} "
                                 f"frames of the same workload run right after the timed region; those frames took "
                                 f"{m['profiled_ms_per_step']:.4f} ms each with the events in place"),
-            "roofline": roof(dom, "dominant kernel of this frame; HIP-event time of the launch on its own stream"),
+            "roofline": roof(dom, "dominant kernel of this frame; HIP-event time of the launch on its own stream"
+                                  + ("; the blend ran beside it on the library's second stream, as in the timed frames (the kernel "
+                                     "alone: roofline_alone, GSR_FLAG_SERIAL_EMIT)" if m.get("emit_overlapped") and dom == "duplicate" else "")),
             "roofline_blend": rb,
             "kernels": kernels,
         }
@@ -658,6 +663,13 @@ def main() -> int:
             out["cpp_caller_ms"] = cpp.get("ms_per_step")
             out["cpp_caller"] = cpp
         out.update(extras)
+        if "serial_emit" in extras and dom == "duplicate":
+            # the dominant kernel with nothing beside it (the frames of GSR_FLAG_SERIAL_EMIT above)
+            alone_ms = extras["serial_emit"]["stage_ms"].get("duplicate", 0.0)
+            if alone_ms > 0:
+                gbs = kernels["duplicate"]["alg_bytes"] / (alone_ms * 1e-3) / 1e9
+                out["roofline_alone"] = {"kernel": dom_names["duplicate"], "avg_launch_ms": alone_ms, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "frame_ms": extras["serial_emit"]["ms_per_step"]}
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)
     if distributed:
@@ -679,6 +691,7 @@ def brief(e, n_splats, what):
             "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
             "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],
             "blend_from_sorted_lists": e["blend_from_lists"], "slow_tiles_first": e.get("tiles_reordered", False),
+            "emit_overlapped": e.get("emit_overlapped", False),
             "sorted_lists_written": e["lists_written"], "stage_ms": {k: round(v, 4) for k, v in e["stage_ms"].items() if v > 0}}
 
 

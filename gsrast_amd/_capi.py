@@ -30,9 +30,11 @@ GSR_FLAG_PLAN_BLOCKS = 0x10
 GSR_FLAG_OVERLAP_EMIT = 0x20
 GSR_FLAG_NO_SORTED_LISTS = 0x40
 GSR_FLAG_NO_TILE_HISTORY = 0x80
+GSR_FLAG_SERIAL_EMIT = 0x100
 GSR_PLAN_LISTS_SKIPPED = 0x100
 GSR_PLAN_BLEND_FROM_LISTS = 0x200
 GSR_PLAN_TILES_REORDERED = 0x400
+GSR_PLAN_EMIT_OVERLAPPED = 0x800
 GSR_SH_LAYOUT_FILE, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 0, 1
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8

@@ -160,6 +160,8 @@ struct Readback {
     int hist_dims[4] = {0, 0, 0, 0};          // width, height, tile rows [begin, end) the ticks belong to
     uint32_t order_serial = 0;                // the call whose blend took tile_order (0: none)
     bool hist_wanted = false;                 // the last statistics say the frame ends on a few slow tiles
+    uint32_t hist_mean = 0;                   // mean tile time (10 ns) of the last statistics; 0: none yet for this size
+    bool overlapped = false;                  // the last block-plan call ran its blend beside the emission
     uint32_t hist_calls = 0;                  // calls since the ticks were last cleared
     hipEvent_t ev_hist_join = nullptr;
     int ensure_history() {
@@ -460,12 +462,13 @@ int gsr_forward(gsr_forward_args* a) {
         if (memcmp(dims_now, g_rb.hist_dims, sizeof(dims_now)) != 0) {
             GSR_HIP_TRY(hipMemsetAsync(g_rb.tile_ticks, 0, sizeof(uint32_t) * (size_t)(d.grid_x * d.grid_y), stream));
             memcpy(g_rb.hist_dims, dims_now, sizeof(dims_now));
-            g_rb.hist_wanted = false; g_rb.hist_calls = 0; g_rb.host[0] = 0;
+            g_rb.hist_wanted = false; g_rb.hist_calls = 0; g_rb.host[0] = 0; g_rb.hist_mean = 0; g_rb.overlapped = false;
         }
         if (g_rb.host[0] != 0u) {
             const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
             g_rb.hist_wanted = 2ull * 5120ull * g_rb.host[1] > 5ull * tiles * g_rb.host[2] ||
                                (g_rb.host[2] != 0u && tiles * g_rb.host[2] < kLightFrameTicks);      // (or a light frame: tile_order_kernel)
+            g_rb.hist_mean = g_rb.host[2];
             g_rb.host[0] = 0;
         }
         order_now = g_rb.hist_wanted || (g_rb.hist_calls++ % 4u) == 1u;       // (call 0 has no ticks yet)
@@ -609,7 +612,19 @@ int gsr_forward(gsr_forward_args* a) {
         // blend (bound by vector ALU work) on a second stream, and the caller's stream waits for it before
         // gsr_forward's work is complete: 5 % shorter frames, but each of the two kernels runs ~20 % longer
         // while they share the chip, so per-kernel times are no longer those of the kernels alone.
-        const bool serial = !(a->flags & GSR_FLAG_OVERLAP_EMIT) || (a->flags & GSR_FLAG_NO_SORTED_LISTS);
+        // By default the library decides: beside each other when the blend — what the tiles of the last calls took, spread
+        // over the chip's 5 120 wave slots — is expected to be the shorter of the two (the emission: 12 R bytes at 5 TB/s);
+        // a blend already running beside the emission takes about twice as long per tile, hence the second threshold.
+        bool overlap = (a->flags & GSR_FLAG_OVERLAP_EMIT) != 0;
+        if (!overlap && !(a->flags & GSR_FLAG_SERIAL_EMIT) && history && g_rb.hist_mean != 0u && (uint64_t)R >= 48ull * (uint64_t)nv) {
+            const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
+            const unsigned long long blend_ticks = (unsigned long long)g_rb.hist_mean * tiles / 5120ull;
+            const unsigned long long emit_ticks = 12ull * (unsigned long long)R / 50000ull;
+            overlap = blend_ticks < (g_rb.overlapped ? 2ull : 1ull) * emit_ticks;
+        }
+        const bool serial = !overlap || (a->flags & GSR_FLAG_NO_SORTED_LISTS);
+        g_rb.overlapped = !serial;
+        if (!serial) a->plan_used |= GSR_PLAN_EMIT_OVERLAPPED;
         // Which lists feed the blend. Out of the block lists a tile walks every unit of its block and picks its entries
         // by mask: as good as the sorted list where a Gaussian covers most tiles of its blocks, but with small splats a
         // tile owns a few of a unit's 2048 entries and pays a round trip to memory per unit for them (the bench scene

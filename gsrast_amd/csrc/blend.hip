@@ -263,12 +263,9 @@ int launch_tile_order(const FrameDims& d, const uint32_t* ticks, uint32_t* order
     int padded = 2;
     while (padded < workgroups) padded <<= 1;
     if (padded > kTileOrderMax) return GSR_ERR_INVALID_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if ((size_t)padded * sizeof(uint32_t) > 48 * 1024)      // (per device: as for coarse_emit_kernel, blockbin.hip)
         GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         kTileOrderMax * (int)sizeof(uint32_t)));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), (size_t)padded * sizeof(uint32_t), stream, ticks, order, workgroups,
                        padded, d.grid_x, d.row_begin, d.row_end - d.row_begin, stats);
     GSR_LAUNCH_CHECK("tile_order_kernel");

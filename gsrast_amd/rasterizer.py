@@ -123,14 +123,15 @@ class SplatRasterizer:
     def draw(self, cam: Camera | None = None, *, profile: bool = False, count_staged: bool = False,
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
              sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
-             overlap_emit: bool = False, sorted_lists: bool = True, colors_precomp: bool = False,
+             overlap_emit: "bool | None" = None, sorted_lists: bool = True, colors_precomp: bool = False,
              tile_history: bool = True) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
         rasterizer's semantics (GSR_FLAG_SEMANTICS_INRIA): shs must then be laid out [N][16][3].
         plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan.
-        overlap_emit: GSR_FLAG_OVERLAP_EMIT (block plan: the blend on a second stream beside the emission).
+        overlap_emit: True = GSR_FLAG_OVERLAP_EMIT (block plan: the blend on a second stream beside the emission), False =
+        GSR_FLAG_SERIAL_EMIT, None = the library decides per call (last_emit_overlapped tells).
         tile_history=False: GSR_FLAG_NO_TILE_HISTORY (the blend does not start the last frame's slowest tiles first).
         sorted_lists=False: GSR_FLAG_NO_SORTED_LISTS (forward-only callers; last_lists_written tells whether the
         binning chunk holds the sorted keys / values of this call).
@@ -146,7 +147,7 @@ class SplatRasterizer:
         a.flags = ((_capi.GSR_FLAG_PROFILE if profile else 0) | (_capi.GSR_FLAG_COUNT_STAGED if count_staged else 0)
                    | (_capi.GSR_FLAG_SEMANTICS_INRIA if inria else 0)
                    | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan]
-                   | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else 0)
+                   | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else (_capi.GSR_FLAG_SERIAL_EMIT if overlap_emit is False else 0))
                    | (0 if sorted_lists else _capi.GSR_FLAG_NO_SORTED_LISTS)
                    | (0 if tile_history else _capi.GSR_FLAG_NO_TILE_HISTORY))
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
@@ -184,6 +185,7 @@ class SplatRasterizer:
         # block plan only: did the blend read the sorted lists (sparse frames) instead of the block lists
         self.last_blend_from_lists = bool(int(a.plan_used) & _capi.GSR_PLAN_BLEND_FROM_LISTS)
         self.last_tiles_reordered = bool(int(a.plan_used) & _capi.GSR_PLAN_TILES_REORDERED)
+        self.last_emit_overlapped = bool(int(a.plan_used) & _capi.GSR_PLAN_EMIT_OVERLAPPED)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()

@@ -114,12 +114,18 @@ enum {
  * keysUnsorted / valuesUnsorted then hold that plan's block lists (scratch, as sortingSpace is). */
 #define GSR_FLAG_PLAN_SORT 0x8u
 #define GSR_FLAG_PLAN_BLOCKS 0x10u
-/* Block plan only: the blend (which reads the block lists, not the sorted lists) runs on a second stream beside the
- * emission of the sorted lists: one is bound by vector issue, the other by the HBM write path. Same results; the call's
- * work is complete, as always, when `stream` is. Shorter frames where the blend is the shorter of the two (bench frame
- * 1.43 -> 1.38 ms, 4K 4.21 -> 3.97 ms); each kernel runs longer while they share the chip, so per-kernel times are no
- * longer those of the kernels alone (the bench's default frame does not set it for that reason). */
+/* Block plan, frames whose blend reads the block lists (48 or more instances per visible Gaussian): the blend can run on a
+ * second stream beside the emission of the sorted lists — one is bound by vector issue, the other by the HBM write path.
+ * Same results; the call's work is complete, as always, when `stream` is. It pays where the blend is not much longer than
+ * the emission (bench frame 1.38 -> 1.31 ms, 4K 4.21 -> 3.85 ms; faint splats, blend three times the emission: 3.13 -> 3.17),
+ * and each kernel runs longer while they share the chip. By DEFAULT the library decides per call, from the tile times of
+ * the calling thread's previous calls of the same size (see GSR_FLAG_NO_TILE_HISTORY; without that history: serial) and
+ * this call's R: overlapped when the blend is expected to be the shorter of the two; plan_used then carries
+ * GSR_PLAN_EMIT_OVERLAPPED. GSR_FLAG_OVERLAP_EMIT forces it on (block plan; the blend then reads the block lists whatever
+ * the frame), GSR_FLAG_SERIAL_EMIT off: one kernel after the other on the caller's stream, per-kernel times those of the
+ * kernels alone. */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
+#define GSR_FLAG_SERIAL_EMIT 0x100u
 /* Forward-only callers: under the block plan the blend can be fed from the block lists without reading the sorted
  * keys / values (it is by default on frames of 48 or more instances per visible Gaussian), and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
  * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
@@ -143,7 +149,8 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
        GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer
                                             than 48 instances per visible Gaussian), not the block lists */,
        GSR_PLAN_TILES_REORDERED = 0x400 /* or-ed in: the blend started the slow tiles of the call before first
-                                           (see GSR_FLAG_NO_TILE_HISTORY; informational) */ };
+                                           (see GSR_FLAG_NO_TILE_HISTORY; informational) */,
+       GSR_PLAN_EMIT_OVERLAPPED = 0x800 /* or-ed in: the blend ran beside the emission (see GSR_FLAG_OVERLAP_EMIT) */ };
 
 /* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
  * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this
