@@ -302,6 +302,7 @@ class Runner:
         out["elapsed"] = time.perf_counter() - t0
         out["tiles_reordered"] = bool(rast.last_tiles_reordered)
         out["emit_overlapped"] = bool(rast.last_emit_overlapped)
+        out["colors_beside"] = bool(rast.last_colors_beside)
         # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
         # every stage cost a few tens of microseconds per frame, which the timed frames do not pay).
         prof_steps = max(5, min(steps, 20))
@@ -577,7 +578,8 @@ def main() -> int:
         ms_per_step = m["ms_per_step"]
         stage_ms = dict(m["stage_ms"])
         blocks = m["plan"] == "blocks"
-        alg = alg_bytes(m, n_splats, W, H, grid_x, 48 if full_sh else 3, colors_precomp=args.colors_precomp)
+        # (colours written beside the depth sort: the preprocess kernel's own bytes are those of the colorsPrecomp route)
+        alg = alg_bytes(m, n_splats, W, H, grid_x, 48 if full_sh else 3, colors_precomp=args.colors_precomp or m.get("colors_beside", False))
         kernels = kernel_table(m, alg)
         dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"), key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
@@ -631,6 +633,7 @@ def main() -> int:
                                          if distributed else None),
                        "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "slow_tiles_first": m.get("tiles_reordered", False), "emit_overlapped": m.get("emit_overlapped", False),
+                       "colors_beside_depth_sort": m.get("colors_beside", False),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
@@ -691,7 +694,7 @@ def brief(e, n_splats, what):
             "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
             "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],
             "blend_from_sorted_lists": e["blend_from_lists"], "slow_tiles_first": e.get("tiles_reordered", False),
-            "emit_overlapped": e.get("emit_overlapped", False),
+            "emit_overlapped": e.get("emit_overlapped", False), "colors_beside_depth_sort": e.get("colors_beside", False),
             "sorted_lists_written": e["lists_written"], "stage_ms": {k: round(v, 4) for k, v in e["stage_ms"].items() if v > 0}}
 
 

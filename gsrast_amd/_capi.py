@@ -35,6 +35,7 @@ GSR_PLAN_LISTS_SKIPPED = 0x100
 GSR_PLAN_BLEND_FROM_LISTS = 0x200
 GSR_PLAN_TILES_REORDERED = 0x400
 GSR_PLAN_EMIT_OVERLAPPED = 0x800
+GSR_PLAN_COLORS_BESIDE = 0x1000
 GSR_SH_LAYOUT_FILE, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 0, 1
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8

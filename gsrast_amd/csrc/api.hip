@@ -164,6 +164,12 @@ struct Readback {
     bool overlapped = false;                  // the last block-plan call ran its blend beside the emission
     uint32_t hist_calls = 0;                  // calls since the ticks were last cleared
     hipEvent_t ev_hist_join = nullptr;
+    hipEvent_t ev_colors = nullptr;           // "geomState.rgb is written" (colors_visible_kernel on the side stream)
+    int ensure_colors() {
+        { const int rc = ensure_side(); if (rc != GSR_OK) return rc; }
+        if (!ev_colors) GSR_HIP_TRY(hipEventCreateWithFlags(&ev_colors, hipEventDisableTiming));
+        return GSR_OK;
+    }
     int ensure_history() {
         { const int rc = ensure_side(); if (rc != GSR_OK) return rc; }
         if (!tile_ticks) {
@@ -473,12 +479,27 @@ int gsr_forward(gsr_forward_args* a) {
         }
         order_now = g_rb.hist_wanted || (g_rb.hist_calls++ % 4u) == 1u;       // (call 0 has no ticks yet)
     }
+    // geomState.rgb (GSCuda.cu:362-366) is a strided read nothing needs before the blend: by default it is written by a kernel
+    // of its own on the second stream while the depth sort runs (launch_colors_visible, preprocess.hip). Whatever way the
+    // call ends, the caller's stream has waited for it (the chunk is the caller's).
+    static const bool colors_env = [] { const char* e = getenv("GSR_COLORS_BESIDE"); return !(e && e[0] == '0'); }();
+    // (up to 16 M Gaussians: there the kernels of the depth sort wait on latency and the colours cost them 0.05 ms for the
+    // 0.10 ms the preprocess saves — bench frame 1.315 -> 1.268 ms; at 50 M they are bound by HBM themselves and lose what
+    // the preprocess gains, 6.10 -> 6.19 ms)
+    const bool colors_beside = colors_env && !inria && !a->colors_precomp && !(a->flags & GSR_FLAG_SERIAL_EMIT) && n <= (1 << 24);
+    struct SideJoin {
+        hipStream_t stream;
+        hipEvent_t pending;
+        ~SideJoin() { if (pending) (void)hipStreamWaitEvent(stream, pending, 0); }
+    } colors_join{stream, nullptr};
+    if (colors_beside) GSR_STEP(g_rb.ensure_colors());
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (inria)
         GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));
     else
-        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));   // :744-768
+        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave,
+                                   colors_beside));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
@@ -521,6 +542,13 @@ int gsr_forward(gsr_forward_args* a) {
     // (no copy command: the kernels that computed the three figures wrote them into the pinned words as well; numRendered
     // is the low word of the un-wrapped instance count)
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
+    if (colors_beside) {
+        // (behind the read-back's event: tilesTouched is final there, and nothing is added to the caller's stream)
+        GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_r, 0));
+        GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
+        colors_join.pending = g_rb.ev_colors;
+    }
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
     GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
@@ -709,6 +737,16 @@ int gsr_forward(gsr_forward_args* a) {
     }
     const float* colors = a->colors_precomp ? a->colors_precomp : geom.rgb;                // :803
     hipStream_t blend_stream = forked ? g_rb.side : stream;
+    // (the colours: long since written — the blend's stream is made to wait only if they are not; a blend on the side stream
+    // follows them in stream order, and the caller's stream joins that stream below)
+    if (colors_join.pending) {
+        if (blend_stream == stream && hipEventQuery(g_rb.ev_colors) != hipSuccess) {
+            (void)hipGetLastError();
+            GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_colors, 0));
+        }
+        colors_join.pending = nullptr;
+        a->plan_used |= GSR_PLAN_COLORS_BESIDE;
+    }
     // (the order: long since sorted — the blend's stream is made to wait only if it is not)
     if (order_now && hipEventQuery(g_rb.ev_hist_join) != hipSuccess) {
         (void)hipGetLastError();                              // ("not ready" is no error of this call)

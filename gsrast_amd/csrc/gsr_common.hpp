@@ -43,7 +43,9 @@ struct FrameDims {
 // ---- stage launchers (each asynchronous on `stream`) ----
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
                       uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream,
-                      uint32_t* others_per_wave = nullptr);
+                      uint32_t* others_per_wave = nullptr, bool colors_elsewhere = false);
+// geomState.rgb for the Gaussians with a tile (zeros for the others), as preprocess_kernel writes it — for a second stream
+int launch_colors_visible(int n, const uint32_t* tiles_touched, const float* shs, float* rgb, hipStream_t stream);
 
 int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t stream);
 

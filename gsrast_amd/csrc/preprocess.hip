@@ -67,6 +67,7 @@ struct PreprocessParams {
     const float* shs;
     const float* cov3D_precomp;
     const float* colors_precomp;
+    bool skip_colors;           // colours given (colors_precomp) or computed by colors_visible_kernel beside the depth sort
     const float* view;
     const float* proj;
     float tan_fovx, tan_fovy, focal;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
         float opacity = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
         if (band_area != 0) {
             opacity = p.opacities[idx];
-            if (!p.colors_precomp) {
+            if (!p.skip_colors) {
                 const float* sh = p.shs + 48 * (size_t)idx;
                 dc0 = sh[0]; dc1 = sh[1]; dc2 = sh[2];
             }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
             __builtin_nontemporal_store((f32x2){o_c3[4], o_c3[5]}, dst + 2);
         }
         if (p.rects) __builtin_nontemporal_store((i32x2){o_ex, o_ey}, reinterpret_cast<i32x2*>(p.rects + idx));
-        if (!p.colors_precomp) {
+        if (!p.skip_colors) {
             float* o = p.rgb + 3 * (size_t)idx;
             __builtin_nontemporal_store(o_rgb[0], o); __builtin_nontemporal_store(o_rgb[1], o + 1); __builtin_nontemporal_store(o_rgb[2], o + 2);
         }
@@ -278,6 +279,29 @@ __global__ __launch_bounds__(256) void colors_from_dc_kernel(int n, const float*
 
 }  // namespace
 
+// geomState.rgb (GSCuda.cu:362-366) for the Gaussians that got a tile, zeros for the others — what preprocess_kernel writes
+// when it computes the colours itself, bit for bit. On its own it is a strided read (12 useful bytes of a 128-byte line per
+// visible Gaussian) that costs the preprocess 0.10 of its 0.27 ms on the bench frame; nothing needs the colours before the
+// blend, and on scenes of a few million Gaussians the kernels between — scan, depth sort, block lists — wait on latency,
+// not on HBM: launched on the library's second stream once tilesTouched is final, it runs in their shadow (they take 0.05
+// ms longer for it). At 50 M those kernels are bound by HBM themselves: the caller (api.hip) keeps the colours in the
+// preprocess there.
+__global__ __launch_bounds__(256) void colors_visible_kernel(int n, const uint32_t* __restrict__ tiles_touched,
+                                                             const float* __restrict__ shs, float* __restrict__ rgb) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= 3 * (size_t)n) return;
+    const size_t g = f / 3;
+    rgb[f] = tiles_touched[g] != 0u ? 0.5f + 0.4f * shs[48 * g + (f - 3 * g)] : 0.0f;
+}
+
+int launch_colors_visible(int n, const uint32_t* tiles_touched, const float* shs, float* rgb, hipStream_t stream) {
+    const size_t floats = 3 * (size_t)n;
+    if (floats == 0) return GSR_OK;
+    hipLaunchKernelGGL(colors_visible_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, stream, n, tiles_touched, shs, rgb);
+    GSR_LAUNCH_CHECK("colors_visible_kernel");
+    return GSR_OK;
+}
+
 int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t stream) {
     const size_t floats = 3 * (size_t)n;
     hipLaunchKernelGGL(colors_from_dc_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, stream, n, shs, colors);
@@ -286,8 +310,10 @@ int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t st
 }
 
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint32_t* others_per_wave) {
+                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint32_t* others_per_wave,
+                      bool colors_elsewhere) {
     PreprocessParams p;
+    p.skip_colors = a.colors_precomp != nullptr || colors_elsewhere;
     p.n = a.num_gaussians;
     p.means3D = reinterpret_cast<const float4*>(a.means3D);
     p.scales = reinterpret_cast<const float4*>(a.scales);

@@ -186,6 +186,7 @@ class SplatRasterizer:
         self.last_blend_from_lists = bool(int(a.plan_used) & _capi.GSR_PLAN_BLEND_FROM_LISTS)
         self.last_tiles_reordered = bool(int(a.plan_used) & _capi.GSR_PLAN_TILES_REORDERED)
         self.last_emit_overlapped = bool(int(a.plan_used) & _capi.GSR_PLAN_EMIT_OVERLAPPED)
+        self.last_colors_beside = bool(int(a.plan_used) & _capi.GSR_PLAN_COLORS_BESIDE)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()

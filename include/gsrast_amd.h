@@ -126,6 +126,10 @@ enum {
  * kernels alone. */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
 #define GSR_FLAG_SERIAL_EMIT 0x100u
+/* (Also by default, gscuda semantics without colors_precomp, up to 16 M Gaussians: geomState.rgb is written by a kernel of
+ * its own on the library's second stream while the depth sort runs — a strided read nothing needs before the blend, 0.10 ms
+ * of the bench frame's preprocess for 0.05 ms more in the depth sort — and the call's stream waits for it before the blend
+ * and on every way out of the call. Same bits. GSR_FLAG_SERIAL_EMIT keeps the colours in the preprocess kernel as well.) */
 /* Forward-only callers: under the block plan the blend can be fed from the block lists without reading the sorted
  * keys / values (it is by default on frames of 48 or more instances per visible Gaussian), and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
  * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
@@ -150,7 +154,8 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
                                             than 48 instances per visible Gaussian), not the block lists */,
        GSR_PLAN_TILES_REORDERED = 0x400 /* or-ed in: the blend started the slow tiles of the call before first
                                            (see GSR_FLAG_NO_TILE_HISTORY; informational) */,
-       GSR_PLAN_EMIT_OVERLAPPED = 0x800 /* or-ed in: the blend ran beside the emission (see GSR_FLAG_OVERLAP_EMIT) */ };
+       GSR_PLAN_EMIT_OVERLAPPED = 0x800 /* or-ed in: the blend ran beside the emission (see GSR_FLAG_OVERLAP_EMIT) */,
+       GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the depth sort, not by the preprocess */ };
 
 /* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
  * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this

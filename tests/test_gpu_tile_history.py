@@ -90,3 +90,37 @@ def test_backward_after_a_reordered_frame_is_unchanged():
         for k in ref:
             assert torch.equal(got[k], ref[k]), k
     assert seen
+
+
+def test_colours_written_beside_the_depth_sort_are_the_preprocess_kernels():
+    """geomState.rgb by a kernel of its own on the library's second stream (GSR_PLAN_COLORS_BESIDE) against the preprocess
+    kernel writing it (GSR_FLAG_SERIAL_EMIT): the same bits for every Gaussian, zeros for the culled ones, with and without
+    instances (R == 0 returns before the blend: the caller's stream must have waited all the same), on a band, and the
+    picture / the backward's colour gradient built on them unchanged."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 512, 288
+    scene = scenes.garden_like_scene(90_000, seed=81)
+    scene["means3D"][:, :3] *= 0.3
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    cam = camera.default_camera(w, h, near=0.05, far=50.0)
+    for kw in ({}, {"plan": "sort"}, {"tile_rows": (3, 11)}):
+        img0 = r.draw(cam, overlap_emit=False, **kw).clone()
+        assert not r.last_colors_beside
+        rgb0 = r.map_geometry_state()["rgb"].clone()
+        r.map_geometry_state()["rgb"].fill_(float("nan"))
+        img1 = r.draw(cam, **kw).clone()
+        assert r.last_colors_beside
+        rgb1 = r.map_geometry_state()["rgb"]
+        assert torch.equal(rgb0.view(torch.int32), rgb1.view(torch.int32))
+        assert torch.equal(img0.view(torch.int32), img1.view(torch.int32))
+    vis = r.map_geometry_state()["tilesTouched"] != 0
+    assert bool((rgb1[~vis] == 0).all()) and bool((rgb1[vis] != 0).any())
+    # a frame without instances: the camera looks away; the colours (all zero: nothing has a tile) are there when the stream is
+    away = camera.default_camera(w, h, near=0.05, far=50.0, position=(0.0, 0.0, 500.0))
+    r.map_geometry_state()["rgb"].fill_(float("nan"))
+    r.draw(away)
+    assert r.last_num_rendered == 0
+    assert bool((r.map_geometry_state()["rgb"] == 0).all())
