@@ -606,7 +606,9 @@ def main() -> int:
         if args.backward:
             stage_ms["render_backward"], stage_ms["chain_backward"] = m["backward_ms"]
         rb = roof("blend", "the kernel BASELINE.json names; bound by vector-instruction issue, not HBM (~100 flop/B): the HBM "
-                           "fraction is reported as measured, the issue fraction beside it")
+                           "fraction is reported as measured, the issue fraction beside it"
+                           + ("; it ran beside the emission here (both take longer while they share the chip): alone, roofline_blend_alone"
+                              if m.get("emit_overlapped") else ""))
         rb.update(blend_issue_fractions(blend_pmc, stage_ms.get("blend", 0.0)))
         rb["ms_per_million_staged_records"] = round(stage_ms.get("blend", 0.0) / max(m["records_staged"], 1) * 1e6, 5)
         out = {
@@ -673,6 +675,12 @@ def main() -> int:
                 gbs = kernels["duplicate"]["alg_bytes"] / (alone_ms * 1e-3) / 1e9
                 out["roofline_alone"] = {"kernel": dom_names["duplicate"], "avg_launch_ms": alone_ms, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "frame_ms": extras["serial_emit"]["ms_per_step"]}
+            blend_alone_ms = extras["serial_emit"]["stage_ms"].get("blend", 0.0)
+            if blend_alone_ms > 0:
+                gbs = kernels["blend"]["alg_bytes"] / (blend_alone_ms * 1e-3) / 1e9
+                out["roofline_blend_alone"] = {"kernel": dom_names["blend"], "avg_launch_ms": blend_alone_ms, "achieved": round(gbs, 1),
+                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                                               **blend_issue_fractions(blend_pmc, blend_alone_ms)}
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)
     if distributed:
