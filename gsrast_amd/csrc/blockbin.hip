@@ -192,11 +192,17 @@ __global__ __launch_bounds__(CHUNK) void coarse_emit_kernel(int n, const uint32_
     for (int i = threadIdx.x; i < nb * W; i += CHUNK) {
         const int at = (i / W) * WP + (i & (W - 1));
         const uint32_t c = (uint32_t)__popc(s_mask[at]);
-        uint32_t incl = c;
-#pragma unroll
-        for (int off = 1; off < W; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, W);
-            if ((int)(threadIdx.x & (W - 1)) >= off) incl += o;
+        // (inclusive prefix over the W lanes that share a block: DPP row shifts — W = 32: + the row broadcast — instead of
+        // five LDS permutes)
+        uint32_t incl;
+        if constexpr (W == 32) incl = prefix32_inclusive(c);
+        else {
+            static_assert(W == 16 || W == 32, "a block's mask words are one or two DPP rows");
+            incl = c;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
         }
         s_pre[at] = incl - c;
         if ((i & (W - 1)) == W - 1) s_pre[(i / W) * WP + W] = incl;
