@@ -165,9 +165,13 @@ struct Readback {
     uint32_t hist_calls = 0;                  // calls since the ticks were last cleared
     hipEvent_t ev_hist_join = nullptr;
     hipEvent_t ev_colors = nullptr;           // "geomState.rgb is written" (colors_visible_kernel on the side stream)
+    hipEvent_t ev_pre_blend = nullptr;        // "the blend is about to start" (colours beside the blend)
     int ensure_colors() {
         { const int rc = ensure_side(); if (rc != GSR_OK) return rc; }
-        if (!ev_colors) GSR_HIP_TRY(hipEventCreateWithFlags(&ev_colors, hipEventDisableTiming));
+        if (!ev_colors) {
+            GSR_HIP_TRY(hipEventCreateWithFlags(&ev_colors, hipEventDisableTiming));
+            GSR_HIP_TRY(hipEventCreateWithFlags(&ev_pre_blend, hipEventDisableTiming));
+        }
         return GSR_OK;
     }
     int ensure_history() {
@@ -482,24 +486,29 @@ int gsr_forward(gsr_forward_args* a) {
     // geomState.rgb (GSCuda.cu:362-366) is a strided read nothing needs before the blend: by default it is written by a kernel
     // of its own on the second stream while the depth sort runs (launch_colors_visible, preprocess.hip). Whatever way the
     // call ends, the caller's stream has waited for it (the chunk is the caller's).
-    static const bool colors_env = [] { const char* e = getenv("GSR_COLORS_BESIDE"); return !(e && e[0] == '0'); }();
-    // (up to 16 M Gaussians: there the kernels of the depth sort wait on latency and the colours cost them 0.05 ms for the
-    // 0.10 ms the preprocess saves — bench frame 1.315 -> 1.268 ms; at 50 M they are bound by HBM themselves and lose what
-    // the preprocess gains, 6.10 -> 6.19 ms)
-    const bool colors_beside = colors_env && !inria && !a->colors_precomp && !(a->flags & GSR_FLAG_SERIAL_EMIT) && n <= (1 << 24);
+    // Up to 16 M Gaussians beside the depth sort: there its kernels wait on latency and the colours cost them 0.05 ms for the
+    // 0.10 ms the preprocess saves — bench frame 1.315 -> 1.268 ms. At 50 M they are bound by HBM themselves and lose what
+    // the preprocess gains (6.10 -> 6.19 ms): there the colours are written beside the BLEND — vector-bound —, which takes a
+    // record's colour straight from the SH array meanwhile (TileFeed::dc_stride). GSR_COLORS_BESIDE = 0 / 1 / 2 (environment,
+    // for A/B runs and the tests): inside the preprocess / beside the depth sort / beside the blend, whatever the size.
+    const char* const colors_env = getenv("GSR_COLORS_BESIDE");
+    const int colors_forced = colors_env && colors_env[0] >= '0' && colors_env[0] <= '2' ? colors_env[0] - '0' : -1;
+    const bool colors_movable = !inria && !a->colors_precomp && !(a->flags & GSR_FLAG_SERIAL_EMIT);
+    const int colors_mode = !colors_movable ? 0 : (colors_forced >= 0 ? colors_forced : (n <= (1 << 24) ? 1 : 2));
+    const bool colors_beside = colors_mode == 1;
     struct SideJoin {
         hipStream_t stream;
         hipEvent_t pending;
         ~SideJoin() { if (pending) (void)hipStreamWaitEvent(stream, pending, 0); }
     } colors_join{stream, nullptr};
-    if (colors_beside) GSR_STEP(g_rb.ensure_colors());
+    if (colors_mode != 0) GSR_STEP(g_rb.ensure_colors());
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (inria)
         GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));
     else
         GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave,
-                                   colors_beside));   // :744-768
+                                   colors_mode != 0));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     GSR_BEGIN(GSR_STAGE_SCAN);
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
@@ -588,6 +597,8 @@ int gsr_forward(gsr_forward_args* a) {
     a->num_rendered = R;
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
     if (R == 0) {
+        // (colours beside the blend: there is no blend — the zeros of a frame without a tile are written here)
+        if (colors_mode == 2) GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, stream));
         if (!inria) { issue_receipt((uint32_t)nv, nullptr); return fail(GSR_OK); }          // :775-778
         // upstream still runs the tile loop: every pixel gets the background
         GSR_HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
@@ -756,17 +767,30 @@ int gsr_forward(gsr_forward_args* a) {
     if (order_now) a->plan_used |= GSR_PLAN_TILES_REORDERED;
     g_rb.order_serial = order_now ? serial : 0u;
     uint32_t* const t_ticks = history ? g_rb.tile_ticks : nullptr;
+    // Colours beside the blend (scenes beyond 16 M Gaussians): the blend takes them from the SH array; geomState.rgb is
+    // written meanwhile on the other stream — or, where the blend itself runs on the second stream beside the emission,
+    // behind it there — and the caller's stream waits for it before the call's work is complete.
+    const bool colors_late = colors_mode == 2;
+    if (colors_late && !forked) {
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_pre_blend, stream));
+        GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_pre_blend, 0));
+        GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
+        colors_join.pending = g_rb.ev_colors;                 // (joined when this function is left)
+    }
+    if (colors_late) { colors = a->shs; a->plan_used |= GSR_PLAN_COLORS_BESIDE; }
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)
         GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
                                      colors, geom.conic_opacity, img.accum_alpha, img.n_contrib, a->background, a->out_color,
-                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, blend_stream, t_order, t_ticks));
+                                     count_staged ? g_rb.staged_dev : nullptr, t_cutoff, blend_stream, t_order, t_ticks, colors_late));
     else
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                              t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks));       // :804-810
+                              t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks, colors_late));       // :804-810
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is
+        if (colors_late) GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));   // (beside the rest of the emission)
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
         GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));
     }

@@ -38,6 +38,7 @@ struct BlendParams {
     int base_workgroups;           // workgroups of one wave per tile; the launch holds four times as many when nonempty is given
     uint32_t num_rendered;         // R of the call (the lists' total length)
     TileOrder history;             // longest tiles first (blend_core.hpp)
+    uint32_t dc_stride;            // 0, or 48: `colors` is the SH array (TileFeed::dc_stride)
 };
 
 // One wave per tile leaves most of the chip idle when few tiles have a list, and the frame lasts as long as the slowest
@@ -62,7 +63,7 @@ constexpr uint32_t kPriorityMeanList = 8192;     // entries per tile with a list
 // a time, one per lane, in wave-private LDS: no workgroup barrier anywhere. The batch size of the
 // reference (256) only survives as the granularity of the "whole tile done" test and of the
 // staged-record count R_f, which therefore stay identical to the reference's.
-__global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) {
     __shared__ StagedRecords s_staged;
     exp_table_init(s_staged.exp_tab, (int)threadIdx.x);      // (wave-private LDS: ordered inside the wave)
 
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(64) void blend_wave_kernel(const BlendParams p) {
 
     TileFeed feed;
     feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
+    feed.dc_stride = p.dc_stride;
     feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
     if (strips) {
         feed.box.y_lo = (float)(ty * kTile + 4 * strip);
@@ -229,8 +231,9 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream, const uint32_t* nonempty_tiles,
-                 uint32_t num_rendered, const uint32_t* tile_order, uint32_t* tile_ticks) {
+                 uint32_t num_rendered, const uint32_t* tile_order, uint32_t* tile_ticks, bool colors_are_shs) {
     BlendParams p;
+    p.dc_stride = colors_are_shs ? 48u : 0u;
     p.history.order = tile_order; p.history.ticks = tile_ticks;
     p.num_rendered = num_rendered;
     p.ranges = reinterpret_cast<const uint2*>(ranges);

@@ -273,6 +273,9 @@ struct TileFeed {
     TileBox box;
     uint32_t total;                 // records in the tile's list
     float t_cutoff;
+    uint32_t dc_stride = 0;         // 0: `colors` are colours, 12 bytes apart. 48: `colors` is the caller's SH array and a record's
+                                    // colour is 0.5 + 0.4 DC (GSCuda.cu:362-366, the preprocess's two operations) — geomState.rgb
+                                    // is then being written BESIDE this blend (api.hip), for whoever reads the chunk afterwards
 };
 
 // One batch of up to 64 list entries on its way through the wave: lane l holds entry l. The loads of a batch are
@@ -320,7 +323,7 @@ __device__ __forceinline__ uint32_t stage_batch(const TileFeed& f, StagedRecords
     const unsigned long long m2 = __ballot(keep);
     if (keep) {
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-        const float* c = f.colors + 3 * (size_t)b.id;
+        const float* c = f.colors + (f.dc_stride != 0u ? (size_t)f.dc_stride : (size_t)3) * (size_t)b.id;
         s_xy[slot] = b.xy;
         // The filter's evaluation of the power differs from the reference's by the rounding of three terms that may cancel:
         // a few 6e-8 of their magnitude, bounded here over the tile.
@@ -339,7 +342,9 @@ __device__ __forceinline__ uint32_t stage_batch(const TileFeed& f, StagedRecords
         s_co[slot] = filtered ? make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, floor2)
                               : make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
         s_raw[slot] = b.co;
-        s_rgb[slot] = make_float4(c[0], c[1], c[2], __uint_as_float(pos + rank + 1u));
+        float c0 = c[0], c1 = c[1], c2 = c[2];
+        if (f.dc_stride != 0u) { c0 = 0.5f + 0.4f * c0; c1 = 0.5f + 0.4f * c1; c2 = 0.5f + 0.4f * c2; }
+        s_rgb[slot] = make_float4(c0, c1, c2, __uint_as_float(pos + rank + 1u));
     }
     if (before_boundary) {
         const uint32_t boundary = (pos + (uint32_t)kBatch - 1u) & ~((uint32_t)kBatch - 1u);   // first multiple of 256 >= pos

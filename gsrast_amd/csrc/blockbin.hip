@@ -690,6 +690,7 @@ struct BlockBlendParams {
     int num_tiles;
     int waves_per_tile;          // 1, or 4 (one 16 x 4 strip per wave) when the call has few tiles
     TileOrder history;           // longest tiles first (blend_core.hpp)
+    uint32_t dc_stride;          // 0, or 48: `colors` is the SH array (TileFeed::dc_stride)
 };
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_blocks_kernel(const BlockBlendParams p) {
@@ -716,6 +717,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void
     const uint32_t list0 = p.meta.list_start()[b];
     TileFeed feed;
     feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
+    feed.dc_stride = p.dc_stride;
     feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
     feed.total = total; feed.t_cutoff = p.t_cutoff;
     // The tile's batches, in list order: batch w of unit u, for every (u, w) whose mask is not empty. An iterator walks
@@ -912,9 +914,10 @@ int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_s
                         const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                         unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
-                        const uint32_t* tile_order, uint32_t* tile_ticks) {
+                        const uint32_t* tile_order, uint32_t* tile_ticks, bool colors_are_shs) {
     const PlanTables t = plan_tables(n, d.grid_x, d.grid_y, r_total, geo_scratch, bin_scratch);
     BlockBlendParams p;
+    p.dc_stride = colors_are_shs ? 48u : 0u;
     p.history.order = tile_order; p.history.ticks = tile_ticks;
     p.meta = t.meta;
     p.nbx = t.nbx;

@@ -127,7 +127,7 @@ int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_s
                         const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                         unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
-                        const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr);
+                        const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr, bool colors_are_shs = false);
 
 // nonempty (may be null): device word, zero before the launch; receives the number of tiles that got a list
 int launch_tile_ranges(const uint64_t* keys, size_t n, uint32_t* ranges, int num_tiles, bool close_single, hipStream_t stream,
@@ -138,7 +138,8 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
                  const uint32_t* nonempty_tiles = nullptr, uint32_t num_rendered = 0,       // (both: see blend.hip, four waves per tile)
-                 const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr);      // (longest tiles first: TileOrder, blend_core.hpp)
+                 const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr,       // (longest tiles first: TileOrder, blend_core.hpp)
+                 bool colors_are_shs = false);                                               // (`colors` = the SH array: TileFeed::dc_stride)
 // Longest tiles first: the order of this call's blend workgroups from the ticks the tiles of the call before left.
 constexpr int kTileOrderMax = 32768;      // workgroups (one per tile, patch grid padded) up to which the order is kept: 128 KB of LDS for its sort
 constexpr unsigned long long kLightFrameTicks = 25000ull * 5120ull;   // 250 us (in 10 ns) per wave slot of the chip, summed over the tiles
