@@ -126,10 +126,12 @@ enum {
  * kernels alone. */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
 #define GSR_FLAG_SERIAL_EMIT 0x100u
-/* (Also by default, gscuda semantics without colors_precomp, up to 16 M Gaussians: geomState.rgb is written by a kernel of
- * its own on the library's second stream while the depth sort runs — a strided read nothing needs before the blend, 0.10 ms
- * of the bench frame's preprocess for 0.05 ms more in the depth sort — and the call's stream waits for it before the blend
- * and on every way out of the call. Same bits. GSR_FLAG_SERIAL_EMIT keeps the colours in the preprocess kernel as well.) */
+/* (Also by default, gscuda semantics without colors_precomp: geomState.rgb is written by a kernel of its own on the
+ * library's second stream — a strided read nothing needs before the blend, 0.10 ms of the bench frame's preprocess. Up to
+ * 16 M Gaussians while the depth sort runs (0.05 ms more there), and the call's stream waits for it before the blend; beyond,
+ * where the depth sort is bound by HBM itself, beside the blend, which takes a record's colour straight from `shs` meanwhile
+ * (50 M Gaussians: 6.3 -> 5.9 ms). The caller's stream has waited for it on every way out of the call. Same bits.
+ * GSR_FLAG_SERIAL_EMIT keeps the colours in the preprocess kernel as well.) */
 /* Forward-only callers: under the block plan the blend can be fed from the block lists without reading the sorted
  * keys / values (it is by default on frames of 48 or more instances per visible Gaussian), and no caller of the reference reads BinningState (GSGaussians.cpp:214-219 maps GeometryState
  * only). With this flag such a call skips writing them (12 R bytes): BinningState.keys / values are then left
