@@ -638,7 +638,10 @@ def main() -> int:
                        "colors_beside_depth_sort": m.get("colors_beside", False),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists", "sort_pass1": "unit masks + prefixes + tile ranges",
+            "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists"
+                                                 + (" (geomState.rgb is written beside them on the second stream: +0.05 ms here for -0.10 ms in preprocess; "
+                                                    "alone: the serial_emit entry)" if m.get("colors_beside") and n_splats <= (1 << 24) else ""),
+                                  "sort_pass1": "unit masks + prefixes + tile ranges",
                                   "duplicate": "block_emit_kernel (the sorted keys / values)",
                                   "blend": "blend_wave_kernel (from the sorted lists)" if m["blend_from_lists"] else "blend_blocks_kernel"} if blocks else
                                  {"depth_order": "visible-key compaction + depth sort + column counts / scan", "duplicate": "emit_chunk_kernel",
