@@ -148,7 +148,8 @@ enum {
  * statistics of the calls before say the frame ends on a few slow tiles (the camera outside the cloud: blend 0.61 -> 0.53
  * ms from (0,0,-30) on the bench scene), and every fourth call to keep them fresh. This flag switches all of it off: the
  * call then neither reads nor writes that buffer and uses no second stream for it (the environment variable
- * GSR_TILE_HISTORY=0 does the same for every call of the process). */
+ * GSR_TILE_HISTORY=0 does the same for every call of the process). Frames of more than 32 768 tiles (beyond 3840 x 2160)
+ * keep no tile times either: the order is sorted by one workgroup in LDS. */
 #define GSR_FLAG_NO_TILE_HISTORY 0x80u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
