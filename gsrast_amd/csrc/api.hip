@@ -136,7 +136,14 @@ struct Readback {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ensure_side() {
         if (!side) {
-            GSR_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            // (a priority of its own: HIP maps the streams of a priority onto a few hardware queues, and in a process with
+            // many streams — torch.distributed and RCCL bring theirs — this one landed on the caller's queue: its kernels then
+            // ran in front of the caller's instead of beside them, forced-distributed bench 1.37 -> 1.45 ms. The lower
+            // priority also suits what it carries: work that is to fill gaps, never to be waited for)
+            // (measured, forced-distributed / plain bench: normal 1.441 / 1.211, lowest 1.214 / 1.208, highest 1.237 / 1.243 ms)
+            int prio_low = 0, prio_high = 0;
+            if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) { (void)hipGetLastError(); prio_low = 0; }
+            GSR_HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_low));
             GSR_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
             GSR_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         }
