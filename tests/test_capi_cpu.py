@@ -134,6 +134,18 @@ def test_ctypes_structs_have_the_headers_layout(tmp_path):
             assert int(got[f"{cname}.{f}"]) == getattr(ctype, f).offset, f"{cname}.{f}"
 
 
+def test_python_constants_are_the_headers(tmp_path):
+    """Every GSR_FLAG_* / GSR_PLAN_* / GSR_ERR_* the Python mirror names has the header's value (the header compiled as C prints
+    them): a flag added on one side only would silently select something else."""
+    names = sorted(k for k in vars(_capi) if k.startswith(("GSR_FLAG_", "GSR_PLAN_", "GSR_ERR_")) or k == "GSR_OK")
+    assert {"GSR_FLAG_NO_TILE_HISTORY", "GSR_FLAG_SERIAL_EMIT", "GSR_PLAN_EMIT_OVERLAPPED", "GSR_PLAN_COLORS_BESIDE"} <= set(names)
+    body = "".join(f'printf("{k} %lld\\n", (long long)({k}));' for k in names)
+    out = _compile_and_run(tmp_path, '#include <stdio.h>\n#include "gsrast_amd.h"\nint main(void){' + body + "return 0;}")
+    got = dict(line.split() for line in out.strip().splitlines())
+    for k in names:
+        assert int(got[k]) == int(getattr(_capi, k)), k
+
+
 def test_poll_async_error_wants_a_receipt():
     L = _capi.lib()
     assert L.gsr_poll_async_error(None) == _capi.GSR_ERR_INVALID_ARG
