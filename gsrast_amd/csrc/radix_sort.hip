@@ -156,6 +156,31 @@ struct LookBack {
     }
 };
 
+// Which tile a workgroup takes. Tiles that follow each other write adjacent runs of every digit's region, and a run
+// (32 keys on average) ends inside a cache line: with tile = ticket the two halves of such a line are written by
+// workgroups on different XCDs, each L2 sends its half to memory as a partial line, and the pass is bound by those
+// (scripts/micro/scatter_records.hip, 46 M records: the write side alone 0.243 ms with neighbouring tiles on different
+// XCDs, 0.173 ms with eight consecutive tiles on one). Workgroups b and b + 8 share an XCD (observed round-robin
+// placement, MI355X_MICROARCH.md: speed only, never correctness), so each residue class r = blockIdx % 8 keeps a ticket
+// of its own and the j-th workgroup of class r to start takes position 8 j + r of a sequence in which every run of
+// kXcdRun consecutive TILES belongs to one class. Whatever the placement, every position below `tiles` is taken exactly
+// once (a class has as many workgroups as positions, the grid being at least `tiles` wide). No deadlock: a tile waits
+// only for tiles below it; the lowest unfinished tile, if nobody has taken it yet, is the next position of its class, and
+// the workgroups that can be waiting for it are those of ITS group of 8 kXcdRun tiles (earlier groups hold lower tiles,
+// all finished) — at most 7 kXcdRun of the chip's 512 slots — so the launch always has room to start it.
+#ifndef GSR_XCD_RUN
+#define GSR_XCD_RUN 8
+#endif
+constexpr uint32_t kXcdRun = GSR_XCD_RUN;
+__device__ __forceinline__ uint32_t take_tile(uint32_t* ticket, uint32_t tiles) {
+    const uint32_t r = blockIdx.x & 7u;
+    const uint32_t j = atomicAdd(ticket + r, 1u);
+    const uint32_t pos = 8u * j + r;
+    const uint32_t full = tiles / (8u * kXcdRun) * (8u * kXcdRun);
+    // (positions in the last, incomplete group — and beyond the last tile: those workgroups leave at once — map to themselves)
+    return pos < full ? (j / kXcdRun) * (8u * kXcdRun) + r * kXcdRun + (j % kXcdRun) : pos;
+}
+
 // SECOND: every key carries a second 32-bit value (vals2_in -> vals2_out; the depth order's packed rectangle), staged and
 // written beside the first. It is loaded after the ranking loop: 16 more registers across that loop would leave one
 // workgroup per CU instead of two.
@@ -185,7 +210,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (threadIdx.x == 0) {
-        s_tile = atomicAdd(ticket, 1u);
+        s_tile = take_tile(ticket, (n + (uint32_t)kSortTile - 1u) / (uint32_t)kSortTile);
         s_fail = 0;
     }
     if (threadIdx.x < RADIX) {
