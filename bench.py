@@ -83,6 +83,7 @@ def parse_args():
                    help="pass the colours as the reference's colorsPrecomp argument (GSCuda.cuh:111), computed once per scene by "
                         "gsr_colors_from_dc: the preprocess then reads no SH and writes no geomState.rgb (gscuda semantics)")
     p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
+    p.add_argument("--no-tile-history", action="store_true", help="GSR_FLAG_NO_TILE_HISTORY for the headline frame")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: a free one)")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher / rendezvous / band-exchange plumbing check on CPU over gloo: renders nothing, measures "
@@ -296,10 +297,14 @@ class Runner:
         out["visible"] = int((geo["radii"] > 0).sum().item())
         self.sync_all()
         t0 = time.perf_counter()
+        stamps = [t0]
         for _ in range(steps):
-            self.step(cam, **kw)
+            self.step(cam, **kw)                    # (ends with the stream's synchronise: a step's work is complete when it returns)
+            stamps.append(time.perf_counter())
         self.sync_all()
         out["elapsed"] = time.perf_counter() - t0
+        per_step = np.diff(np.asarray(stamps)) * 1e3
+        out["ms_median"], out["ms_p99"] = float(np.median(per_step)), float(np.percentile(per_step, 99))
         out["tiles_reordered"] = bool(rast.last_tiles_reordered)
         out["emit_overlapped"] = bool(rast.last_emit_overlapped)
         out["colors_beside"] = bool(rast.last_colors_beside)
@@ -344,6 +349,100 @@ class Runner:
             out["records_staged_total"], out["num_rendered_total"] = out["records_staged"], out["num_rendered"]
         out["ms_per_step"] = out["elapsed"] / steps * 1e3
         return out
+
+
+def walk_path(W, H, near, far, frames=120):
+    """A viewer's frames (FirstPersonCamera.cpp:28-38, Inspector.cpp:60-62: the reference's only metric is the frame rate
+    of a moving first-person camera): the camera walks from (0,0,-30), outside the cloud, to the reference's default pose
+    (0,0,-5) inside it — two thirds of the frames, crossing the instances-per-Gaussian thresholds of the binning plan and
+    of the blend's feed — and then turns on the spot (yaw to 0.9 rad, a little pitch)."""
+    import math
+    from gsrast_amd import camera
+    cams = []
+    walk = (2 * frames) // 3
+    for i in range(frames):
+        if i < walk:
+            z, yaw, pitch = -30.0 + 25.0 * i / (walk - 1), 0.0, 0.0
+        else:
+            t = (i - walk + 1) / (frames - walk)
+            z, yaw, pitch = -5.0, 0.9 * t, 0.15 * math.sin(3.0 * t)
+        cams.append(camera.first_person_camera((0.0, 0.0, z), yaw, pitch, math.radians(45.0), near, far, W, H, True))
+    return cams
+
+
+def random_views(W, H, near, far, frames=60, seed=5):
+    """A trainer's frames (BASELINE config 5's access pattern): unrelated cameras of one size, every call another — eyes
+    between 3 and 30 units from the origin in any direction, each looking at a point near the origin."""
+    import math
+    from gsrast_amd import camera
+    rng = np.random.default_rng(seed)
+    cams = []
+    for _ in range(frames):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        eye = d * rng.uniform(3.0, 30.0)
+        front = rng.normal(scale=1.0, size=3) - eye
+        front /= np.linalg.norm(front)
+        yaw, pitch = math.atan2(front[0], front[2]), math.asin(max(-1.0, min(1.0, front[1])))
+        cams.append(camera.first_person_camera(tuple(eye), yaw, pitch, math.radians(45.0), near, far, W, H, True))
+    return cams
+
+
+def time_sequence(run, cams, draw_kw, backward=False, repeats=3):
+    """Every camera of the sequence rendered ONCE per pass, a device synchronise after each frame (what the reference's
+    caller does); one untimed pass first (the chunks grow to the sequence's largest frame), then `repeats` timed passes
+    with the tile history and as many without, alternating. Host wall time per frame."""
+    rast = run.rast
+    saved = run.dl_dout
+    if backward and run.dl_dout is None:
+        run.dl_dout = torch.randn((3, run.H, run.W), generator=torch.Generator(device="cpu").manual_seed(7)).to(run.device)
+    if not backward:
+        run.dl_dout = None
+
+    def one_pass(hist, record):
+        times, plans, overl, dropped, reordered = [], [], 0, 0, 0
+        for cam in cams:
+            t0 = time.perf_counter()
+            run.step(cam, **{**draw_kw, "tile_history": hist})
+            times.append((time.perf_counter() - t0) * 1e3)
+            plans.append(rast.last_plan + ("/lists" if rast.last_blend_from_lists else ""))
+            overl += int(rast.last_emit_overlapped)
+            dropped += int(rast.last_tile_order_dropped)
+            reordered += int(rast.last_tiles_reordered)
+        if record is not None:
+            record.append({"ms": np.asarray(times), "flips": sum(1 for a, b in zip(plans, plans[1:]) if a != b),
+                           "overlapped": overl, "dropped": dropped, "reordered": reordered})
+    one_pass(True, None)             # (untimed: the chunks grow, and every kernel either mode uses has been loaded once)
+    one_pass(False, None)
+    with_h, without = [], []
+    for _ in range(repeats):
+        one_pass(True, with_h)
+        one_pass(False, without)
+    run.dl_dout = saved
+    allw, allo = np.concatenate([r["ms"] for r in with_h]), np.concatenate([r["ms"] for r in without])
+    return {"frames": len(cams), "passes": repeats,
+            "hist_over_nohist": round(float(allw.sum() / allo.sum()), 4),      # (the same frames, summed: below 1 = the history pays)
+            "ms_mean": round(float(allw.mean()), 4), "ms_p50": round(float(np.median(allw)), 4), "ms_p99": round(float(np.percentile(allw, 99)), 4),
+            "nohist_ms_mean": round(float(allo.mean()), 4), "nohist_ms_p50": round(float(np.median(allo)), 4),
+            "nohist_ms_p99": round(float(np.percentile(allo, 99)), 4),
+            "plan_flips": with_h[-1]["flips"], "overlapped_frames": with_h[-1]["overlapped"], "order_dropped_frames": with_h[-1]["dropped"],
+            "reordered_frames": with_h[-1]["reordered"], "nohist_overlapped_frames": without[-1]["overlapped"]}
+
+
+def cpu_config1():
+    """BASELINE config 1: 1 000 isotropic Gaussians, 128 x 128, the C++ oracle on ONE thread."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.isotropic_scene(1000, 42)
+    cam = camera.default_camera(128, 128)
+    cpu_oracle.forward(scene, cam, threads=1)
+    best = 1e9
+    for _ in range(5):
+        t = {}
+        cpu_oracle.forward(scene, cam, threads=1, timings=t)
+        best = min(best, t["total_s"])
+    return {"msplats_per_s": round(1000 / best / 1e6, 4), "ms": round(best * 1e3, 4), "threads": 1,
+            "what": "BASELINE config 1: 1 000 isotropic Gaussians (seed 42), 128x128, oracle/gsr_oracle.cpp single-threaded, best of 5"}
 
 
 def cpp_caller(cam, n_splats, seed, steps, warmup):
@@ -497,13 +596,13 @@ def main() -> int:
         run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
     draw_kw = dict(plan=args.plan, overlap_emit=True if args.overlap else (False if args.serial_emit else None),
                    semantics=args.semantics, sh_degree=args.sh_degree,
-                   sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp)
+                   sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp, tile_history=not args.no_tile_history)
     m = run.measure(cam, args.steps, args.warmup, **draw_kw)
 
     # (extras and the committed PMC figures belong to the default workload; with --ply the frame is the file's)
     default_frame = (not from_file and args.scene == "garden_like" and args.splats == DEFAULT_SPLATS and (W, H) == (1920, 1080) and not args.pose
                      and args.opacity_scale == 1.0 and not inria and not args.backward and args.plan == "auto"
-                     and not args.overlap and not args.no_sorted_lists and not args.colors_precomp)
+                     and not args.overlap and not args.no_sorted_lists and not args.colors_precomp and not args.no_tile_history)
     extras = {}
     if not args.no_extras and default_frame:
         # (6 warm-up frames: the library notices within five that a new viewpoint ends on a few slow tiles — GSR_FLAG_NO_TILE_HISTORY)
@@ -520,6 +619,9 @@ def main() -> int:
             # (b) forward-only callers: GSR_FLAG_NO_SORTED_LISTS on the headline frame
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["no_sorted_lists"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_SORTED_LISTS (block plan: the 12 R bytes of sorted keys / values are not written)")
+            # (b-) GSR_FLAG_NO_TILE_HISTORY on the headline frame: what a first frame, or a frame after a camera cut, takes
+            e = run.measure(cam, **short, **{**draw_kw, "tile_history": False})
+            extras["no_tile_history"] = brief(e, n_splats, "headline frame with GSR_FLAG_NO_TILE_HISTORY: patch order, and (without the tile times) the blend never beside the emission")
             # (b'') GSR_FLAG_SERIAL_EMIT on the headline frame: the kernels one after the other, their times those of kernels alone
             e = run.measure(cam, **short, **{**draw_kw, "overlap_emit": False})
             extras["serial_emit"] = brief(e, n_splats, "headline frame with GSR_FLAG_SERIAL_EMIT: by default the library runs the blend (vector-issue-bound) on a second "
@@ -562,6 +664,13 @@ def main() -> int:
             e = run.measure(cam, **short, **{**draw_kw, "sorted_lists": False})
             extras["forward_backward_no_sorted_lists"] = brief(e, n_splats, "the same with GSR_FLAG_NO_SORTED_LISTS: the backward reads the tile lists from the block lists")
             run.dl_dout = None
+            # (e) what a viewer and a trainer get: a camera path and a sequence of unrelated views, every frame rendered once
+            extras["path"] = time_sequence(run, walk_path(W, H, near, far), draw_kw)
+            extras["path"]["what"] = ("120 poses of the reference's first-person camera walking from (0,0,-30) to the default pose and turning there, each "
+                                      "rendered once, device sync per frame; with this rasterizer's tile history / with GSR_FLAG_NO_TILE_HISTORY")
+            extras["random_views"] = time_sequence(run, random_views(W, H, near, far), draw_kw, backward=True)
+            extras["random_views"]["what"] = ("60 unrelated cameras of one size, forward + backward (every array) each, rendered once in turn: BASELINE "
+                                              "config 5's access pattern; with the tile history (which drops its order) / without")
         else:
             # BASELINE config 3: the same scene at 3840 x 2160, tile rows sharded over the ranks
             run4k = Runner(dev_scene, 3840, 2160, device, distributed, args)
@@ -618,6 +727,7 @@ def main() -> int:
             "fps": round(1e3 / ms_per_step, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(m["ms_median"], 4), "ms_per_step_p99": round(m["ms_p99"], 4),   # (BASELINE.md section 2 defines the median)
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -658,8 +768,21 @@ def main() -> int:
         # what the driver keeps of this line is its head: the representative frames and the whole-frame rate go into `config`
         cfg = out["config"]
         cfg["frame_alg_gbs"] = round(sum(v["alg_bytes"] for v in kernels.values()) / (ms_per_step * 1e-3) / 1e9, 1)   # all stages' algorithmic bytes / frame time
-        cfg["frames_ms"] = {k: extras[k]["ms_per_step"] for k in ("pose_outside", "pose_far", "blend_bound", "no_sorted_lists", "config3_4k")
-                            if k in extras}
+        # (flat scalars only: the driver's record keeps nothing nested)
+        for key, name in (("pose_outside", "ms_pose_outside"), ("pose_far", "ms_pose_far"), ("blend_bound", "ms_faint"),
+                          ("no_sorted_lists", "ms_no_sorted_lists"), ("serial_emit", "ms_serial"), ("no_tile_history", "ms_no_tile_history"),
+                          ("colors_precomp", "ms_colors_precomp"), ("forward_backward", "ms_forward_backward"), ("config3_4k", "ms_config3_4k")):
+            if key in extras:
+                cfg[name] = extras[key]["ms_per_step"]
+        if "path" in extras:
+            pth, rv = extras["path"], extras["random_views"]
+            cfg.update({"path_ms_p50": pth["ms_p50"], "path_ms_p99": pth["ms_p99"], "path_ms_mean": pth["ms_mean"],
+                        "path_ms_nohist_p50": pth["nohist_ms_p50"], "path_ms_nohist_p99": pth["nohist_ms_p99"],
+                        "path_hist_over_nohist": pth["hist_over_nohist"], "randview_hist_over_nohist": rv["hist_over_nohist"],
+                        "path_plan_flips": pth["plan_flips"], "path_overlapped_frames": pth["overlapped_frames"],
+                        "path_order_dropped_frames": pth["order_dropped_frames"],
+                        "randview_ms": rv["ms_mean"], "randview_ms_nohist": rv["nohist_ms_mean"], "randview_ms_p50": rv["ms_p50"],
+                        "randview_ms_nohist_p50": rv["nohist_ms_p50"], "randview_order_dropped_frames": rv["order_dropped_frames"]})
         if distributed:
             proj, src = load_profile_json("band_projection.json")
             key = f"{W}x{H}"
@@ -686,6 +809,7 @@ def main() -> int:
                                                **blend_issue_fractions(blend_pmc, blend_alone_ms)}
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_sample)
+            out["cpu_baseline"]["config1_single_thread"] = cpu_config1()
     if distributed:
         if run.exch is not None:
             run.exch.close()                  # (the library's own RCCL communicator, if the exchange ran on it)

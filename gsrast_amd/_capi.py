@@ -36,6 +36,7 @@ GSR_PLAN_BLEND_FROM_LISTS = 0x200
 GSR_PLAN_TILES_REORDERED = 0x400
 GSR_PLAN_EMIT_OVERLAPPED = 0x800
 GSR_PLAN_COLORS_BESIDE = 0x1000
+GSR_PLAN_TILE_ORDER_DROPPED = 0x2000
 GSR_SH_LAYOUT_FILE, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 0, 1
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8
@@ -71,7 +72,7 @@ class ForwardReceipt(C.Structure):
                 ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
                 ("num_rendered", C.c_uint32), ("num_visible", C.c_uint32), ("serial", C.c_uint32),
                 ("geometry_chunk", C.c_void_p), ("image_chunk", C.c_void_p), ("binning_chunk", C.c_void_p),
-                ("async_words", C.c_void_p)]
+                ("async_words", C.c_void_p), ("tile_history", C.c_void_p)]
 
     def copy(self) -> "ForwardReceipt":
         r = ForwardReceipt()
@@ -94,6 +95,7 @@ class ForwardArgs(C.Structure):
         ("prefiltered", C.c_int32), ("out_color", C.c_void_p), ("radii", C.c_void_p), ("rects", C.c_void_p),
         ("box_min", C.c_void_p), ("box_max", C.c_void_p),
         ("stream", C.c_void_p), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
+        ("tile_history", C.c_void_p),
         ("num_rendered", C.c_uint32), ("records_staged", C.c_uint64),
         ("stage_ms", C.c_float * GSR_NUM_STAGES),
         ("plan_used", C.c_uint32),
@@ -144,6 +146,9 @@ SIGNATURES = {
     "gsr_error_string": (C.c_char_p, [C.c_int]),
     "gsr_last_hip_error": (C.c_char_p, []),
     "gsr_poll_async_error": (C.c_int, [C.POINTER(ForwardReceipt)]),
+    "gsr_tile_history_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gsr_tile_history_destroy": (C.c_int, [C.c_void_p]),
+    "gsr_tile_history_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "gsr_higher_msb": (C.c_uint32, [C.c_uint32]),
     "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),
     "gsr_inclusive_scan_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <map>
+#include <vector>
 
 #include "gsr_common.hpp"
 #include "blockbin.hpp"
@@ -49,6 +50,7 @@ struct GeoScratch {
                               // [2..3] u64: sum of tilesTouched without the u32 wrap-around, [4] tiles with a list
     uint32_t* vis_partial;    // per 4096-key chunk: visible keys before it (compaction)
     uint32_t* main_partial;   // the same for the keys with the main top byte only (the depth order's side way, radix_sort.hip)
+    uint32_t* big_partial;    // per 4096 Gaussians: the instances of those that touch kBigSplatTiles tiles or more
     uint32_t* others_per_wave;  // per 64 Gaussians: visible ones with another top byte (written by the preprocess, summed by the scan)
     uint32_t *side_k, *side_v, *side_r;   // the side list (kDepthSideMax entries); its words: sort_info[8..10]
     uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
@@ -70,6 +72,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.sort_info = reinterpret_cast<uint32_t*>(base + off); off += 128;
     g.vis_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
     g.main_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
+    g.big_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
     g.others_per_wave = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * ((n + 63) / 64));
     g.side_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
     g.side_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
@@ -114,11 +117,77 @@ BinScratch carve_bin_scratch(char* base, size_t r) {
 // thread AND device (events and streams belong to the device that was current when they were created). These are
 // resources, not state: nothing a later call needs to know about an earlier one is kept here — that travels in the
 // gsr_forward_receipt, and lives in the caller's chunks.
+}  // namespace
+}  // namespace gsr
+
+// A tile history (include/gsrast_amd.h, GSR_FLAG_NO_TILE_HISTORY): how long the tiles of a view's two last frames took, the
+// order the next blend takes them in (TileOrder, blend_core.hpp), and what the host remembers of tile_order_kernel's
+// statistics. One per view — the caller's own (gsr_tile_history_create), or one the library keeps per host thread, device
+// and stream. It decides WHEN a tile is composited, never what comes out.
+struct gsr_tile_history {
+    uint32_t magic = 0;
+    int device = -1;
+    uint32_t* ticks[2] = {nullptr, nullptr};  // device: tile times (10 ns) of the two last frames; ticks[cur] receives the next one's
+    uint32_t* order = nullptr;                // device: the blend's workgroup order
+    uint32_t* stats = nullptr;                // pinned host words, written by tile_order_kernel: [0] fresh, [1] longest tile, [2] mean,
+    uint32_t* stats_dev = nullptr;            //   [3] similarity of the two frames x 1000, [4] order dropped (they do not resemble each other)
+    int cur = 0;
+    int dims[4] = {0, 0, 0, 0};               // width, height, tile rows [begin, end) the ticks belong to
+    uint32_t order_serial = 0;                // the call whose blend took `order` (0: none)
+    bool wanted = false;                      // the last statistics say the frame ends on a few slow tiles (or is a light one)
+    bool decorrelated = false;                // ... and that the two last frames did not resemble each other
+    bool overlapped = false;                  // the last block-plan call ran its blend beside the emission
+    bool block_fed = false;                   // ... and read the block lists (else the sorted lists: a tile's time then says less about the block-fed blend)
+    uint32_t mean = 0, longest = 0;           // mean and longest tile time of the last statistics; mean 0: none yet for this size
+    uint32_t calls = 0;                       // calls since the ticks were last cleared
+    bool used = false;
+    hipStream_t last_stream = nullptr;        // the stream of the call that used it last: what orders two calls' kernels
+    hipEvent_t ev_order = nullptr;            // "the order is sorted" (recorded on the library's second stream)
+    hipEvent_t ev_switch = nullptr;           // a caller's own history taken to another stream: that stream waits for the old one's tail
+};
+
+namespace gsr {
+namespace {
+constexpr uint32_t kHistoryMagic = 0x54485347u;   // "GSHT"
+// Instances per visible Gaussian (R / V) at which the plans and the blend's feed change hands (each with the frames it was
+// measured on; `profiles/r05_trained_like.txt` has all of them on a scene of flat, opaque splats on surfaces):
+constexpr uint64_t kBlockPlanMinInstances = 6;    // block plan from here on, sort plan below
+constexpr uint64_t kBlockFeedMinInstances = 48;   // a SERIAL blend reads the block lists from here on, the sorted lists below
+constexpr uint32_t kBigSplatTiles = 256;          // "a big splat" (16 x 16 tiles and more) for the plan's choice
+constexpr uint64_t kOverlapMinInstances = 16;     // the blend may run beside the emission (block-fed) from here on — when the tile times say it is the shorter of the two
+constexpr size_t kMaxDefaultHistories = 8;        // streams per host thread and device that get a history of the library's own
+
+int tile_history_new(gsr_tile_history** out) {
+    gsr_tile_history* h = new gsr_tile_history;
+    auto fail_with = [&](hipError_t e, const char* what) {
+        set_hip_error(e, what);
+        if (h->ticks[0]) (void)hipFree(h->ticks[0]);
+        if (h->stats) (void)hipHostFree(h->stats);
+        if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+        if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
+        delete h;
+        return GSR_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipGetDevice(&h->device)) != hipSuccess) return fail_with(e, "hipGetDevice");
+    uint32_t* dev = nullptr;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&dev), sizeof(uint32_t) * 3 * kTileOrderMax)) != hipSuccess) return fail_with(e, "hipMalloc (tile history)");
+    h->ticks[0] = dev; h->ticks[1] = dev + kTileOrderMax; h->order = dev + 2 * kTileOrderMax;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->stats), 64, hipHostMallocMapped)) != hipSuccess) return fail_with(e, "hipHostMalloc (tile history)");
+    memset(h->stats, 0, 64);
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stats_dev), h->stats, 0)) != hipSuccess) return fail_with(e, "hipHostGetDevicePointer");
+    if ((e = hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming)) != hipSuccess) return fail_with(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming)) != hipSuccess) return fail_with(e, "hipEventCreate");
+    h->magic = kHistoryMagic;
+    *out = h;
+    return GSR_OK;
+}
+
 constexpr uint32_t kAsyncSlots = 64;       // error-word slots handed out in turn, one per gsr_forward call
 constexpr uint32_t kAsyncBase = 16;        // first slot word inside the pinned block
 struct Readback {
     uint32_t* host_dev = nullptr;      // the same words as the device sees them (pinned host memory is mapped)
-    uint32_t* host = nullptr;          // [0..2] tile_order_kernel's statistics {fresh, longest tile, mean}, [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
+    uint32_t* host = nullptr;          // [3] top digits, [4] V, [6..7] u64 un-wrapped instance count, [10] side way taken, [11] side keys below the main top
                                        // byte, [12] side keys as the scan counted them, [13] as the compaction listed them (all written by the
                                        // kernels that compute them), [8..9] staged count;
                                        // from [kAsyncBase]: kAsyncSlots x {N-sized sort gave up, R-sized sort gave up (both
@@ -160,17 +229,8 @@ struct Readback {
         if (!ev_r) GSR_HIP_TRY(hipEventCreateWithFlags(&ev_r, hipEventDisableTiming));
         return GSR_OK;
     }
-    // longest tiles first (TileOrder, blend_core.hpp): what the tiles of this thread's last call on this device took, and
-    // the order this call's blend takes them in
-    uint32_t* tile_ticks = nullptr;
-    uint32_t* tile_order = nullptr;
-    int hist_dims[4] = {0, 0, 0, 0};          // width, height, tile rows [begin, end) the ticks belong to
-    uint32_t order_serial = 0;                // the call whose blend took tile_order (0: none)
-    bool hist_wanted = false;                 // the last statistics say the frame ends on a few slow tiles
-    uint32_t hist_mean = 0;                   // mean tile time (10 ns) of the last statistics; 0: none yet for this size
-    bool overlapped = false;                  // the last block-plan call ran its blend beside the emission
-    uint32_t hist_calls = 0;                  // calls since the ticks were last cleared
-    hipEvent_t ev_hist_join = nullptr;
+    // the tile histories this thread's calls without one of their own take: one per stream (see TileHistory below)
+    std::vector<gsr_tile_history*> default_histories;
     hipEvent_t ev_colors = nullptr;           // "geomState.rgb is written" (colors_visible_kernel on the side stream)
     hipEvent_t ev_pre_blend = nullptr;        // "the blend is about to start" (colours beside the blend)
     int ensure_colors() {
@@ -178,15 +238,6 @@ struct Readback {
         if (!ev_colors) {
             GSR_HIP_TRY(hipEventCreateWithFlags(&ev_colors, hipEventDisableTiming));
             GSR_HIP_TRY(hipEventCreateWithFlags(&ev_pre_blend, hipEventDisableTiming));
-        }
-        return GSR_OK;
-    }
-    int ensure_history() {
-        { const int rc = ensure_side(); if (rc != GSR_OK) return rc; }
-        if (!tile_ticks) {
-            GSR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tile_ticks), sizeof(uint32_t) * kTileOrderMax));
-            GSR_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tile_order), sizeof(uint32_t) * kTileOrderMax));
-            GSR_HIP_TRY(hipEventCreateWithFlags(&ev_hist_join, hipEventDisableTiming));
         }
         return GSR_OK;
     }
@@ -214,11 +265,18 @@ int current_readback(Readback*& out) {
 
 }  // namespace
 
-const uint32_t* tile_order_of_call(uint32_t serial, int width, int height, int row_begin, int row_end) {
+const uint32_t* tile_order_of_call(const gsr_forward_receipt& r, int row_begin, int row_end) {
+    if (r.serial == 0u) return nullptr;
+    const int dims[4] = {r.width, r.height, row_begin, row_end};
+    auto fits = [&](const gsr_tile_history* h) {
+        return h && h->magic == kHistoryMagic && h->order_serial == r.serial && memcmp(dims, h->dims, sizeof(dims)) == 0;
+    };
+    if (r.tile_history) return fits(r.tile_history) ? r.tile_history->order : nullptr;    // (the caller's own: its to share between threads)
     Readback* rb = nullptr;
-    if (current_readback(rb) != GSR_OK || !rb->tile_order || serial == 0u || rb->order_serial != serial) return nullptr;
-    const int dims[4] = {width, height, row_begin, row_end};
-    return memcmp(dims, rb->hist_dims, sizeof(dims)) == 0 ? rb->tile_order : nullptr;
+    if (current_readback(rb) != GSR_OK) return nullptr;
+    for (const gsr_tile_history* h : rb->default_histories)
+        if (fits(h)) return h->order;
+    return nullptr;
 }
 
 // What a gsr_backward call may read of the forward call that issued `r` (see gsr_backward_args.receipt): derived from
@@ -363,6 +421,39 @@ int gsr_footprint_misses_tile(int n, const float* means2D, const float* conic_op
     return fail(launch_footprint_test(n, means2D, conic_opacity, tile_xy, width, height, misses, (hipStream_t)stream));
 }
 
+int gsr_tile_history_create(gsr_tile_history** out) {
+    g_hip_error[0] = 0;
+    if (!out) return fail(GSR_ERR_INVALID_ARG);
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GSR_ERR_NO_DEVICE);
+    return fail(tile_history_new(out));
+}
+
+int gsr_tile_history_destroy(gsr_tile_history* h) {
+    g_hip_error[0] = 0;
+    if (!h) return fail(GSR_OK);
+    if (h->magic != kHistoryMagic) return fail(GSR_ERR_INVALID_ARG);
+    h->magic = 0;
+    (void)hipFree(h->ticks[0]);
+    (void)hipHostFree(h->stats);
+    (void)hipEventDestroy(h->ev_order);
+    (void)hipEventDestroy(h->ev_switch);
+    delete h;
+    return fail(GSR_OK);
+}
+
+int gsr_tile_history_stats(const gsr_tile_history* h, uint32_t out[6]) {
+    if (!h || h->magic != kHistoryMagic || !out) return fail(GSR_ERR_INVALID_ARG);
+    out[0] = h->stats[0] != 0u ? h->stats[2] : h->mean;          // (words the last sort has left and no call has read yet come first)
+    out[1] = h->stats[1];
+    out[2] = h->stats[3];
+    out[3] = (h->stats[0] != 0u ? h->stats[4] != 0u : h->decorrelated) ? 1u : 0u;
+    out[4] = h->calls;
+    out[5] = h->overlapped ? 1u : 0u;
+    return fail(GSR_OK);
+}
+
 int gsr_poll_async_error(const gsr_forward_receipt* r) {
     if (!r || r->magic != GSR_RECEIPT_MAGIC || !r->async_words) return fail(GSR_ERR_INVALID_ARG);
     const volatile uint32_t* w = r->async_words;
@@ -456,39 +547,71 @@ int gsr_forward(gsr_forward_args* a) {
         rc_.serial = serial;
         rc_.geometry_chunk = geo_chunk; rc_.image_chunk = img_chunk; rc_.binning_chunk = bin_chunk_or_null;
         rc_.async_words = g_rb.host + slot_at;
+        rc_.tile_history = a->tile_history;
         rc_.magic = GSR_RECEIPT_MAGIC;
     };
     for (bool& r : g_rb.recorded) r = false;
     for (int s = 0; s < GSR_NUM_STAGES; ++s) g_rb.begin_of[s] = 2 * s;
 
-    // Longest tiles first (TileOrder, blend_core.hpp): the order of this call's blend workgroups is sorted from the ticks of
-    // the last call while the preprocess runs, on the library's second stream. A call of another size starts from zeros
-    // (= patch order).
+    // Slow tiles first (TileOrder, blend_core.hpp): the order of this call's blend workgroups is sorted from the tile times of
+    // the history's last frame while the depth sort runs, on the library's second stream. Which history: the caller's, or
+    // this thread's own for the call's stream (a call of another size starts from zeros = patch order).
     static const bool history_env = [] { const char* e = getenv("GSR_TILE_HISTORY"); return !(e && e[0] == '0'); }();
-    const bool history = history_env && !(a->flags & GSR_FLAG_NO_TILE_HISTORY) && tile_order_workgroups(d) <= kTileOrderMax &&
-                         d.grid_x * d.grid_y <= kTileOrderMax;
+    gsr_tile_history* hist = nullptr;
+    if (history_env && !(a->flags & GSR_FLAG_NO_TILE_HISTORY) && tile_order_workgroups(d) <= kTileOrderMax &&
+        d.grid_x * d.grid_y <= kTileOrderMax) {
+        if (a->tile_history) {
+            int dev_now = -1;
+            GSR_HIP_TRY(hipGetDevice(&dev_now));
+            if (a->tile_history->magic != kHistoryMagic || a->tile_history->device != dev_now) return fail(GSR_ERR_INVALID_ARG);
+            hist = a->tile_history;
+            if (hist->used && hist->last_stream != stream) {
+                // (the caller has taken its history to another stream: this call's kernels go behind what the old stream holds
+                // now — if that stream is gone, so is its work)
+                if (hipEventRecord(hist->ev_switch, hist->last_stream) == hipSuccess) GSR_HIP_TRY(hipStreamWaitEvent(stream, hist->ev_switch, 0));
+                else (void)hipGetLastError();
+            }
+        } else {
+            for (gsr_tile_history* h : g_rb.default_histories)
+                if (h->last_stream == stream) { hist = h; break; }
+            if (!hist && g_rb.default_histories.size() < kMaxDefaultHistories) {
+                GSR_STEP(tile_history_new(&hist));
+                g_rb.default_histories.push_back(hist);
+            }
+        }
+        if (hist) { hist->last_stream = stream; hist->used = true; GSR_STEP(g_rb.ensure_side()); }
+    }
+    const bool history = hist != nullptr;
     // The order costs a launch on the second stream and the host a few microseconds, and it pays on frames that END on a
-    // few slow tiles and on light frames: it is sorted when the last statistics (host words 0-2, left by tile_order_kernel: fresh, the longest
-    // tile and the mean) say the longest tile takes 2.5 times what the tiles would take spread evenly over the chip's
+    // few slow tiles and on light frames: it is sorted when the last statistics (the history's pinned host words, left by
+    // tile_order_kernel: fresh, the longest tile and the mean) say the longest tile takes 2.5 times what the tiles would take spread evenly over the chip's
     // 5 120 wave slots — and every fourth call, to have fresh statistics (a camera that leaves the cloud is noticed within
     // five frames). The ticks are recorded by every call.
     bool order_now = false;
+    uint32_t* t_ticks = nullptr;
     if (history) {
-        GSR_STEP(g_rb.ensure_history());
         const int dims_now[4] = {a->width, a->height, d.row_begin, d.row_end};
-        if (memcmp(dims_now, g_rb.hist_dims, sizeof(dims_now)) != 0) {
-            GSR_HIP_TRY(hipMemsetAsync(g_rb.tile_ticks, 0, sizeof(uint32_t) * (size_t)(d.grid_x * d.grid_y), stream));
-            memcpy(g_rb.hist_dims, dims_now, sizeof(dims_now));
-            g_rb.hist_wanted = false; g_rb.hist_calls = 0; g_rb.host[0] = 0; g_rb.hist_mean = 0; g_rb.overlapped = false;
+        if (memcmp(dims_now, hist->dims, sizeof(dims_now)) != 0) {
+            GSR_HIP_TRY(hipMemsetAsync(hist->ticks[0], 0, sizeof(uint32_t) * 2 * (size_t)kTileOrderMax, stream));
+            memcpy(hist->dims, dims_now, sizeof(dims_now));
+            hist->wanted = hist->decorrelated = hist->overlapped = false;
+            hist->calls = 0; hist->stats[0] = 0; hist->mean = hist->longest = 0; hist->order_serial = 0;
         }
-        if (g_rb.host[0] != 0u) {
+        if (hist->stats[0] != 0u) {
             const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
-            g_rb.hist_wanted = 2ull * 5120ull * g_rb.host[1] > 5ull * tiles * g_rb.host[2] ||
-                               (g_rb.host[2] != 0u && tiles * g_rb.host[2] < kLightFrameTicks);      // (or a light frame: tile_order_kernel)
-            g_rb.hist_mean = g_rb.host[2];
-            g_rb.host[0] = 0;
+            hist->wanted = 2ull * 5120ull * hist->stats[1] > 5ull * tiles * hist->stats[2] ||
+                           (hist->stats[2] != 0u && tiles * hist->stats[2] < kLightFrameTicks);      // (or a light frame: tile_order_kernel)
+            hist->mean = hist->stats[2];
+            hist->longest = hist->stats[1];
+            hist->decorrelated = hist->stats[4] != 0u;
+            hist->stats[0] = 0;
         }
-        order_now = g_rb.hist_wanted || (g_rb.hist_calls++ % 4u) == 1u;       // (call 0 has no ticks yet)
+        // (while the frames do not resemble each other the sort runs every call: it is what looks whether they do again — a
+        // camera cut is over after three frames — and it hands out the patch order as long as they do not)
+        order_now = hist->wanted || hist->decorrelated || (hist->calls % 4u) == 1u;       // (call 0 has no ticks yet)
+        ++hist->calls;
+        t_ticks = hist->ticks[hist->cur];                 // (this call's times; the order is sorted from the other set)
+        hist->cur ^= 1;
     }
     // geomState.rgb (GSCuda.cu:362-366) is a strided read nothing needs before the blend: by default it is written by a kernel
     // of its own on the second stream while the depth sort runs (launch_colors_visible, preprocess.hip). Whatever way the
@@ -503,11 +626,23 @@ int gsr_forward(gsr_forward_args* a) {
     const bool colors_movable = !inria && !a->colors_precomp && !(a->flags & GSR_FLAG_SERIAL_EMIT);
     const int colors_mode = !colors_movable ? 0 : (colors_forced >= 0 ? colors_forced : (n <= (1 << 24) ? 1 : 2));
     const bool colors_beside = colors_mode == 1;
+    // (SideJoin: whatever way the call is left — a failing step included — the caller's stream waits for what this call
+    // has put on the second stream: for `pending`, an event already recorded there, or, while `tail` is armed, for an
+    // event recorded behind everything the second stream holds at that moment)
     struct SideJoin {
         hipStream_t stream;
         hipEvent_t pending;
-        ~SideJoin() { if (pending) (void)hipStreamWaitEvent(stream, pending, 0); }
-    } colors_join{stream, nullptr};
+        Readback* rb;
+        bool tail;
+        ~SideJoin() {
+            if (tail && rb->side && rb->ev_join) {
+                if (hipEventRecord(rb->ev_join, rb->side) == hipSuccess) (void)hipStreamWaitEvent(stream, rb->ev_join, 0);
+                else (void)hipGetLastError();
+            } else if (pending) {
+                (void)hipStreamWaitEvent(stream, pending, 0);
+            }
+        }
+    } colors_join{stream, nullptr, &g_rb, false};
     if (colors_mode != 0) GSR_STEP(g_rb.ensure_colors());
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
@@ -526,7 +661,8 @@ int gsr_forward(gsr_forward_args* a) {
                                    gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2),
                                    gs.vis_partial, gs.sort_info + 1, g_rb.host_dev + 4,
                                    gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n),
-                                   gs.others_per_wave, gs.main_partial, kDepthSideMax, gs.sort_info + 8));
+                                   gs.others_per_wave, gs.main_partial, kDepthSideMax, gs.sort_info + 8,
+                                   gs.big_partial, kBigSplatTiles));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low
     // half is the same for every key of a Gaussian, so those digit passes run once per
@@ -561,20 +697,27 @@ int gsr_forward(gsr_forward_args* a) {
     if (colors_beside) {
         // (behind the read-back's event: tilesTouched is final there, and nothing is added to the caller's stream)
         GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_r, 0));
+        colors_join.tail = true;
         GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
         colors_join.pending = g_rb.ev_colors;
+        colors_join.tail = false;
     }
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
     GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
                              xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     if (order_now) {
-        // (behind the same event — it follows the last call's blend in stream order — and queued while the host would
+        // (behind the same event — it follows the history's last blend in stream order — and queued while the host would
         // only wait: nothing is added to the caller's stream, and by the time the blend is launched the order is there)
+        // From here until this call's blend has been launched the order belongs to no call (a backward of an earlier one
+        // must not take it: order_serial).
+        hist->order_serial = 0;
         GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_r, 0));
-        GSR_STEP(launch_tile_order(d, g_rb.tile_ticks, g_rb.tile_order, g_rb.host_dev, g_rb.side));
-        GSR_HIP_TRY(hipEventRecord(g_rb.ev_hist_join, g_rb.side));
+        bool sorted = false;
+        GSR_STEP(launch_tile_order(d, hist->ticks[hist->cur], t_ticks, hist->order, hist->stats_dev, g_rb.side, &sorted));
+        if (sorted) GSR_HIP_TRY(hipEventRecord(hist->ev_order, g_rb.side));
+        else order_now = false;                               // (no room for the sort on this device: patch order)
     }
     GSR_HIP_TRY(hipEventSynchronize(g_rb.ev_r));
     // The reference's offsets are u32 (AuxBuffer.cuh:51): a frame whose instance count does not fit them would size
@@ -633,7 +776,15 @@ int gsr_forward(gsr_forward_args* a) {
     // The block plan pays per (Gaussian, block) entry and per unit, the sort plan 36 bytes per instance: what decides is
     // the instances per VISIBLE Gaussian. Measured (binning without the blend, sort / blocks): R/V = 2.7 (50 M tiny splats)
     // 5.6 / 5.9 ms, 5.3 (the bench scene from far away) 0.98 / 1.00 ms, 7.5: 2.08 / 1.81 ms, 11: 2.76 / 1.58 ms, 88: 2x.
-    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS)) use_blocks = (uint64_t)R >= 6ull * (uint64_t)nv;
+    // ... of the splats that ARE small: the sort plan's emission walks a Gaussian's columns and keys chunk by chunk of 512
+    // Gaussians, and a few hundred background splats that cover a thousand tiles each (any trained scene seen from outside)
+    // make its slowest chunks five times the others — 1 M flat splats + 500 huge ones from 48 units away, R/V = 2.8:
+    // 1.53 against 1.08 ms; 5.8 M: 2.46 / 2.14 (`profiles/r05_trained_like.txt`). The scan has counted the instances of the
+    // splats of kBigSplatTiles tiles and more (host words 14-15): with an eighth of the frame's instances in such splats the
+    // frame goes to the block plan whatever its average.
+    const unsigned long long big_instances = (unsigned long long)g_rb.host[14] | ((unsigned long long)g_rb.host[15] << 32);
+    if (use_blocks && !(a->flags & GSR_FLAG_PLAN_BLOCKS))
+        use_blocks = (uint64_t)R >= kBlockPlanMinInstances * (uint64_t)nv || 8ull * big_instances >= (unsigned long long)R;
     a->plan_used = use_blocks ? GSR_PLAN_BLOCKS : (xy_plan ? GSR_PLAN_SORT : GSR_PLAN_GENERIC);
     // (the block plan has no R-sized sort: sortingSpace then holds its unit tables, not look-back words)
     if (!use_blocks)
@@ -662,21 +813,41 @@ int gsr_forward(gsr_forward_args* a) {
         // over the chip's 5 120 wave slots — is expected to be the shorter of the two (the emission: 12 R bytes at 5 TB/s);
         // a blend already running beside the emission takes about twice as long per tile, hence the second threshold.
         bool overlap = (a->flags & GSR_FLAG_OVERLAP_EMIT) != 0;
-        if (!overlap && !(a->flags & GSR_FLAG_SERIAL_EMIT) && history && g_rb.hist_mean != 0u && (uint64_t)R >= 48ull * (uint64_t)nv) {
+        // (not while the history's frames do not resemble each other: the last frame's tile times then say nothing about this one)
+        if (!overlap && !(a->flags & GSR_FLAG_SERIAL_EMIT) && history && hist->mean != 0u && !hist->decorrelated &&
+            (uint64_t)R >= kOverlapMinInstances * (uint64_t)nv) {
             const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
-            const unsigned long long blend_ticks = (unsigned long long)g_rb.hist_mean * tiles / 5120ull;
-            const unsigned long long emit_ticks = 12ull * (unsigned long long)R / 50000ull;
-            overlap = blend_ticks < (g_rb.overlapped ? 2ull : 1ull) * emit_ticks;
+            // how long the blend will take: the tiles' times spread over the chip's 5 120 wave slots — beside the emission, whose
+            // persistent workgroups keep their registers, over the 3 072 it gets there —, but never less than the longest tile
+            // (frames of small splats end on a few lone waves: the mean alone said 0.16 ms for a blend of 0.36)
+            unsigned long long blend_ticks = std::max((unsigned long long)hist->mean * tiles / (hist->overlapped ? 3072ull : 5120ull),
+                                                      (unsigned long long)hist->longest);
+            // (times of a blend fed from the SORTED lists: out of the block lists a tile walks every unit of its block for its
+            // entries — measured on the stand-in, block feed over sorted-list feed: 1.1 at 88 instances per visible Gaussian,
+            // 1.44 at 23, 3 at 5 = 1 + 10 V / R)
+            if (!hist->block_fed) blend_ticks = blend_ticks * ((unsigned long long)R + 10ull * (unsigned long long)nv) / (unsigned long long)R;
+            // The emission: 12 R bytes at 5 TB/s — then the blend must be the shorter of the two, beside a kernel that fills
+            // the memory pipes it is throttled (the stand-in from outside the cloud, R/V = 22: 1.66 -> 1.99 ms) —, but never
+            // under the 0.11 ms a wave takes for its one unit: a light frame's emission leaves the chip idle, and a blend of
+            // up to twice that still gains beside it (1 M flat splats, frames of 0.45 ms: 8-17 %; `profiles/r05_trained_like.txt`).
+            // Once overlapped, the times are those of a blend that shares the chip (up to twice as long): it stays beside the
+            // emission while it ends within 1.5 times the limit (break-even is 2: max(e, b') against e + b' / 2) — a looser
+            // bound keeps a frame overlapped whose blend has become the longer of the two (the stand-in from outside the cloud
+            // entered from an overlapped pose: 1.48 -> 1.70 ms, for good).
+            const unsigned long long emit_bw = 12ull * (unsigned long long)R / 50000ull, emit_floor = 11000ull;
+            const unsigned long long limit = emit_bw >= emit_floor ? emit_bw : 2ull * emit_floor;
+            overlap = hist->overlapped ? 2ull * blend_ticks < 3ull * limit : blend_ticks < limit;
         }
         const bool serial = !overlap || (a->flags & GSR_FLAG_NO_SORTED_LISTS);
-        g_rb.overlapped = !serial;
+        if (history) hist->overlapped = !serial;
         if (!serial) a->plan_used |= GSR_PLAN_EMIT_OVERLAPPED;
         // Which lists feed the blend. Out of the block lists a tile walks every unit of its block and picks its entries
         // by mask: as good as the sorted list where a Gaussian covers most tiles of its blocks, but with small splats a
         // tile owns a few of a unit's 2048 entries and pays a round trip to memory per unit for them (the bench scene
         // from outside the cloud, R/V = 23: 0.65 against 0.45 ms; from far away, R/V = 5: 1.98 against 0.65 ms; bench
         // frame, R/V = 88: equal). With the sorted lists written anyway, sparse frames blend from them.
-        blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) && (uint64_t)R < 48ull * (uint64_t)nv;
+        blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) && (uint64_t)R < kBlockFeedMinInstances * (uint64_t)nv;
+        if (history) hist->block_fed = !blend_from_lists;
         // (the emission stays on the caller's stream and is launched first: its persistent workgroups must be resident
         // before the blend's thousands of waves arrive — the other way round the blend takes every register file and the
         // emission starts when the blend is nearly over: no gain)
@@ -685,6 +856,7 @@ int gsr_forward(gsr_forward_args* a) {
             GSR_HIP_TRY(hipEventRecord(g_rb.ev_fork, stream));
             GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_fork, 0));
             forked = true;
+            colors_join.tail = true;                          // (until the join at the end of the call has been queued)
         }
         hipStream_t emit_stream = stream;
         // (What a gsr_backward call after this one may use — the block lists and, for its per-entry gradient sums, the
@@ -766,14 +938,13 @@ int gsr_forward(gsr_forward_args* a) {
         a->plan_used |= GSR_PLAN_COLORS_BESIDE;
     }
     // (the order: long since sorted — the blend's stream is made to wait only if it is not)
-    if (order_now && hipEventQuery(g_rb.ev_hist_join) != hipSuccess) {
+    if (order_now && hipEventQuery(hist->ev_order) != hipSuccess) {
         (void)hipGetLastError();                              // ("not ready" is no error of this call)
-        GSR_HIP_TRY(hipStreamWaitEvent(blend_stream, g_rb.ev_hist_join, 0));
+        GSR_HIP_TRY(hipStreamWaitEvent(blend_stream, hist->ev_order, 0));
     }
-    const uint32_t* const t_order = order_now ? g_rb.tile_order : nullptr;
-    if (order_now) a->plan_used |= GSR_PLAN_TILES_REORDERED;
-    g_rb.order_serial = order_now ? serial : 0u;
-    uint32_t* const t_ticks = history ? g_rb.tile_ticks : nullptr;
+    const uint32_t* const t_order = order_now ? hist->order : nullptr;
+    if (order_now && !hist->decorrelated) a->plan_used |= GSR_PLAN_TILES_REORDERED;
+    if (history && hist->decorrelated) a->plan_used |= GSR_PLAN_TILE_ORDER_DROPPED;
     // Colours beside the blend (scenes beyond 16 M Gaussians): the blend takes them from the SH array; geomState.rgb is
     // written meanwhile on the other stream — or, where the blend itself runs on the second stream beside the emission,
     // behind it there — and the caller's stream waits for it before the call's work is complete.
@@ -781,9 +952,11 @@ int gsr_forward(gsr_forward_args* a) {
     if (colors_late && !forked) {
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_pre_blend, stream));
         GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_pre_blend, 0));
+        colors_join.tail = true;
         GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
         colors_join.pending = g_rb.ev_colors;                 // (joined when this function is left)
+        colors_join.tail = false;
     }
     if (colors_late) { colors = a->shs; a->plan_used |= GSR_PLAN_COLORS_BESIDE; }
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
@@ -795,11 +968,13 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
                               t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks, colors_late));       // :804-810
+    if (order_now) hist->order_serial = serial;               // (the blend that takes the order is in its stream: a backward of this call may take it too)
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is
         if (colors_late) GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));   // (beside the rest of the emission)
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
         GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));
+        colors_join.tail = false;
     }
 
     if (profile || count_staged) {

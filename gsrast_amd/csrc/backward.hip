@@ -915,7 +915,7 @@ static int backward_impl(gsr_backward_args* a) {
     r.dims = d;
     r.num_tiles = (d.row_end - d.row_begin) * d.grid_x;
     // (the tiles that were slow in the forward blend are the slow ones here: they go first, as they did there)
-    r.tile_order = have_receipt ? tile_order_of_call(a->receipt.serial, a->width, a->height, d.row_begin, d.row_end) : nullptr;
+    r.tile_order = have_receipt ? tile_order_of_call(a->receipt, d.row_begin, d.row_end) : nullptr;
     // (all blocks of the frame, also in a sharded call: the blocks outside the band were not walked)
     const unsigned acc_wgs = (unsigned)(((d.grid_x + kBW - 1) / kBW) * ((d.grid_y + kBH - 1) / kBH)) * kAccParts;
     if (r.num_tiles > 0) {

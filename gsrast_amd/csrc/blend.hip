@@ -13,6 +13,7 @@
 // 1/255 cut for every lane) is skipped after the power evaluation by one ballot.
 
 #include <algorithm>
+#include <map>
 #include <type_traits>
 
 #include "blend_core.hpp"
@@ -143,29 +144,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void bl
 // together on one XCD's L2. What separates the two groups on every frame measured is the tile time per wave slot (78-243
 // us against 313-2 131 us): below 250 us the frame is sorted whole, above it only the tiles beyond twice the mean move —
 // there nobody loses. The padding of the patch grid sorts to the end. `stats` (pinned host words): the longest tile, the mean.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ticks, uint32_t* __restrict__ order,
+//
+// Whether the frame before says anything about this one is read off the frame before THAT (ticks_before): similarity =
+// sum over the tiles of min(t / T, t' / T'), each frame's times as shares of its own total T — how much of the time goes
+// to the same tiles, whatever the level (the same frame blended beside the emission takes twice as long in every tile).
+// A camera that moves, or stands still, keeps it near one; a caller that draws another view every call (a trainer; two
+// views alternating on one history) does not, and an order made from an unrelated frame is a random order: 5-28 % slower
+// than the patch order. Below kMinSimilarity the patch order goes out (stats[4] = 1: the host then stops asking for the
+// order except every fourth call, which looks again). A frame before without any times (the history is new, or was
+// cleared) counts as similar.
+// (bench scene, 1920 x 1080, scripts/history_similarity.py, `profiles/r05_history_similarity.txt`)
+// along bench.py's camera path (0.31 units a frame) 0.85 to 0.97, median 0.91; between unrelated views 0.51 to 0.90, median 0.77
+constexpr uint32_t kMinSimilarity = 800;         // of 1000
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ticks, const uint32_t* __restrict__ ticks_before,
+                                                          uint32_t* __restrict__ order,
                                                           int workgroups, int padded, int grid_x, int row_begin, int rows,
                                                           uint32_t* __restrict__ stats) {
     extern __shared__ uint32_t s_key[];
-    __shared__ unsigned long long s_sum;
+    __shared__ unsigned long long s_sum, s_common, s_before;
     __shared__ uint32_t s_cnt, s_max;
-    if (threadIdx.x == 0) { s_sum = 0; s_cnt = 0; s_max = 0; }
+    if (threadIdx.x == 0) { s_sum = 0; s_cnt = 0; s_max = 0; s_common = 0; s_before = 0; }
     __syncthreads();
-    unsigned long long sum = 0;
+    unsigned long long sum = 0, sum_before = 0;
     uint32_t cnt = 0, mx = 0;
     for (int i = threadIdx.x; i < workgroups; i += 1024) {
         const int tile_local = tile_of_workgroup(i, grid_x, rows);
-        if (tile_local >= 0) { const uint32_t t = ticks[row_begin * grid_x + tile_local]; sum += t; mx = max(mx, t); ++cnt; }
+        if (tile_local >= 0) {
+            const uint32_t t = ticks[row_begin * grid_x + tile_local];
+            sum += t; mx = max(mx, t); ++cnt;
+            sum_before += ticks_before[row_begin * grid_x + tile_local];
+        }
     }
     atomicAdd(&s_sum, sum);
     atomicAdd(&s_cnt, cnt);
     atomicMax(&s_max, mx);
+    atomicAdd(&s_before, sum_before);
     __syncthreads();
+    // shares in units of 2^-20 of the frame's total (a tile's time is below 2^32, times 2^20 fits 64 bits)
+    unsigned long long common = 0;
+    const unsigned long long total = max(s_sum, 1ull), total_before = max(s_before, 1ull);
+    for (int i = threadIdx.x; i < workgroups; i += 1024) {
+        const int tile_local = tile_of_workgroup(i, grid_x, rows);
+        if (tile_local >= 0) {
+            const unsigned long long a = ((unsigned long long)ticks[row_begin * grid_x + tile_local] << 20) / total;
+            const unsigned long long b = ((unsigned long long)ticks_before[row_begin * grid_x + tile_local] << 20) / total_before;
+            common += min(a, b);
+        }
+    }
+    atomicAdd(&s_common, common);
+    __syncthreads();
+    const uint32_t similarity = s_before == 0ull ? 1000u : (uint32_t)min(1000ull, (1000ull * s_common) >> 20);
+    const bool dropped = similarity < kMinSimilarity;
     // (a LIGHT frame — less than 250 us of tile time per wave slot — is sorted whole: its lists are short, it lasts as long as
     // its longest tiles whatever the neighbours do; see kLightFrameTicks)
     const unsigned long long slow_from = s_sum < kLightFrameTicks ? 0ull : 2ull * s_sum / max(s_cnt, 1u);
-    // what the host decides on whether the next calls need an order at all: {longest tile, mean, fresh}
-    if (stats && threadIdx.x == 0) { stats[1] = s_max; stats[2] = (uint32_t)(s_sum / max(s_cnt, 1u)); __threadfence_system(); stats[0] = 1u; }
+    // what the host decides on whether the next calls need an order at all: {fresh, longest tile, mean, similarity, dropped}
+    if (stats && threadIdx.x == 0) {
+        stats[1] = s_max; stats[2] = (uint32_t)(s_sum / max(s_cnt, 1u)); stats[3] = similarity; stats[4] = dropped ? 1u : 0u;
+        __threadfence_system();
+        stats[0] = 1u;
+    }
+    if (dropped) {                                   // (the patch order itself)
+        for (int i = threadIdx.x; i < workgroups; i += 1024) order[i] = (uint32_t)i;
+        return;
+    }
     for (int i = threadIdx.x; i < padded; i += 1024) {
         uint32_t key = 0xFFF00000u | (uint32_t)i;
         if (i < workgroups) {
@@ -260,18 +302,33 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
 
 // (see TileOrder, blend_core.hpp) `order` receives patch_workgroups(...) entries; asynchronous on stream
 int tile_order_workgroups(const FrameDims& d) { return patch_workgroups(d.grid_x, d.row_end - d.row_begin); }
-int launch_tile_order(const FrameDims& d, const uint32_t* ticks, uint32_t* order, uint32_t* stats, hipStream_t stream) {
+int launch_tile_order(const FrameDims& d, const uint32_t* ticks, const uint32_t* ticks_before, uint32_t* order, uint32_t* stats,
+                      hipStream_t stream, bool* sorted) {
+    *sorted = false;
     const int workgroups = tile_order_workgroups(d);
     if (workgroups <= 0) return GSR_OK;
     int padded = 2;
     while (padded < workgroups) padded <<= 1;
     if (padded > kTileOrderMax) return GSR_ERR_INVALID_ARG;
-    if ((size_t)padded * sizeof(uint32_t) > 48 * 1024)      // (per device: as for coarse_emit_kernel, blockbin.hip)
-        GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        kTileOrderMax * (int)sizeof(uint32_t)));
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), (size_t)padded * sizeof(uint32_t), stream, ticks, order, workgroups,
-                       padded, d.grid_x, d.row_begin, d.row_end - d.row_begin, stats);
+    if ((size_t)padded * sizeof(uint32_t) > 48 * 1024) {
+        // more than the default 48 KB of dynamic LDS: asked for once per device; a device that has not got the 128 KB goes
+        // without the order (the call is none the worse for it)
+        static thread_local std::map<int, bool> lds_ok;
+        int dev = 0;
+        GSR_HIP_TRY(hipGetDevice(&dev));
+        auto it = lds_ok.find(dev);
+        if (it == lds_ok.end()) {
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                kTileOrderMax * (int)sizeof(uint32_t)) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            it = lds_ok.emplace(dev, ok).first;
+        }
+        if (!it->second) return GSR_OK;
+    }
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), (size_t)padded * sizeof(uint32_t), stream, ticks, ticks_before, order,
+                       workgroups, padded, d.grid_x, d.row_begin, d.row_end - d.row_begin, stats);
     GSR_LAUNCH_CHECK("tile_order_kernel");
+    *sorted = true;
     return GSR_OK;
 }
 

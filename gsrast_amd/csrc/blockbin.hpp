@@ -44,10 +44,10 @@ BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_
 // Which lists the forward call that issued `r` left for a backward call with these sizes / rows / point_list (api.hip):
 // *lists_written — the sorted lists are in point_list; *from_blocks — it ran the block plan and blended from the block
 // lists: *feed says where they are. GSR_ERR_INVALID_ARG if the receipt does not fit the arguments or promises no list.
-// The order the calling thread's last gsr_forward call on the current device gave its blend workgroups (slow tiles
-// first: TileOrder, blend_core.hpp), if it made one for exactly these dimensions and call `serial`; else null. A hint: the
-// render backward's tiles take long where the forward's did.
-const uint32_t* tile_order_of_call(uint32_t serial, int width, int height, int row_begin, int row_end);
+// The order the gsr_forward call that issued `r` gave its blend workgroups (slow tiles first: TileOrder, blend_core.hpp), if
+// it made one for exactly these rows and its tile history still holds it (the receipt's own history, or one of the calling
+// thread's); else null. A hint: the render backward's tiles take long where the forward's did.
+const uint32_t* tile_order_of_call(const gsr_forward_receipt& r, int row_begin, int row_end);
 int lists_of_receipt(const gsr_forward_receipt& r, int n, int width, int height, int row_begin, int row_end,
                      const void* point_list, BlockFeed* feed, bool* from_blocks, bool* lists_written);
 

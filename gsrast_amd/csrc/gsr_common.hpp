@@ -61,7 +61,8 @@ int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* tem
                           unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr,
                           uint32_t* host_words = nullptr, void* clear = nullptr, size_t clear_bytes = 0,
                           const uint32_t* others_per_wave = nullptr, uint32_t* main_count = nullptr,
-                          uint32_t side_max = 0, uint32_t* side_words = nullptr);
+                          uint32_t side_max = 0, uint32_t* side_words = nullptr,
+                          uint32_t* big = nullptr, uint32_t big_from = 0);     // big (u32 per 4096 elements, needs host_words): host_words[10..11] = the 64-bit sum of the elements >= big_from
 size_t scan_temp_bytes(size_t n);
 
 int launch_gather_counts(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* tiles_touched,
@@ -144,7 +145,10 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
 constexpr int kTileOrderMax = 32768;      // workgroups (one per tile, patch grid padded) up to which the order is kept: 128 KB of LDS for its sort
 constexpr unsigned long long kLightFrameTicks = 25000ull * 5120ull;   // 250 us (in 10 ns) per wave slot of the chip, summed over the tiles
 int tile_order_workgroups(const FrameDims& d);
-int launch_tile_order(const FrameDims& d, const uint32_t* ticks, uint32_t* order, uint32_t* stats, hipStream_t stream);
+// ticks / ticks_before: the tile times of the history's last frame and of the one before it; *sorted = false (and nothing
+// launched): this device has no room for the sort's LDS
+int launch_tile_order(const FrameDims& d, const uint32_t* ticks, const uint32_t* ticks_before, uint32_t* order, uint32_t* stats,
+                      hipStream_t stream, bool* sorted);
 
 int launch_exp_test(int n, const float* in, float* out, hipStream_t stream);
 int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,

@@ -65,6 +65,8 @@ __device__ __forceinline__ void load_items(const uint32_t* in, size_t n, size_t 
     }
 }
 
+// big / big_from (big may be null): also the sum of the tile's elements that are >= big_from (a tile's own sum cannot wrap) — gsr_forward's
+// choice of the binning plan wants to know how much of the frame's instances belongs to splats that cover hundreds of tiles.
 // nonzero (may be null): also the number of non-zero elements of the tile — gsr_forward's depth order compacts the
 // Gaussians with tilesTouched != 0 in chunks of the same 4096 elements, and this kernel has them in registers anyway.
 // clear / clear_vecs (may be null / 0): 16-byte words this launch also zeroes, a slice per thread — gsr_forward's depth
@@ -77,8 +79,9 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
                                                                     uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero,
                                                                     uint4* __restrict__ clear, size_t clear_vecs,
                                                                     const uint32_t* __restrict__ others_per_wave,
-                                                                    uint32_t* __restrict__ main_count) {
-    __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave];
+                                                                    uint32_t* __restrict__ main_count,
+                                                                    uint32_t* __restrict__ big, uint32_t big_from) {
+    __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave], wave_big[kScanThreads / kWave];
     for (size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x; i < clear_vecs; i += (size_t)gridDim.x * kScanThreads)
         clear[i] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t v[kScanItems];
@@ -88,20 +91,22 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
         const size_t w = (size_t)blockIdx.x * (kScanTile / kWave) + threadIdx.x;
         others = (w * kWave < n) ? others_per_wave[w] : 0u;
     }
-    uint32_t s = 0, z = 0;
+    uint32_t s = 0, z = 0, b = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) { s += v[k]; z += v[k] != 0u ? 1u : 0u; }
+    for (int k = 0; k < kScanItems; ++k) { s += v[k]; z += v[k] != 0u ? 1u : 0u; b += v[k] >= big_from ? v[k] : 0u; }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
         s += __shfl_down(s, off, kWave); z += __shfl_down(z, off, kWave); others += __shfl_down(others, off, kWave);
+        b += __shfl_down(b, off, kWave);
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) { wave_sums[threadIdx.x / kWave] = s; wave_nz[threadIdx.x / kWave] = z; }
+    if ((threadIdx.x & (kWave - 1)) == 0) { wave_sums[threadIdx.x / kWave] = s; wave_nz[threadIdx.x / kWave] = z; wave_big[threadIdx.x / kWave] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0, tz = 0;
+        uint32_t t = 0, tz = 0, tb = 0;
 #pragma unroll
-        for (int w = 0; w < kScanThreads / kWave; ++w) { t += wave_sums[w]; tz += wave_nz[w]; }
+        for (int w = 0; w < kScanThreads / kWave; ++w) { t += wave_sums[w]; tz += wave_nz[w]; tb += wave_big[w]; }
         partial[blockIdx.x] = t;
+        if (big) big[blockIdx.x] = tb;
         if (nonzero) nonzero[blockIdx.x] = tz;
         if (main_count) main_count[blockIdx.x] = tz - others;             // (thread 0 holds the first wave's sum)
     }
@@ -117,15 +122,17 @@ __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict
                                                             unsigned long long* __restrict__ total64,
                                                             uint32_t* __restrict__ nonzero, uint32_t* __restrict__ nonzero_total,
                                                             uint32_t* __restrict__ host_words, uint32_t* __restrict__ main_count,
-                                                            uint32_t side_max, uint32_t* __restrict__ side_words) {
+                                                            uint32_t side_max, uint32_t* __restrict__ side_words,
+                                                            const uint32_t* __restrict__ big) {
     __shared__ uint32_t wave_sums[1024 / kWave];
-    __shared__ unsigned long long wide_sums[1024 / kWave];
+    __shared__ unsigned long long wide_sums[1024 / kWave], big_sums[1024 / kWave];
     uint32_t carry = 0, carry_nz = 0, carry_main = 0;
-    unsigned long long wide = 0;
+    unsigned long long wide = 0, wide_big = 0;
     for (size_t base = 0; base < tiles; base += 1024) {
         const size_t i = base + threadIdx.x;
         const uint32_t v = (i < tiles) ? partial[i] : 0u;
         wide += v;
+        if (big && i < tiles) wide_big += big[i];
         uint32_t total;
         const uint32_t excl = block_exclusive_scan<1024>(v, wave_sums, total);
         if (i < tiles) partial[i] = carry + excl;
@@ -163,15 +170,18 @@ __global__ __launch_bounds__(1024) void partial_scan_kernel(uint32_t* __restrict
     }
     if (total64) {
 #pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) wide += __shfl_down(wide, off, kWave);
-        if ((threadIdx.x & (kWave - 1)) == 0) wide_sums[threadIdx.x / kWave] = wide;
+        for (int off = kWave / 2; off > 0; off >>= 1) { wide += __shfl_down(wide, off, kWave); wide_big += __shfl_down(wide_big, off, kWave); }
+        if ((threadIdx.x & (kWave - 1)) == 0) { wide_sums[threadIdx.x / kWave] = wide; big_sums[threadIdx.x / kWave] = wide_big; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long t = 0;
+            unsigned long long t = 0, tb = 0;
 #pragma unroll
-            for (int w = 0; w < 1024 / kWave; ++w) t += wide_sums[w];
+            for (int w = 0; w < 1024 / kWave; ++w) { t += wide_sums[w]; tb += big_sums[w]; }
             *total64 = t;
-            if (host_words) *reinterpret_cast<unsigned long long*>(host_words + 2) = t;
+            if (host_words) {
+                *reinterpret_cast<unsigned long long*>(host_words + 2) = t;
+                if (big) *reinterpret_cast<unsigned long long*>(host_words + 10) = tb;      // (the instances of splats of big_from tiles and more)
+            }
         }
     }
 }
@@ -219,17 +229,18 @@ size_t scan_temp_bytes(size_t n) {
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
                           unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total, uint32_t* host_words,
                           void* clear, size_t clear_bytes, const uint32_t* others_per_wave, uint32_t* main_count,
-                          uint32_t side_max, uint32_t* side_words) {
+                          uint32_t side_max, uint32_t* side_words, uint32_t* big, uint32_t big_from) {
     if (n == 0) return GSR_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
     if (clear_bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(clear) & 15) != 0 || (host_words && !total64)) return GSR_ERR_INVALID_ARG;
     if ((others_per_wave != nullptr) != (main_count != nullptr) || (main_count && (!nonzero || !side_words))) return GSR_ERR_INVALID_ARG;
+    if (big && !host_words) return GSR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero,
-                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, others_per_wave, main_count);
+                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, others_per_wave, main_count, big, big_from);
     GSR_LAUNCH_CHECK("tile_reduce_kernel");
     hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total, host_words,
-                       main_count, side_max, side_words);
+                       main_count, side_max, side_words, big);
     GSR_LAUNCH_CHECK("partial_scan_kernel");
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, partial);
     GSR_LAUNCH_CHECK("tile_scan_kernel");

@@ -89,6 +89,20 @@ class SplatRasterizer:
         self._cam_host = torch.zeros(35, dtype=torch.float32).pin_memory()
         self._view, self._proj, self._cam_pos = self._cam_dev[0:16], self._cam_dev[16:32], self._cam_dev[32:35]
         self._last_cam = None
+        # this view's tile history (gsr_tile_history: how long the tiles of its last frames took; the blend starts the slow
+        # ones first). One per rasterizer object, so two of them on one thread do not feed each other's frames.
+        self._history = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.gsr_tile_history_create(C.byref(self._history)), "gsr_tile_history_create")
+
+    def __del__(self):
+        h, self._history = getattr(self, "_history", None), None
+        if h is not None and h.value:
+            try:
+                torch.cuda.synchronize(self.device)          # (the streams it was used on must be idle)
+                self.lib.gsr_tile_history_destroy(h)
+            except Exception:
+                pass
 
     # -- scene upload -----------------------------------------------------------------
     def configure_from_scene(self, scene: dict, use_rects: bool = True) -> None:
@@ -124,7 +138,7 @@ class SplatRasterizer:
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
              sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
              overlap_emit: "bool | None" = None, sorted_lists: bool = True, colors_precomp: bool = False,
-             tile_history: bool = True) -> torch.Tensor:
+             tile_history: "bool | str" = True) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
@@ -132,7 +146,9 @@ class SplatRasterizer:
         plan: "auto" | "sort" | "blocks" — binning plan (GSR_FLAG_PLAN_*); the one used is in last_plan.
         overlap_emit: True = GSR_FLAG_OVERLAP_EMIT (block plan: the blend on a second stream beside the emission), False =
         GSR_FLAG_SERIAL_EMIT, None = the library decides per call (last_emit_overlapped tells).
-        tile_history=False: GSR_FLAG_NO_TILE_HISTORY (the blend does not start the last frame's slowest tiles first).
+        tile_history=False: GSR_FLAG_NO_TILE_HISTORY (the blend does not start the last frame's slowest tiles first); True: this
+        object's own gsr_tile_history; "default": none passed — the library's own for the calling thread and stream (what a
+        caller of the reference's signature gets); last_tile_order_dropped: the history's frames did not resemble each other.
         sorted_lists=False: GSR_FLAG_NO_SORTED_LISTS (forward-only callers; last_lists_written tells whether the
         binning chunk holds the sorted keys / values of this call).
         colors_precomp: pass the scene's colours as the reference's `colorsPrecomp` argument (GSCuda.cuh:111) — computed once
@@ -169,6 +185,7 @@ class SplatRasterizer:
         a.rects = self.rects.data_ptr() if (self.rects is not None and not inria) else None
         a.box_min = a.box_max = None
         a.stream = torch.cuda.current_stream(self.device).cuda_stream
+        a.tile_history = self._history if tile_history is True else None
         if tile_rows is not None:
             a.tile_row_begin, a.tile_row_end = int(tile_rows[0]), int(tile_rows[1])
         with torch.cuda.device(self.device):
@@ -185,6 +202,7 @@ class SplatRasterizer:
         # block plan only: did the blend read the sorted lists (sparse frames) instead of the block lists
         self.last_blend_from_lists = bool(int(a.plan_used) & _capi.GSR_PLAN_BLEND_FROM_LISTS)
         self.last_tiles_reordered = bool(int(a.plan_used) & _capi.GSR_PLAN_TILES_REORDERED)
+        self.last_tile_order_dropped = bool(int(a.plan_used) & _capi.GSR_PLAN_TILE_ORDER_DROPPED)
         self.last_emit_overlapped = bool(int(a.plan_used) & _capi.GSR_PLAN_EMIT_OVERLAPPED)
         self.last_colors_beside = bool(int(a.plan_used) & _capi.GSR_PLAN_COLORS_BESIDE)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
@@ -192,6 +210,13 @@ class SplatRasterizer:
             torch.cuda.current_stream(self.device).synchronize()
             self.poll_async_error()
         return self.out_color
+
+    def tile_history_stats(self) -> dict:
+        """gsr_tile_history_stats of this object's history (host side; what the last sort of the blend's tile order found)."""
+        out = (C.c_uint32 * 6)()
+        _capi.check(self.lib.gsr_tile_history_stats(self._history, out), "gsr_tile_history_stats")
+        return {"mean_ticks": int(out[0]), "longest_ticks": int(out[1]), "similarity": int(out[2]) / 1000.0,
+                "order_dropped": bool(out[3]), "calls": int(out[4]), "overlapped": bool(out[5])}
 
     def precomputed_colors(self) -> torch.Tensor:
         """vec3[N] = 0.5 + 0.4 DC (gsr_colors_from_dc), computed on first use and kept for the scene."""
@@ -256,7 +281,8 @@ class SplatRasterizer:
         and, with with_cov3D, dL_dcov2D [N,4] (m00, m01, m11, 0), dL_dcov3D [N,6], dL_dshs [N,48] (gscuda: the DC triple only; inria: every coefficient
         up to sh_degree), dL_dmeans3D / dL_dscales / dL_drotations [N,4].
         wide_sums: accumulate the per-Gaussian sums in double (gsr_backward_args.sums_f64: 96 N bytes of scratch kept by this
-        object, zero between calls) — the gradients of screen-filling splats then no longer depend on the order in which the
+        object for as long as it lives — 0.56 GB for the 5.8 M-splat bench scene, 4.8 GB at 50 M; wide_sums=False does without
+        it —, zero between calls and dropped if a call fails) — the gradients of screen-filling splats then no longer depend on the order in which the
         tiles' atomics arrive. outputs (needs wide_sums): the names to compute, e.g. BASELINE config 5's ("dL_dmean2D",
         "dL_dcov3D", "dL_dshs"); the others are neither computed nor written (the chain is bound by its writes) and
         absent from the result. The tensors are owned by this object and overwritten by the next call."""
@@ -330,6 +356,8 @@ class SplatRasterizer:
             a.receipt = rcpt
         with torch.cuda.device(dev):
             rc = self.lib.gsr_backward(C.byref(a))
+        if rc != _capi.GSR_OK and wide_sums:
+            self._sums_f64 = None           # (a call that failed half way may have left sums behind: the next call starts from a zeroed scratch again)
         _capi.check(rc, "gsr_backward")
         self.last_backward_ms = (float(a.stage_ms[0]), float(a.stage_ms[1])) if profile else ()
         torch.cuda.current_stream(dev).synchronize()

@@ -114,6 +114,96 @@ def stress_scene(n: int = 50_000_000, seed: int = 44, full_sh: bool = False) -> 
     return _pack(pos, scale, quat, opacity, dc, rest)
 
 
+def _quat_from_columns(t1: np.ndarray, t2: np.ndarray, t3: np.ndarray) -> np.ndarray:
+    """Unit quaternions (real part first) of the rotations whose matrix has columns t1, t2, t3 (right-handed, orthonormal)."""
+    m00, m10, m20 = t1[:, 0], t1[:, 1], t1[:, 2]
+    m01, m11, m21 = t2[:, 0], t2[:, 1], t2[:, 2]
+    m02, m12, m22 = t3[:, 0], t3[:, 1], t3[:, 2]
+    # the largest of the four squared components is computed from the trace, the others from the off-diagonal sums
+    q = np.empty((t1.shape[0], 4))
+    w2, x2 = 1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22
+    y2, z2 = 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22
+    pick = np.argmax(np.stack([w2, x2, y2, z2], axis=1), axis=1)
+    for k, (d2, comps) in enumerate(((w2, (None, m21 - m12, m02 - m20, m10 - m01)),
+                                     (x2, (m21 - m12, None, m01 + m10, m02 + m20)),
+                                     (y2, (m02 - m20, m01 + m10, None, m12 + m21)),
+                                     (z2, (m10 - m01, m02 + m20, m12 + m21, None)))):
+        sel = pick == k
+        if not sel.any():
+            continue
+        r = np.sqrt(np.maximum(d2[sel], 1e-12))
+        for c in range(4):
+            q[sel, c] = 0.5 * r if comps[c] is None else 0.5 * comps[c][sel] / r
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def trained_like(n: int = 1_000_000, seed: int = 45) -> dict:
+    """What a TRAINED scene looks like to the rasterizer, as far as a generator can say (the garden .ply itself is not
+    available offline; SplatData.cpp:114-156 loads such files): splats lie ON surfaces — a ground plane, a few hundred
+    plane patches and shells — and are FLAT (the scale along the surface normal 10-100 times smaller than the two in the
+    surface), their in-surface scales are log-normal with a heavy tail, opacity is bimodal (most splats nearly opaque, a
+    third nearly transparent), and some 500 huge splats far out stand for the background. Deterministic (splitmix64)."""
+    s = Stream(seed)
+    n_bg = min(500, n // 20)
+    n_fg = n - n_bg
+    n_surf = 320
+    kind = s.uniform(n_surf)                                   # < 0.7: plane patch, else shell
+    centre = s.normal(n_surf, 3) * np.array([4.0, 1.2, 4.0])
+    normal = s.normal(n_surf, 3)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    ext = np.exp(math.log(0.3) + s.uniform(n_surf, 2) * (math.log(3.0) - math.log(0.3)))      # plane half-extents
+    radius = np.exp(math.log(0.2) + s.uniform(n_surf) * (math.log(1.5) - math.log(0.2)))
+    base_dc = s.normal(n_surf, 3)
+    is_plane = kind < 0.7
+    # surface 0 is the ground: a big plane below the camera (the inverted-up convention: +y is down)
+    centre[0], normal[0], ext[0], is_plane[0] = (0.0, 1.6, 0.0), (0.0, -1.0, 0.0), (12.0, 12.0), True
+    area = np.where(is_plane, 4.0 * ext[:, 0] * ext[:, 1], 4.0 * math.pi * radius ** 2)
+    area[0] *= 0.35                                            # (the ground is sampled more thinly than the objects)
+    cum = np.cumsum(area) / area.sum()
+    surf = np.minimum(np.searchsorted(cum, s.uniform(n_fg)), n_surf - 1)
+    # a frame (t1, t2, nrm) per splat: the surface's for planes, the radial one for shells
+    nrm = normal[surf]
+    uv = s.uniform(n_fg, 2) * 2.0 - 1.0
+    d = s.normal(n_fg, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    shell = ~is_plane[surf]
+    nrm = np.where(shell[:, None], d, nrm)
+    helper = np.where(np.abs(nrm[:, 1:2]) < 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+    t1 = np.cross(helper, nrm)
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(nrm, t1)
+    pos = np.where(shell[:, None], centre[surf] + radius[surf][:, None] * d,
+                   centre[surf] + (uv[:, 0] * ext[surf, 0])[:, None] * t1 + (uv[:, 1] * ext[surf, 1])[:, None] * t2)
+    pos += 0.01 * s.normal(n_fg, 3)                            # (trained surfaces are not perfectly thin)
+    # in-surface rotation, then scales: two log-normal in-surface ones (2 % of them 4.5-20 times larger), a thin one
+    phi = s.uniform(n_fg) * 2.0 * math.pi
+    a1 = np.cos(phi)[:, None] * t1 + np.sin(phi)[:, None] * t2
+    a2 = np.cross(nrm, a1)
+    quat = _quat_from_columns(a1, a2, nrm)
+    st = np.exp(-4.6 + 0.9 * s.normal(n_fg, 2))
+    st *= np.where(s.uniform(n_fg) < 0.02, np.exp(1.5 + 1.5 * s.uniform(n_fg)), 1.0)[:, None]
+    sn = st.min(axis=1) * np.exp(-(math.log(10.0) + s.uniform(n_fg) * math.log(10.0)))
+    scale = np.concatenate([st, sn[:, None]], axis=1)
+    opacity = np.where(s.uniform(n_fg) < 0.65, _sigmoid(4.0 + s.normal(n_fg)), _sigmoid(-2.5 + s.normal(n_fg)))
+    dc = base_dc[surf] + 0.25 * s.normal(n_fg, 3)
+    # the background: huge flat splats on a far shell, facing the origin
+    bd = s.normal(n_bg, 3)
+    bd /= np.linalg.norm(bd, axis=1, keepdims=True)
+    bpos = bd * (25.0 + 15.0 * s.uniform(n_bg))[:, None]
+    bh = np.where(np.abs(bd[:, 1:2]) < 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+    b1 = np.cross(bh, bd)
+    b1 /= np.linalg.norm(b1, axis=1, keepdims=True)
+    bquat = _quat_from_columns(b1, np.cross(bd, b1), bd)
+    bst = np.exp(math.log(2.0) + s.uniform(n_bg, 2) * (math.log(8.0) - math.log(2.0)))
+    bscale = np.concatenate([bst, 0.05 * bst.min(axis=1, keepdims=True)], axis=1)
+    bop = _sigmoid(3.0 + s.normal(n_bg))
+    bdc = 0.5 * s.normal(n_bg, 3)
+    # the background splats are dealt through the file as a trainer's densification leaves them: anywhere
+    order = np.argsort(splitmix64(seed ^ 0x5bd1e995, 0, n), kind="stable")
+    cat = lambda a, b: np.concatenate([a, b], axis=0)[order]
+    return _pack(cat(pos, bpos), cat(scale, bscale), cat(quat, bquat), cat(opacity, bop), cat(dc, bdc))
+
+
 # ---- the same scenes generated on a torch device -----------------------------------------------------
 # 50 M splats x 48 SH floats are 9.6 GB: building them with numpy on the host and uploading takes minutes.
 # The arithmetic definition is the same (splitmix64 -> 24-bit uniforms -> float64 transforms -> float32);

@@ -10,7 +10,11 @@
  * The reference interface is a C++ ABI (by-value std::function, namespaces); this header is
  * the plain-C core a binding targets. include/gscuda_shim.hpp re-creates the exact C++
  * signature on top of it. All pointers named "device" are HIP device pointers owned by
- * the caller; the library allocates no device memory of its own.
+ * the caller. Everything a frame needs lives in the caller's chunks; what the library itself allocates, once per host
+ * thread and device, is listed here in full: 1 KB of pinned host memory (the numRendered read-back and the calls' error
+ * words), a second stream of the lowest priority and a handful of events, an 8-byte device counter (GSR_FLAG_COUNT_STAGED
+ * only), and per tile history (below: one per stream the thread calls on, at most eight, or the caller's own
+ * gsr_tile_history) 384 KB of device memory and 64 bytes of pinned host memory. None of it influences any output.
  */
 #ifndef GSRAST_AMD_H
 #define GSRAST_AMD_H
@@ -140,16 +144,26 @@ enum {
  * Pixels, ranges, finalT, nContrib and numRendered are unchanged. Ignored under the other plans, whose blend
  * reads the sorted list. Default off: the reference's contract (sorted lists in the binning chunk) holds. */
 #define GSR_FLAG_NO_SORTED_LISTS 0x40u
-/* The blend starts the tiles that took longest in the calling thread's PREVIOUS call of the same size on this device first
- * (a frame lasts as long as its slowest tiles, and a camera moves little between two frames): every tile's wave leaves how
- * long it ran in a small buffer the library owns, and the next call sorts its workgroups by it beside the preprocess, on a
- * stream of the library's. Outputs do not depend on it — the same tiles are composited the same way, sooner or later —
- * and a first call, a new size or another scene simply find an order that helps less. The order is only made when the
- * statistics of the calls before say the frame ends on a few slow tiles (the camera outside the cloud: blend 0.61 -> 0.53
- * ms from (0,0,-30) on the bench scene), and every fourth call to keep them fresh. This flag switches all of it off: the
- * call then neither reads nor writes that buffer and uses no second stream for it (the environment variable
- * GSR_TILE_HISTORY=0 does the same for every call of the process). Frames of more than 32 768 tiles (beyond 3840 x 2160)
- * keep no tile times either: the order is sorted by one workgroup in LDS. */
+/* Slow tiles first. A frame's blend lasts as long as its slowest tiles, and a camera moves little between two frames:
+ * every tile's wave leaves how long it ran in a TILE HISTORY, and the next call that is given the same history sorts its
+ * blend workgroups by it beside the depth sort, on a stream of the library's (blend 0.61 -> 0.53 ms from (0,0,-30) on the
+ * bench scene). Outputs do not depend on it — the same tiles are composited the same way, sooner or later.
+ * Which history a call takes: gsr_forward_args.tile_history, a gsr_tile_history the caller created (one per VIEW: a
+ * rasterizer object, an eye of a stereo pair) — or, when that is NULL, one the library keeps per host thread, device and
+ * STREAM of the call (at most eight streams per thread and device; calls on further streams run without). A history
+ * belongs to the stream of the call that used it last: kernels of two calls that share a history are ordered by that
+ * stream alone, so calls on different streams never share a default history, and a caller who moves its own history to
+ * another stream must have ordered that stream behind the last call's (the library adds an event wait when it sees the
+ * switch, if the old stream still exists). A history whose frames stop resembling each other — a trainer that draws an
+ * unrelated camera every call, two views alternating on one history — is noticed (the two last frames' tile times are
+ * compared when the order is sorted: sum of minima over sum of maxima below 0.6) and the order is dropped, patch order
+ * as without a history, until they do again: plan_used then carries GSR_PLAN_TILE_ORDER_DROPPED. The order is only sorted
+ * when the statistics of the calls before say the frame ends on a few slow tiles or is a light one, and every fourth
+ * call to keep them fresh. A history also carries the statistics by which the library decides, per call, whether the
+ * blend runs beside the emission (GSR_FLAG_OVERLAP_EMIT). This flag switches all of it off for the call: it neither reads
+ * nor writes a history and uses no second stream for it (GSR_TILE_HISTORY=0 in the environment does the same for every
+ * call of the process). Frames of more than 32 768 tiles (beyond 3840 x 2160) keep no tile times either: the order is
+ * sorted by one workgroup in LDS. */
 #define GSR_FLAG_NO_TILE_HISTORY 0x80u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
@@ -158,7 +172,21 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
        GSR_PLAN_TILES_REORDERED = 0x400 /* or-ed in: the blend started the slow tiles of the call before first
                                            (see GSR_FLAG_NO_TILE_HISTORY; informational) */,
        GSR_PLAN_EMIT_OVERLAPPED = 0x800 /* or-ed in: the blend ran beside the emission (see GSR_FLAG_OVERLAP_EMIT) */,
-       GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the depth sort, not by the preprocess */ };
+       GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the depth sort, not by the preprocess */,
+       GSR_PLAN_TILE_ORDER_DROPPED = 0x2000 /* or-ed in: the history's last frames did not resemble each other (another view
+                                               every call): the blend took the patch order (informational) */ };
+
+/* A tile history (see GSR_FLAG_NO_TILE_HISTORY): opaque, created for the CURRENT device, owned by the caller, one per view.
+ * gsr_tile_history_destroy: the streams it was used on must be idle. */
+typedef struct gsr_tile_history gsr_tile_history;
+int gsr_tile_history_create(gsr_tile_history** out);
+int gsr_tile_history_destroy(gsr_tile_history* history);
+/* What the library last learnt about the history (host side, no device access; for tools and tests): out[0] = mean tile
+ * time of its last sorted frame in units of 10 ns (0: none yet), [1] = that frame's longest tile, [2] = similarity of its two
+ * last frames x 1000 (sum of minima over sum of maxima of the tiles' times), [3] = 1 if the order is dropped at present,
+ * [4] = calls since the history was last cleared (a new size), [5] = 1 if the last block-plan call ran its blend beside the
+ * emission. */
+int gsr_tile_history_stats(const gsr_tile_history* history, uint32_t out[6]);
 
 /* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
  * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this
@@ -184,6 +212,7 @@ typedef struct gsr_forward_receipt {
     const volatile uint32_t* async_words;   /* host memory (pinned, never freed): {N-sized sort gave up, R-sized sort gave up
                                                (each: 0, or the serial of the call whose kernel gave up), serial of the call
                                                that owns the words, 0} — see gsr_poll_async_error */
+    gsr_tile_history* tile_history;         /* gsr_forward_args.tile_history of the call (NULL: one of the library's own) */
 } gsr_forward_receipt;
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
@@ -223,6 +252,8 @@ typedef struct gsr_forward_args {
     int32_t tile_row_end;          /*   sorted and blended; 0,0 = all rows. In such a call  */
                                    /*   a Gaussian without a tile in the band counts as     */
                                    /*   invisible (radius 0, its geometry fields unwritten) */
+    gsr_tile_history* tile_history;/* the view's tile history, or NULL: the library's own for this thread, device and
+                                      stream (see GSR_FLAG_NO_TILE_HISTORY) */
     /* ---- outputs ---- */
     uint32_t num_rendered;         /* R = sum of tiles touched (for the rows processed)    */
     uint64_t records_staged;       /* R_f, only with GSR_FLAG_COUNT_STAGED                 */

@@ -1,6 +1,7 @@
 """Parity soak: random first-person poses of a mid-size scene, every frame against the CPU oracle (oracle/gsr_oracle.cpp):
 sorted lists, ranges, transmittance and nContrib bit for bit, pixels within 2e-6 — the claim of DESIGN.md §5 outside the
-BASELINE poses. Test infrastructure (imports oracle/).  python scripts/soak_parity.py [poses] [splats] [width height]"""
+BASELINE poses. Test infrastructure (imports oracle/).  python scripts/soak_parity.py [poses] [splats] [width height] [scene]
+scene: garden_like (default) | trained_like (scenes.trained_like: flat splats on surfaces, heavy-tailed scales, huge background splats)"""
 import os
 import sys
 
@@ -13,7 +14,8 @@ from oracle import cpu_oracle
 poses = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 400_000
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (960, 540)
-scene = scenes.garden_like_scene(n, seed=77)
+which = sys.argv[5] if len(sys.argv) > 5 else "garden_like"
+scene = scenes.trained_like(n, seed=77) if which == "trained_like" else scenes.garden_like_scene(n, seed=77)
 span = float(np.max(scene["means3D"][:, :3].max(0) - scene["means3D"][:, :3].min(0)))
 r = SplatRasterizer(W, H, background=(0.2, 0.1, 0.3))
 r.configure_from_scene(scene)
@@ -45,6 +47,6 @@ for i in range(poses):
     worst_px = max(worst_px, float(np.abs(img - exp["out_color"]).max()))
     if i % 10 == 0:
         print(f"pose {i}: R={exp['num_rendered']} R_f={exp['records_staged']} plan={r.last_plan} opacity x {scale} lists_ok={ok_lists} worst pixel so far {worst_px:.2e}", flush=True)
-print(f"{frames} frames with R > 0 ({n} splats, {W}x{H}): frames whose lists / ranges / R / R_f differ: {list_bad}; finalT words differing: {t_words}; "
+print(f"{frames} frames with R > 0 ({which}, {n} splats, {W}x{H}): frames whose lists / ranges / R / R_f differ: {list_bad}; finalT words differing: {t_words}; "
       f"nContrib flips: {flips}; largest pixel difference: {worst_px:.3e}")
 sys.exit(0 if (list_bad == 0 and t_words == 0 and flips == 0 and worst_px <= 2e-6) else 1)

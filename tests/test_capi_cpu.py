@@ -115,12 +115,12 @@ def _compile_and_run(tmp_path, source: str, flags=(), cxx=False):
 def test_ctypes_structs_have_the_headers_layout(tmp_path):
     """The header is compiled as C and asked for sizes / offsets; the ctypes mirrors must agree field for field (a
     silent mismatch would shift every pointer behind it)."""
-    probes = {"gsr_forward_args": (_capi.ForwardArgs, ["flags", "num_gaussians", "out_color", "stream", "num_rendered",
+    probes = {"gsr_forward_args": (_capi.ForwardArgs, ["flags", "num_gaussians", "out_color", "stream", "tile_history", "num_rendered",
                                                         "records_staged", "stage_ms", "plan_used", "receipt"]),
               "gsr_backward_args": (_capi.BackwardArgs, ["point_list", "dL_dout_color", "dL_drotations", "stage_ms", "sh_dims",
                                                           "receipt"]),
               "gsr_forward_receipt": (_capi.ForwardReceipt, ["plan_used", "tile_row_end", "num_visible", "serial",
-                                                             "geometry_chunk", "binning_chunk", "async_words"])}
+                                                             "geometry_chunk", "binning_chunk", "async_words", "tile_history"])}
     lines = []
     for cname, (_, fields) in probes.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -138,7 +138,8 @@ def test_python_constants_are_the_headers(tmp_path):
     """Every GSR_FLAG_* / GSR_PLAN_* / GSR_ERR_* the Python mirror names has the header's value (the header compiled as C prints
     them): a flag added on one side only would silently select something else."""
     names = sorted(k for k in vars(_capi) if k.startswith(("GSR_FLAG_", "GSR_PLAN_", "GSR_ERR_")) or k == "GSR_OK")
-    assert {"GSR_FLAG_NO_TILE_HISTORY", "GSR_FLAG_SERIAL_EMIT", "GSR_PLAN_EMIT_OVERLAPPED", "GSR_PLAN_COLORS_BESIDE"} <= set(names)
+    assert {"GSR_FLAG_NO_TILE_HISTORY", "GSR_FLAG_SERIAL_EMIT", "GSR_PLAN_EMIT_OVERLAPPED", "GSR_PLAN_COLORS_BESIDE",
+            "GSR_PLAN_TILE_ORDER_DROPPED"} <= set(names)
     body = "".join(f'printf("{k} %lld\\n", (long long)({k}));' for k in names)
     out = _compile_and_run(tmp_path, '#include <stdio.h>\n#include "gsrast_amd.h"\nint main(void){' + body + "return 0;}")
     got = dict(line.split() for line in out.strip().splitlines())

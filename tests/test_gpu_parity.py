@@ -123,6 +123,48 @@ def test_anisotropic_scenes_against_oracle(w, h, n, seed):
     _compare_all(r, img, exp, n)
 
 
+@pytest.mark.parametrize("eye", [(0.5, -0.2, -4.0), (0.0, 0.0, -48.0)])
+def test_trained_like_scene_against_oracle(eye):
+    """Flat splats on surfaces, a heavy-tailed scale distribution, bimodal opacity and 500 huge background splats
+    (scenes.trained_like): from inside, and from 48 units away, where a Gaussian touches three tiles on average and the
+    background splats a thousand each."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    scene = scenes.trained_like(60_000, seed=46)
+    cam = camera.default_camera(640, 368, near=0.02, far=120.0, position=eye)
+    bg = (0.1, 0.2, 0.3)
+    exp = cpu_oracle.forward(scene, cam, bg, threads=8)
+    assert exp["num_rendered"] > 50_000
+    r, img = _run(scene, cam, bg)
+    _compare_all(r, img, exp, 60_000)
+
+
+def test_a_few_huge_splats_send_a_frame_of_small_ones_to_the_block_plan():
+    """The plan follows the instances per visible Gaussian — of the splats that are small: with an eighth of the frame's
+    instances in splats of 256 tiles and more (the scan counts them) the block plan is taken whatever the average
+    (the sort plan's emission walks a Gaussian's keys chunk by chunk: 1.53 against 1.08 ms on 1 M flat splats + 500 huge ones)."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    scene = scenes.trained_like(200_000, seed=47)
+    w, h = 1920, 1080
+    r = SplatRasterizer(w, h)
+    r.configure_from_scene(scene)
+    cam = camera.default_camera(w, h, near=0.02, far=200.0, position=(0.0, 0.0, -48.0))
+    img = r.draw(cam).clone()
+    tt = r.map_geometry_state()["tilesTouched"].to(torch.int64)
+    R, V, big = int(tt.sum()), int((tt != 0).sum()), int(tt[tt >= 256].sum())
+    assert R == r.last_num_rendered and R < 6 * V and 8 * big >= R          # (small on average, an eighth and more in big splats)
+    assert r.last_plan == "blocks"
+    # forced, both plans give the same picture; without its big splats the same frame takes the sort plan
+    assert torch.equal(r.draw(cam, plan="sort").view(torch.int32), img.view(torch.int32)) and r.last_plan == "sort"
+    small_ones = (tt < 256).cpu().numpy()
+    r2 = SplatRasterizer(w, h)
+    r2.configure_from_scene({k: np.ascontiguousarray(v[small_ones]) for k, v in scene.items()})
+    r2.draw(cam)
+    assert r2.last_num_rendered == R - big and r2.last_plan == "sort"
+
+
 def test_grid_wider_than_255_tiles_uses_generic_digit_passes():
     """4112 x 40 -> 257 x 3 tiles: depth-ordered emission + 8-bit digit passes over the tile bits."""
     from gsrast_amd import camera, scenes

@@ -281,22 +281,24 @@ def test_forward_only_calls_may_skip_the_sorted_lists():
 
 
 def test_plan_and_blend_feed_follow_the_instances_per_visible_gaussian():
-    """The default choices (csrc/api.hip): the block plan from 6 instances per VISIBLE Gaussian up; under it the blend
-    reads the sorted lists on sparse frames (fewer than 48 per visible Gaussian) and the block lists on dense ones.
-    Whatever is chosen, pixels, finalT, nContrib, ranges, R and R_f are those of every other choice."""
+    """The default choices (csrc/api.hip): the block plan from 6 instances per VISIBLE Gaussian up, or with an eighth of the
+    instances in splats of 256 tiles and more; under it a blend that does not run beside the emission reads the sorted lists
+    on sparse frames (fewer than 48 per visible Gaussian) and the block lists on dense ones. Whatever is chosen, pixels,
+    finalT, nContrib, ranges, R and R_f are those of every other choice."""
     import torch
     from gsrast_amd import camera, scenes
     scene = scenes.garden_like_scene(400_000, seed=47)
     r = _rast(1920, 1080, background=(0.1, 0.0, 0.2))
     r.configure_from_scene(scene)
     seen = set()
-    for z in (-5.0, -14.0, -30.0, -50.0):
+    for z in (-5.0, -14.0, -30.0, -50.0, -90.0):
         cam = camera.default_camera(1920, 1080, near=0.05, far=120.0, position=(0.0, 0.0, z))
         img = r.draw(cam, count_staged=True).clone()
         R, staged, plan, from_lists = r.last_num_rendered, r.last_records_staged, r.last_plan, r.last_blend_from_lists
-        V = int((r.map_geometry_state()["tilesTouched"] != 0).sum().item())
-        assert plan == ("blocks" if R >= 6 * V else "sort"), (z, R, V, plan)
-        assert from_lists == (plan == "blocks" and R < 48 * V), (z, R, V, from_lists)
+        tt = r.map_geometry_state()["tilesTouched"].to(torch.int64)
+        V, big = int((tt != 0).sum().item()), int(tt[tt >= 256].sum().item())
+        assert plan == ("blocks" if (R >= 6 * V or 8 * big >= R) else "sort"), (z, R, V, big, plan)
+        assert from_lists == (plan == "blocks" and R < 48 * V and not r.last_emit_overlapped), (z, R, V, from_lists)
         seen.add((plan, from_lists))
         st = {k: v.clone() for k, v in r.map_image_state().items()}
         for kw in (dict(plan="sort"), dict(plan="blocks"), dict(plan="blocks", sorted_lists=False)):
