@@ -701,7 +701,7 @@ def main() -> int:
         # same command (profiles/): valid only for the default single-GPU workload they were taken on.
         traffic, traffic_src, blend_pmc = {}, None, {}
         if default_frame and not distributed:
-            tj, traffic_src = load_profile_json("pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json")
+            tj, traffic_src = load_profile_json("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json")
             traffic = tj.get("blocks" if blocks else "sort", {})
             blend_pmc = tj.get("blend_insts", {})
 

@@ -826,17 +826,28 @@ int gsr_forward(gsr_forward_args* a) {
             // entries — measured on the stand-in, block feed over sorted-list feed: 1.1 at 88 instances per visible Gaussian,
             // 1.44 at 23, 3 at 5 = 1 + 10 V / R)
             if (!hist->block_fed) blend_ticks = blend_ticks * ((unsigned long long)R + 10ull * (unsigned long long)nv) / (unsigned long long)R;
-            // The emission: 12 R bytes at 5 TB/s — then the blend must be the shorter of the two, beside a kernel that fills
+            // The emission: 12 R bytes at 4 TB/s (measured 4.9 on the bench frame's 3.2 GB, 3.8 on 1 GB, 3.3-4.6 on 0.46 GB) — then the blend must be the shorter of the two, beside a kernel that fills
             // the memory pipes it is throttled (the stand-in from outside the cloud, R/V = 22: 1.66 -> 1.99 ms) —, but never
-            // under the 0.11 ms a wave takes for its one unit: a light frame's emission leaves the chip idle, and a blend of
-            // up to twice that still gains beside it (1 M flat splats, frames of 0.45 ms: 8-17 %; `profiles/r05_trained_like.txt`).
-            // Once overlapped, the times are those of a blend that shares the chip (up to twice as long): it stays beside the
-            // emission while it ends within 1.5 times the limit (break-even is 2: max(e, b') against e + b' / 2) — a looser
-            // bound keeps a frame overlapped whose blend has become the longer of the two (the stand-in from outside the cloud
-            // entered from an overlapped pose: 1.48 -> 1.70 ms, for good).
-            const unsigned long long emit_bw = 12ull * (unsigned long long)R / 50000ull, emit_floor = 11000ull;
-            const unsigned long long limit = emit_bw >= emit_floor ? emit_bw : 2ull * emit_floor;
-            overlap = hist->overlapped ? 2ull * blend_ticks < 3ull * limit : blend_ticks < limit;
+            // under the 0.07 ms a wave takes for its share of one unit: a light frame's emission leaves the chip idle, and a
+            // blend of up to twice that still gains beside it (1 M flat splats, frames of 0.4 ms; `profiles/r05_trained_like.txt`).
+            // Once overlapped, the times are those of a blend that shares the chip: while the emission runs it advances at 0.46
+            // of its pace (bench frame: 0.11 ms alone, 0.24 beside an emission that outlasts it), so b' = b / 0.46 if that ends
+            // inside the emission e, else e + (b - 0.46 e). The time it would take alone is taken back out of b' and held to
+            // the same limit, a tenth more (the stand-in from outside the cloud, entered from an overlapped pose, stayed
+            // overlapped under a looser bound: 1.48 -> 1.70 ms, for good).
+            const unsigned long long emit_bw = 12ull * (unsigned long long)R / 40000ull, emit_floor = 7000ull;
+            unsigned long long limit = emit_bw >= emit_floor ? emit_bw : 2ull * emit_floor;
+            // (a frame that is block-fed either way — 48 instances per visible Gaussian and more — changes nothing but the
+            // company its blend keeps: there a blend of up to twice the emission still gains, 1 M-splat stand-in, emission
+            // 0.10 ms, blend 0.13-0.24: 6-10 %; three times loses: the bench frame with faint splats)
+            if (hist->block_fed && (uint64_t)R >= kBlockFeedMinInstances * (uint64_t)nv) limit *= 2ull;
+            if (hist->overlapped) {
+                const unsigned long long e = std::max(emit_bw, emit_floor);
+                const unsigned long long alone = blend_ticks <= e ? blend_ticks * 46ull / 100ull : blend_ticks - e * 54ull / 100ull;
+                overlap = 10ull * alone < 11ull * limit;
+            } else {
+                overlap = blend_ticks < limit;
+            }
         }
         const bool serial = !overlap || (a->flags & GSR_FLAG_NO_SORTED_LISTS);
         if (history) hist->overlapped = !serial;
@@ -870,7 +881,7 @@ int gsr_forward(gsr_forward_args* a) {
         } else {
             if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
             GSR_STEP(launch_block_emit(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
-                                       bin.sorting_space, bin.keys, bin.values, emit_stream));
+                                       bin.sorting_space, bin.keys, bin.values, emit_stream, forked));
             if (profile) {
                 GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], emit_stream));
                 g_rb.recorded[GSR_STAGE_DUPLICATE] = true;

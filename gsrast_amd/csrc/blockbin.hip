@@ -532,7 +532,17 @@ __global__ __launch_bounds__(kEmitWaves* kWave) void block_emit_kernel(BlockMeta
     // 0.654 / 0.704 ms. What pays is the fine-grained dynamic dealing itself. (`gpurun_out/r3b` - `r3d`.)
     const uint32_t nwaves = gridDim.x * kEmitWaves;
     const uint32_t keys_per_unit = r_total / max(total_units, 1u);
-    const uint32_t parts = (total_units >= 32u * nwaves || keys_per_unit < kDenseUnitKeys) ? 1u : 4u;
+    uint32_t parts = (total_units >= 32u * nwaves || keys_per_unit < kDenseUnitKeys) ? 1u : 4u;
+    // A LIGHT frame has fewer units than the launch has waves (1 M splats: 800 units for 4 096 waves): a wave alone on its
+    // SIMD takes 0.11 ms for the 64 tiles x 32 batches of its one unit, whatever the keys — the frame's emission lasted
+    // 0.13 ms for 0.17 GB. With room for them the items are made smaller, down to one tile row of the block each, as long as
+    // every wave still gets at most one.
+#ifndef GSR_LIGHT_PARTS
+#define GSR_LIGHT_PARTS 8
+#endif
+    if (parts == 1u) {
+        while (parts < (uint32_t)GSR_LIGHT_PARTS && total_units * parts * 2u <= nwaves) parts *= 2u;
+    }
     const uint32_t total_items = total_units * parts, tiles_per_item = 64u / parts;
     bool first = true;
     for (;;) {
@@ -895,12 +905,15 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
 
 // The emission: the sorted keys / values written from the tables launch_block_binning left.
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
-                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream) {
+                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream, bool beside_blend) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
     // Workgroups (of four waves) per CU: two where the Gaussians cover many tiles each (long, dense runs: three or four
     // measured 1.5 % slower on the bench frame and at 4K), four where they cover few (short runs, the waves wait more than
     // they store: 0.416 -> 0.366 ms from outside the cloud, R / V = 23 against 88 on the bench frame).
-    const uint32_t per_cu = (uint64_t)r_total >= 48ull * (uint64_t)n ? 2u : 4u;
+    // With the blend beside it (second stream) always two: four of these workgroups hold 448 of a SIMD's 512 vector registers
+    // and no wave of the blend fits until they retire — the stand-in from outside the cloud, overlapped: blend 0.96 ms for
+    // 0.45 alone, the frame 1.70 for 1.50.
+    const uint32_t per_cu = ((uint64_t)r_total >= 48ull * (uint64_t)n || beside_blend) ? 2u : 4u;
     // (a unit may be dealt as four items, see the kernel: a wave per item on small frames)
     const uint32_t emit_wgs = std::min<uint32_t>(t.max_units, 256u * per_cu);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, t.meta, t.nb, t.nbx, grid_x, grid_y,

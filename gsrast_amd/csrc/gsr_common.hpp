@@ -123,7 +123,8 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
                          hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles = nullptr, uint32_t* skipped_stamp = nullptr);
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
-                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream);
+                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream,
+                      bool beside_blend = false);          // (the blend runs on another stream meanwhile: leave it room)
 int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
                         const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,

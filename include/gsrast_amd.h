@@ -111,23 +111,28 @@ enum {
  * cut-off 1e-4, R == 1 renders, R == 0 still writes the background. cam_pos is read. Parity of this
  * profile is unpinned (no upstream source in the reference tree). */
 #define GSR_FLAG_SEMANTICS_INRIA 0x4u
-/* Binning plan (both produce bit-identical sorted keys / values / ranges; default: chosen per frame
- * from numRendered per visible Gaussian: the block plan from 6 up). PLAN_SORT: column-major key emission + one onesweep radix pass;
+/* Binning plan (both produce bit-identical sorted keys / values / ranges; default: chosen per frame: the block plan from 6
+ * instances (numRendered) per visible Gaussian up, or when an eighth of the instances belongs to splats of 256 tiles and more —
+ * the few hundred background splats of a trained scene seen from outside — whatever the average). PLAN_SORT: column-major key
+ * emission + one onesweep radix pass;
  * keysUnsorted / valuesUnsorted then hold the reference's pairs in (tile column, depth) order.
  * PLAN_BLOCKS: the sorted lists are written directly by tile-block owners, no R-sized sort;
  * keysUnsorted / valuesUnsorted then hold that plan's block lists (scratch, as sortingSpace is). */
 #define GSR_FLAG_PLAN_SORT 0x8u
 #define GSR_FLAG_PLAN_BLOCKS 0x10u
-/* Block plan, frames whose blend reads the block lists (48 or more instances per visible Gaussian): the blend can run on a
- * second stream beside the emission of the sorted lists — one is bound by vector issue, the other by the HBM write path.
- * Same results; the call's work is complete, as always, when `stream` is. It pays where the blend is not much longer than
- * the emission (bench frame 1.38 -> 1.31 ms, 4K 4.21 -> 3.85 ms; faint splats, blend three times the emission: 3.13 -> 3.17),
- * and each kernel runs longer while they share the chip. By DEFAULT the library decides per call, from the tile times of
- * the calling thread's previous calls of the same size (see GSR_FLAG_NO_TILE_HISTORY; without that history: serial) and
- * this call's R: overlapped when the blend is expected to be the shorter of the two; plan_used then carries
- * GSR_PLAN_EMIT_OVERLAPPED. GSR_FLAG_OVERLAP_EMIT forces it on (block plan; the blend then reads the block lists whatever
- * the frame), GSR_FLAG_SERIAL_EMIT off: one kernel after the other on the caller's stream, per-kernel times those of the
- * kernels alone. */
+/* Block plan: the blend can run on a second stream beside the emission of the sorted lists — one is bound by vector issue, the
+ * other by the HBM write path (or, on light frames, by nothing: a wave per unit) — reading the block lists instead of the sorted
+ * ones. Same results; the call's work is complete, as always, when `stream` is. It pays where the blend is the shorter of the
+ * two (bench frame 1.34 -> 1.22 ms, 4K 4.21 -> 3.85 ms; faint splats, blend three times the emission: 3.10 -> 3.16), and each
+ * kernel runs longer while they share the chip. By DEFAULT the library decides per call, from 16 instances per visible Gaussian
+ * up, from the call's tile history (see GSR_FLAG_NO_TILE_HISTORY; without one, or while its frames do not resemble each other:
+ * serial) and this call's R: overlapped when the blend — the tiles' times spread over the chip, never less than the longest
+ * tile, and 1 + 10 V / R times that if they were measured on a blend fed from the sorted lists — is expected to end before an
+ * emission of 12 R bytes at 4 TB/s does (twice that on frames that are block-fed either way; on light frames: before 0.14 ms);
+ * plan_used then carries GSR_PLAN_EMIT_OVERLAPPED. GSR_FLAG_OVERLAP_EMIT forces it on (block plan), GSR_FLAG_SERIAL_EMIT off: one
+ * kernel after the other on the caller's stream, per-kernel times those of the kernels alone; a serial blend reads the sorted
+ * lists below 48 instances per visible Gaussian and the block lists from there on. (`profiles/r05_trained_like.txt`: the
+ * library's choice against every forced one on 240 poses of two scene families.) */
 #define GSR_FLAG_OVERLAP_EMIT 0x20u
 #define GSR_FLAG_SERIAL_EMIT 0x100u
 /* (Also by default, gscuda semantics without colors_precomp: geomState.rgb is written by a kernel of its own on the

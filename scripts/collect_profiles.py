@@ -1,34 +1,158 @@
-"""Turns the raw rocprofv3 / bench outputs of one GPU run (gpurun_out/) into the summaries kept under profiles/.
-Usage: python scripts/collect_profiles.py <tag of the run, e.g. r01e>"""
-import csv, json, re, sys
-tag = sys.argv[1]
-rows = list(csv.DictReader(open(f"gpurun_out/prof_{tag}/run_kernel_stats.csv")))
-line = [l for l in open("gpurun_out/bench_prof.log") if l.startswith('{"metric')][-1].strip()
-with open("profiles/r01_blocks_kernel_stats.txt", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline   (block binning plan, the default for this frame)\n# bench line of the same run:\n" + line + "\n")
-    f.write("# kernel stats (Name, Calls, TotalDurationNs, AverageNs, Percentage, MinNs, MaxNs, StdDev):\n")
-    f.write(",".join('"%s"' % k for k in rows[0].keys()) + "\n")
-    for r in rows[:26]:
-        f.write(",".join('"%s"' % r[k] if k == "Name" else r[k] for k in r.keys()) + "\n")
-with open("profiles/r01_blocks_pmc.txt", "w") as f:
-    f.write("# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   (one run per counter set; per-kernel averages over dispatches; block binning plan)\n")
-    f.write("# FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (MI355X_MICROARCH.md, HBM): double it before comparing with bytes.\n")
-    for i in range(3):
-        f.write(open(f"gpurun_out/pmc_{tag}_sum_{i}.txt").read())
-vals = {}
-for i in range(2):
-    for l in open(f"gpurun_out/pmc_{tag}_sum_{i}.txt"):
-        k = l.split()[0]
-        for n, v in re.findall(r"(\w+)=([0-9.e+]+)", l):
-            vals.setdefault(k, {})[n] = float(v)
-traffic = lambda k: int((2 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]) * 1024)
-j = json.load(open("profiles/pmc_traffic_r01.json"))
-j["blocks"] = {"duplicate": traffic("block_emit_kernel"), "preprocess": traffic("preprocess_kernel"), "blend": traffic("blend_blocks_kernel")}
-json.dump(j, open("profiles/pmc_traffic_r01.json", "w"), indent=1)
-for name, out in (("bench_default", "r01_bench_default.json"), ("bench_backward", "r01_bench_backward.json"), ("bench_4k", "r01_bench_4k.json"), ("bench_overlap", "r01_bench_overlap.json")):
+"""Turns gpurun_out/<round>/ (scripts/profile.sh, run on the GPU box) into the summaries committed under profiles/.
+Usage: python scripts/collect_profiles.py [round, default r05]"""
+import glob
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_stats_table as kst
+
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+SRC, DST = f"gpurun_out/{ROUND}", "profiles"
+
+
+def bench_line(path):
     try:
-        d = json.loads([l for l in open(f"gpurun_out/{name}.log") if l.startswith('{"metric')][-1])
-        open(f"profiles/{out}", "w").write(json.dumps(d, indent=1))
-        print(name, d["ms_per_step"], d["stage_ms"], d["roofline"]["frac"])
-    except Exception as e:
-        print(name, "missing", e)
+        lines = [ln for ln in open(path) if ln.startswith('{"metric')]
+        return json.loads(lines[-1]) if lines else None
+    except OSError:
+        return None
+
+
+def stats_file(name):
+    f = glob.glob(f"{SRC}/trace_{name}/**/*kernel_stats.csv", recursive=True)
+    return f[0] if f else None
+
+
+def write_trace(name, cmd):
+    import csv
+    f = stats_file(name)
+    if not f:
+        print("missing trace", name)
+        return {}
+    line = bench_line(f"{SRC}/trace_{name}.log")
+    # (the scene generator's torch kernels — 50 M scene built on the device — are not the library's)
+    rows = [r for r in csv.DictReader(open(f)) if "at::native" not in r["Name"] and not r["Name"].startswith("void at::")]
+    with open(f"{DST}/{ROUND}_{name}_kernel_stats.txt", "w") as o:
+        o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {cmd}\n# bench line of the same run:\n{json.dumps(line)}\n")
+        o.write("# kernel  calls  average / min / max microseconds  share of device time\n")
+        for r in rows[:28]:
+            o.write(f"{kst.short(r['Name']):44s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs']) / 1e3:9.1f} "
+                    f"min_us={float(r['MinNs']) / 1e3:9.1f} max_us={float(r['MaxNs']) / 1e3:9.1f}  {float(r['Percentage']):5.1f} %\n")
+    return {kst.short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+
+
+def pmc_values(name):
+    vals = {}
+    try:
+        for ln in open(f"{SRC}/pmc_{name}.txt"):
+            k = ln.split()[0] if ln.split() else ""
+            for n, v in re.findall(r"(\w+)=([0-9.e+-]+)", ln):
+                try:
+                    vals.setdefault(k, {})[n] = float(v)
+                except ValueError:
+                    pass
+    except OSError:
+        print("missing pmc", name)
+    return vals
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    write_trace("head", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras   (the headline frame)")
+    write_trace("head_precomp", "--steps 20 --warmup 5 --no-cpu-baseline --no-extras --colors-precomp   (the headline frame, colours passed as colorsPrecomp)")
+    write_trace("outside", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --pose 0,0,-14")
+    write_trace("far", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --pose 0,0,-30")
+    write_trace("bound", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --opacity-scale 0.1")
+    write_trace("stress50M", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --scene stress --splats 50000000")
+    write_trace("stress50M_precomp", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --colors-precomp")
+    write_trace("4k", "--steps 5 --warmup 2 --no-cpu-baseline --no-extras --width 3840 --height 2160")
+    with open(f"{DST}/{ROUND}_pmc.txt", "w") as o:
+        o.write("# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras [frame]\n"
+                "# one run per counter set; per-kernel averages over dispatches. FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE\n"
+                "# tallies a 128-B request of a wide coalesced read at 64 B (MI355X_MICROARCH.md, HBM): doubled before it is compared with bytes.\n"
+                "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs.\n")
+        for name, what in (("head_sq", "headline frame"), ("head_lds", "headline frame"), ("head_fetch", "headline frame"),
+                           ("head_write", "headline frame"), ("precomp_fetch", "headline frame, --colors-precomp"),
+                           ("precomp_write", "headline frame, --colors-precomp"), ("bound_sq", "opacities x 0.1"),
+                           ("outside_sq", "pose (0,0,-14)"), ("far_sq", "pose (0,0,-30)"),
+                           ("stress_fetch", "50 M stress scene"), ("stress_write", "50 M stress scene"),
+                           ("stress_precomp_fetch", "50 M stress scene, --colors-precomp"),
+                           ("stress_precomp_write", "50 M stress scene, --colors-precomp")):
+            o.write(f"## {name}: {what}\n")
+            try:
+                o.write(open(f"{SRC}/pmc_{name}.txt").read())
+            except OSError:
+                o.write("(missing)\n")
+    fetch, write, sq = pmc_values("head_fetch"), pmc_values("head_write"), pmc_values("head_sq")
+
+    def traffic(k):
+        if k in fetch and k in write and "FETCH_SIZE" in fetch[k] and "WRITE_SIZE" in write[k]:
+            return int((2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024)
+        return None
+
+    def clock(v):       # effective clock from GRBM_GUI_ACTIVE (sum over 8 XCDs) and the dispatch's duration
+        return None
+
+    out = {"_comment": f"HBM bytes per launch from rocprofv3 PMC passes (profiles/{ROUND}_pmc.txt): (2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes, "
+                       "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; blend_insts: SQ_INSTS_VALU / SQ_INSTS_SALU per "
+                       "launch of the blend kernel on the same frame. Workload: the bench.py default frame (N=5834784, 1920x1080).",
+           "blocks": {}, "sort": {}}
+    for stage, kern in (("duplicate", "block_emit_kernel"), ("preprocess", "preprocess_kernel"), ("blend", "blend_blocks_kernel")):
+        t = traffic(kern)
+        if t is not None:
+            out["blocks"][stage] = t
+    # the preprocess kernel's traffic with the colours precomputed, bench frame and 50 M
+    for key, fn, wn in (("preprocess_colors_precomp", "precomp_fetch", "precomp_write"), ("preprocess_50M", "stress_fetch", "stress_write"),
+                        ("preprocess_50M_colors_precomp", "stress_precomp_fetch", "stress_precomp_write")):
+        f2, w2 = pmc_values(fn).get("preprocess_kernel", {}), pmc_values(wn).get("preprocess_kernel", {})
+        if "FETCH_SIZE" in f2 and "WRITE_SIZE" in w2:
+            out["blocks"][key] = int((2 * f2["FETCH_SIZE"] + w2["WRITE_SIZE"]) * 1024)
+    old = json.load(open(f"{DST}/pmc_traffic_r01.json"))
+    out["sort"] = old.get("sort", {})
+    out["sort_note"] = "sort-plan figures are round 1's (profiles/r01_final_pmc.txt): that plan's kernels other than the blend are unchanged"
+    b = sq.get("blend_blocks_kernel", {})
+    if "SQ_INSTS_VALU" in b:
+        out["blend_insts"] = {"SQ_INSTS_VALU": b["SQ_INSTS_VALU"], "SQ_INSTS_SALU": b["SQ_INSTS_SALU"],
+                              "SQ_WAVE_CYCLES": b.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": b.get("SQ_WAIT_ANY"),
+                              "SQ_ACTIVE_INST_ANY": b.get("SQ_ACTIVE_INST_ANY"), "clock_ghz": 2.4,
+                              "source": f"profiles/{ROUND}_pmc.txt, set head_sq"}
+    for name in ("bound_sq", "outside_sq", "far_sq"):
+        pv = pmc_values(name)
+        # (sparse frames blend from the sorted lists: blend_wave_kernel)
+        v = pv.get("blend_blocks_kernel") or pv.get("blend_wave_kernel") or {}
+        if v:
+            v = dict(v, kernel="blend_blocks_kernel" if "blend_blocks_kernel" in pv else "blend_wave_kernel")
+            out[f"blend_insts_{name.split('_')[0]}"] = v
+    json.dump(out, open(f"{DST}/pmc_traffic_{ROUND}.json", "w"), indent=1)
+    import shutil
+    if os.path.exists(f"{SRC}/band_projection.json"):
+        shutil.copy(f"{SRC}/band_projection.json", f"{DST}/band_projection.json")
+    for txt in ("band_timings", "band_timings_4k", "parity", "soak", "history_similarity", "soak_trained_like", "micro_gather_dc",
+                "micro_scatter_records", "micro_xcd_placement"):
+        if os.path.exists(f"{SRC}/{txt}.txt"):
+            shutil.copy(f"{SRC}/{txt}.txt", f"{DST}/{ROUND}_{txt}.txt")
+    thr = sorted(glob.glob(f"{SRC}/thresholds_*.txt"))
+    if thr:
+        with open(f"{DST}/{ROUND}_trained_like.txt", "w") as o:
+            o.write("# scripts/thresholds_check.py on one MI355X: is the library's own choice (binning plan, the blend's feed, blend beside the emission)\n"
+                    "# within 5 % of the best forced one? Scenes: scenes.trained_like (flat splats on surfaces, heavy-tailed scales, bimodal opacity, 500 huge\n"
+                    "# background splats) and the garden-like stand-in, 1 M and 5.83 M splats, 1920 x 1080, a random first-person tour of 60 poses each (every\n"
+                    "# fifth from further out, every seventh from 48 units away). Round 4's switch points (plan at R/V = 6, feed and overlap at 48) on the\n"
+                    "# first version of these tours: trained_like 1 M 48 %, 5.83 M 52 % of the poses within 5 % (gpurun_out/r5c).\n")
+            for f in thr:
+                o.write("\n" + open(f).read())
+    for name in ("bench_default", "bench_backward", "bench_backward_outside", "bench_backward_nolists", "bench_4k", "bench_stress50M",
+                 "bench_stress50M_precomp", "bench_stress50M_inria_sh3", "bench_forced_dist_1rank"):
+        d = bench_line(f"{SRC}/{name}.json")
+        if d is None:
+            print(name, "missing")
+            continue
+        open(f"{DST}/{ROUND}_{name}.json", "w").write(json.dumps(d, indent=1))
+        print(name, d["ms_per_step"], {k: v for k, v in d["stage_ms"].items() if v}, "roofline", d["roofline"]["frac"])
+
+
+if __name__ == "__main__":
+    main()

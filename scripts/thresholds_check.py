@@ -5,7 +5,8 @@ frame time under every forced alternative:
     sort            GSR_FLAG_PLAN_SORT
     blocks          GSR_FLAG_PLAN_BLOCKS | GSR_FLAG_SERIAL_EMIT   (blend fed from the sorted lists below 48 instances per Gaussian, else from the block lists)
     blocks+overlap  GSR_FLAG_PLAN_BLOCKS | GSR_FLAG_OVERLAP_EMIT  (blend fed from the block lists, beside the emission)
-    auto            no flag (with this rasterizer's tile history, warmed up on the pose)
+    auto            no flag
+(every variant with this rasterizer's tile history, warmed up on the pose: slow tiles first under all of them)
 and whether "auto" is within 5 % of the best of them. Host wall time per frame incl. the device synchronise, median of 5 after 4 (a camera cut is over for the tile history after three frames).
 Usage: python scripts/thresholds_check.py [scene] [splats] [poses] [width height]"""
 import os
@@ -30,8 +31,8 @@ near, far = 0.001 * span, 4.0 * span
 r = SplatRasterizer(W, H)
 r.configure_from_scene(scene)
 rng = np.random.default_rng(21)
-variants = {"sort": dict(plan="sort", tile_history=False), "blocks": dict(plan="blocks", overlap_emit=False, tile_history=False),
-            "blocks+overlap": dict(plan="blocks", overlap_emit=True, tile_history=False), "auto": dict()}
+variants = {"sort": dict(plan="sort"), "blocks": dict(plan="blocks", overlap_emit=False),
+            "blocks+overlap": dict(plan="blocks", overlap_emit=True), "auto": dict()}
 
 
 def timed(cam, kw):

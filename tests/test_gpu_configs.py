@@ -48,8 +48,7 @@ def _compare_with_oracle(r, exp, img, what):
     im = r.map_image_state()
     max_err = assert_blend_parity(img, im["finalT"].cpu().numpy(), im["nContrib"].cpu().numpy(), exp,
                                   f"{what}: R={r.last_num_rendered} R_f={r.last_records_staged} plan={r.last_plan}")
-    n_bad = 0
-    return max_err, n_bad
+    return max_err
 
 
 def test_config3_garden_4k_in_eight_bands_and_against_the_oracle():
