@@ -685,8 +685,17 @@ int gsr_forward(gsr_forward_args* a) {
     side.main_partial = gs.main_partial;
     side.keys = gs.side_k; side.vals = gs.side_v; side.rects = xy_plan ? gs.side_r : nullptr;
     side.capacity = kDepthSideMax;
-    GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
-                              xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3, &side));
+    // Scenes beyond 16 M Gaussians (there every one of these kernels is bound by HBM): no compaction — its 20 N bytes buy
+    // nothing where nearly every Gaussian is visible (50 M: 0.20 ms). The digit counts come from a pass over the keys alone
+    // and the first depth pass reads the per-Gaussian arrays itself, leaving out what has no tile (onesweep_kernel, DROP).
+    // (GSR_FUSED_DEPTH = 0 / 1 in the environment, for A/B runs and the tests: never / whatever the size)
+    const char* const fused_env = getenv("GSR_FUSED_DEPTH");
+    const bool fused_depth = xy_plan && (fused_env && (fused_env[0] == '0' || fused_env[0] == '1') ? fused_env[0] == '1' : n > (1 << 24));
+    if (fused_depth)
+        GSR_STEP(sort_u32_prepare_counts(gs.depth_key, (uint32_t)n, four, gs.sort_info, stream, g_rb.host_dev + 3, &side));
+    else
+        GSR_STEP(sort_u32_prepare(gs.depth_key, (uint32_t)n, gs.c_k, gs.c_v, gs.vis_partial, four, gs.sort_info, stream, true,
+                                  xy_plan ? gs.rect_idx : nullptr, xy_plan ? gs.c_r : nullptr, g_rb.host_dev + 3, &side));
     // :772 — the pipeline's one device->host read: the binning chunk is sized by R. The host waits for the
     // copies only (an event). They also bring V and whether the fourth depth pass is needed: depth keys are
     // float bits, and when every visible Gaussian has the same top byte (NDC z in [0.5, 1)) that pass would
@@ -705,8 +714,12 @@ int gsr_forward(gsr_forward_args* a) {
     }
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
-    GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
-                             xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
+    if (fused_depth)
+        GSR_STEP(sort_u32_passes(gs.depth_key, nullptr, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
+                                 gs.rect_idx, gs.a_r, gs.b_r, &side));
+    else
+        GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
+                                 xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
     if (order_now) {
         // (behind the same event — it follows the history's last blend in stream order — and queued while the host would
         // only wait: nothing is added to the caller's stream, and by the time the blend is launched the order is there)
@@ -731,7 +744,8 @@ int gsr_forward(gsr_forward_args* a) {
     const uint32_t side_m = side_way ? g_rb.host[12] : 0u, side_lo = side_way ? g_rb.host[11] : 0u;
     // (host[13]: the keys the compaction actually put on the side list — it must be the count the scan decided on, or
     // depth_side_kernel would rank entries of an earlier frame)
-    if (side_way && (four_passes || side_m > kDepthSideMax || side_lo > side_m || side_m > (uint32_t)nv || g_rb.host[13] != side_m))
+    // (without the compaction the side list is filled by the first depth pass, which may still be running: its count is not known here)
+    if (side_way && (four_passes || side_m > kDepthSideMax || side_lo > side_m || side_m > (uint32_t)nv || (!fused_depth && g_rb.host[13] != side_m)))
         return fail(GSR_ERR_INTERNAL);
     if (four_passes)
         GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)nv, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 3, 4, stream, nullptr,

@@ -27,7 +27,10 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kItems = 16;                              // keys per lane (measured: 8192-key tiles beat 4096 and 2048)
+#ifndef GSR_SORT_ITEMS
+#define GSR_SORT_ITEMS 16
+#endif
+constexpr int kItems = GSR_SORT_ITEMS;                  // keys per lane (measured: 8192-key tiles beat 4096 and 2048)
 constexpr int kSortTile = kThreads * kItems;            // keys per workgroup
 constexpr int kWaveSpan = kWave * kItems;
 // The ranked tile leaves through LDS in kStageRounds slices of kStageSlots slots: a smaller LDS
@@ -184,14 +187,23 @@ __device__ __forceinline__ uint32_t take_tile(uint32_t* ticket, uint32_t tiles) 
 // SECOND: every key carries a second 32-bit value (vals2_in -> vals2_out; the depth order's packed rectangle), staged and
 // written beside the first. It is loaded after the ranking loop: 16 more registers across that loop would leave one
 // workgroup per CU instead of two.
-template <typename KeyT, int BITS, bool SECOND>
+// DROP (the depth order's first pass on scenes beyond 16 M Gaussians, which then needs no compaction in front of it): the
+// input is the preprocess's per-Gaussian array itself — keys of Gaussians without a tile are the 0xFFFFFFFF sentinel and take
+// no part (no rank, no slot: the tile's live keys leave in index order as if the others were not there), a key's value is its
+// position, and the few keys with another top byte than the main one go to the side list (DepthSide) as the compaction
+// would have sent them. drop.n_out: the device word with the number of keys that do take part (bounds the stores).
+struct DropSpec {
+    const uint32_t* n_out = nullptr;
+    DepthSide side;
+};
+template <typename KeyT, int BITS, bool SECOND, bool DROP = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             const uint32_t* __restrict__ vals2_in, uint32_t* __restrict__ vals2_out,
                                                             uint32_t n_host, const uint32_t* __restrict__ n_dev, const DigitSpec spec,
                                                             const uint32_t* __restrict__ digit_hist,
                                                             unsigned long long* status, uint32_t* ticket,
-                                                            uint32_t* error_word, uint32_t error_value) {
+                                                            uint32_t* error_word, uint32_t error_value, const DropSpec drop = DropSpec()) {
     // n_dev (may be null): the key count lives on the device — the pass was queued before the host knew it, with a
     // grid sized for an upper bound; workgroups whose ticket lies beyond the last tile leave at once.
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     __shared__ uint32_t global_start[RADIX];     // output index of this tile's first digit-d key
     __shared__ uint32_t run_delta[RADIX];        // global_start - run_start (u32 wrap-around)
     __shared__ uint32_t scan_ws[kWaves];
-    __shared__ uint32_t s_tile, s_fail;
+    __shared__ uint32_t s_tile, s_fail, s_live;
     __shared__ KeyT stage_keys[kStageSlots];
     __shared__ uint32_t stage_vals[kStageSlots];
     __shared__ uint32_t stage_vals2[SECOND ? kStageSlots : 1];
@@ -239,6 +251,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         val[i] = (local < valid && vals_in) ? vals_in[tile_base + local] : tile_base + local;
     }
     const uint32_t hist_c = (threadIdx.x < spec.nbins) ? digit_hist[threadIdx.x] : 0u;
+    uint32_t live_bits = 0;                      // DROP: bit i = item i of this lane takes part
+    if constexpr (DROP) {
+        const bool side_on = drop.side.words != nullptr && drop.side.words[0] != 0u;
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+            bool live = local < valid && (uint32_t)key[i] != 0xFFFFFFFFu;
+            if (live && side_on && ((uint32_t)key[i] >> 24) != drop.side.main_top) {
+                // (a handful per frame; any order: depth_side_kernel ranks them by key and index)
+                const uint32_t slot = atomicAdd(&drop.side.words[1], 1u);
+                if (slot < drop.side.capacity) {
+                    drop.side.keys[slot] = (uint32_t)key[i];
+                    drop.side.vals[slot] = tile_base + local;
+                    if (drop.side.rects) drop.side.rects[slot] = vals2_in ? vals2_in[tile_base + local] : 0u;
+                }
+                live = false;                    // (how many of them lie below the main top byte: counted by depth_hist_kernel, for the host)
+            }
+            live_bits |= live ? (1u << i) : 0u;
+        }
+    }
 
     // exclusive scan of the global digit histogram -> first output index of every digit
     {
@@ -265,8 +297,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        // padding of the last tile ranks after every real key: top digit, highest indices
-        const uint32_t d = (local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1);
+        const bool live = DROP ? ((live_bits >> i) & 1u) != 0u : true;
+        // padding of the last tile ranks after every real key: top digit, highest indices (DROP: a key that takes no part
+        // has no rank at all — it is taken out of every lane's peers)
+        const uint32_t d = DROP ? (live ? digit_of<KeyT>(key[i], spec) : 0u)
+                                : ((local < valid) ? digit_of<KeyT>(key[i], spec) : (uint32_t)(RADIX - 1));
         uint32_t peers_lo = ~0u, peers_hi = ~0u;
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
@@ -275,10 +310,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
             peers_lo &= ~((uint32_t)bal ^ (uint32_t)m);
             peers_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)m);
         }
+        if constexpr (DROP) {
+            const unsigned long long lm = __ballot(live);
+            peers_lo &= (uint32_t)lm;
+            peers_hi &= (uint32_t)(lm >> 32);
+        }
         const uint32_t below = __builtin_amdgcn_mbcnt_hi(peers_hi, __builtin_amdgcn_mbcnt_lo(peers_lo, 0u));
-        const uint32_t prior = wave_hist[wave][d];
-        if (below == 0) wave_hist[wave][d] = prior + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
-        rd[i] = (d << 16) | (prior + below);
+        if (live) {
+            const uint32_t prior = wave_hist[wave][d];
+            if (below == 0) wave_hist[wave][d] = prior + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
+            rd[i] = (d << 16) | (prior + below);
+        } else {
+            rd[i] = 0xFFFFu;                     // (no slot: never staged)
+        }
     }
     __syncthreads();
     // The second values come in now, with the ranking loop behind (see SECOND above): their round trip is hidden
@@ -312,7 +356,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
                 acc += c;
             }
             // Padding keys were counted in the top digit: they are not published.
-            const uint32_t real = (threadIdx.x == RADIX - 1) ? acc - ((uint32_t)kSortTile - valid) : acc;
+            const uint32_t real = (!DROP && threadIdx.x == RADIX - 1) ? acc - ((uint32_t)kSortTile - valid) : acc;
             tile_hist[threadIdx.x] = real;
             if (threadIdx.x < spec.nbins)
                 __hip_atomic_store(status + (size_t)tile * RADIX + threadIdx.x,
@@ -333,13 +377,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         for (int w = 0; w < kWaves; ++w)
             if (w < wave) wbase += scan_ws[w];
         if (threadIdx.x < RADIX) run_start[threadIdx.x] = wbase + incl - acc;
+        if (DROP && threadIdx.x == RADIX - 1) s_live = wbase + incl;      // (the tile's keys that take part)
     }
     __syncthreads();
+    const uint32_t valid_out = DROP ? s_live : valid;
     // final slot of every key inside the ranked tile (kept in the low half of rd)
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const uint32_t d = rd[i] >> 16;
-        rd[i] = (rd[i] & 0xFFFF0000u) | ((rd[i] & 0xFFFFu) + run_start[d] + wave_hist[wave][d]);
+        if (!DROP || ((live_bits >> i) & 1u))
+            rd[i] = (rd[i] & 0xFFFF0000u) | ((rd[i] & 0xFFFFu) + run_start[d] + wave_hist[wave][d]);
     }
 
     if (lb.active) {
@@ -360,6 +407,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     }
     __syncthreads();
     if (s_fail) return;
+    const uint32_t n_out = DROP ? *drop.n_out : n;
     if (threadIdx.x < RADIX) run_delta[threadIdx.x] = global_start[threadIdx.x] - run_start[threadIdx.x];
     __syncthreads();
 
@@ -382,11 +430,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
         for (int i = 0; i < kItems / kStageRounds; ++i) {
             const uint32_t q = (uint32_t)(i * kThreads) + threadIdx.x;          // slot inside the slice
             const uint32_t p = q + (uint32_t)(r * kStageSlots);                  // slot inside the tile
-            if (p < valid) {
+            if (p < valid_out) {
                 const KeyT k = stage_keys[q];
                 const uint32_t d = digit_of<KeyT>(k, spec);
                 const uint32_t dst = p + run_delta[d];                       // global start - start in tile
-                if (dst < n) {
+                if (dst < n_out) {
                     keys_out[dst] = k;
                     vals_out[dst] = stage_vals[q];
                     if constexpr (SECOND) vals2_out[dst] = stage_vals2[q];
@@ -406,7 +454,7 @@ template <typename KeyT>
 int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
                 const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
                 bool already_cleared, const uint32_t* n_dev = nullptr, const uint32_t* vals2_in = nullptr,
-                uint32_t* vals2_out = nullptr) {
+                uint32_t* vals2_out = nullptr, const DropSpec* drop = nullptr) {
     const int bits = radix_bits_for(spec.nbins);
     if (bits > 8) return GSR_ERR_INVALID_ARG;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
@@ -421,7 +469,14 @@ int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, ui
         // a second value per key: the depth passes only (u32 keys, 256 bins)
         if constexpr (sizeof(KeyT) == 4) {
             if (bits != 8 || !vals2_out) return GSR_ERR_INVALID_ARG;
-            GSR_SWEEP(8, true);
+            if (drop) {
+                if (vals_in || n_dev || !drop->n_out) return GSR_ERR_INVALID_ARG;      // (the value is the key's position; n is the array's length)
+                hipLaunchKernelGGL((onesweep_kernel<KeyT, 8, true, true>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, keys_out,
+                                   vals_out, vals2_in, vals2_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word,
+                                   sc.error_value, *drop);
+            } else {
+                GSR_SWEEP(8, true);
+            }
         } else {
             return GSR_ERR_INVALID_ARG;
         }
@@ -526,8 +581,22 @@ __global__ __launch_bounds__(256) void top_digit_count_kernel(const uint32_t* __
     }
 }
 
+// One LDS atomic per distinct value and wave instead of one per lane: for digits that take FEW values in a wave — the top
+// byte of float bit patterns, and the byte below it (NDC z crowds towards 1: on the 50 M scene 64 lanes hit two or three
+// counters, and LDS atomics on one address are served one lane at a time: 150 M of them took 0.16 ms).
+__device__ __forceinline__ void wave_count_digit(uint32_t* counters, uint32_t d, bool vis) {
+    unsigned long long todo = __ballot(vis);
+    while (todo) {
+        const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)d, __ffsll((long long)todo) - 1);
+        const unsigned long long same = __ballot(vis && d == val) & todo;
+        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&counters[val], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 // ---- visible keys first: stable compaction of the keys that are not the 0xFFFFFFFF sentinel --------
 constexpr int kCompactThreads = 256, kCompactRows = 16, kCompactChunk = kCompactThreads * kCompactRows;
+constexpr int kByte2Copies = 8;
 static_assert(kCompactChunk == 4096, "the scan of tilesTouched (scan.hip) counts the visible Gaussians per 4096 elements for this compaction");
 
 __global__ __launch_bounds__(kCompactThreads) void visible_count_kernel(const uint32_t* __restrict__ keys, uint32_t n,
@@ -587,9 +656,12 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
                                                                           uint32_t* __restrict__ hist, const DepthSide side) {
     constexpr int kCompactWaves = kCompactThreads / kWave;
     static_assert(kCompactRows * kCompactWaves == kWave, "one wave scans the (row, wave) counts");
-    __shared__ uint32_t lds[4 * 256];
+    // (digit counters: bytes 0, 1, 3, then kByte2Copies copies of byte 2's — NDC z crowds towards 1 and the lanes of a wave
+    // share two or three values of that byte; LDS atomics on one address are served a lane at a time: with one copy the
+    // 50 M scene's 46 M keys spent 75 us there, with a copy per eighth of the wave a tenth of it)
+    __shared__ uint32_t lds[(3 + kByte2Copies) * 256];
     __shared__ uint32_t s_off[kCompactRows * kCompactWaves];       // (row, wave): keys of that row in that wave, then where they go
-    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads) lds[i] = 0;
+    for (int i = threadIdx.x; i < (3 + kByte2Copies) * 256; i += kCompactThreads) lds[i] = 0;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     // A workgroup takes several chunks (chunk = blockIdx.x, += gridDim.x) and adds its digit counts to the global
     // histograms ONCE: with a workgroup per chunk the 1 425 workgroups of the bench frame each sent 1 024 atomics to the same
@@ -666,23 +738,21 @@ __global__ __launch_bounds__(kCompactThreads) void visible_compact_kernel(const 
             if (out_r) out_r[pos] = rect[r];
             atomicAdd(&lds[k[r] & 255u], 1u);
             atomicAdd(&lds[256 + ((k[r] >> 8) & 255u)], 1u);
-            atomicAdd(&lds[512 + ((k[r] >> 16) & 255u)], 1u);
+            atomicAdd(&lds[768 + (lane & (kByte2Copies - 1)) * 256 + ((k[r] >> 16) & 255u)], 1u);
         }
-        // The top byte of float bit patterns takes few distinct values: one LDS atomic per distinct value
-        // and wave instead of 64 colliding on the same counter.
-        const uint32_t d = k[r] >> 24;
-        unsigned long long todo = m[r];
-        while (todo) {
-            const uint32_t v = (uint32_t)__shfl((int)d, __ffsll((long long)todo) - 1, kWave);
-            const unsigned long long same = __ballot(vis && d == v) & todo;
-            if (lane == __ffsll((long long)same) - 1) atomicAdd(&lds[768 + v], (uint32_t)__popcll(same));
-            todo &= ~same;
-        }
+        // (the top byte of float bit patterns takes few distinct values in a wave)
+        wave_count_digit(lds + 512, k[r] >> 24, vis);
     }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads)
-        if (lds[i]) atomicAdd(&hist[i], lds[i]);
+    // hist: [byte 0 | byte 1 | byte 2 | byte 3] x 256
+    for (int i = threadIdx.x; i < 4 * 256; i += kCompactThreads) {
+        uint32_t c;
+        if (i < 512) c = lds[i];
+        else if (i < 768) { c = 0; for (int r = 0; r < kByte2Copies; ++r) c += lds[768 + r * 256 + (i - 512)]; }
+        else c = lds[512 + (i - 768)];
+        if (c) atomicAdd(&hist[i], c);
+    }
 }
 // ---- the side way: the few visible keys whose top byte is not the main one -----------------------------------------
 // Depth keys are float bits of NDC z. Nearly every visible Gaussian has z in [0.5, 1): top byte 0x3F; the fourth sort
@@ -711,6 +781,66 @@ __global__ __launch_bounds__(1024) void depth_side_kernel(const DepthSide side, 
     out_k[at] = key;
     out_v[at] = val;
     if (out_r) out_r[at] = rect;
+}
+// The digit counts visible_compact_kernel takes on its way, without the compaction: for scenes beyond 16 M Gaussians, whose
+// first depth pass reads the per-Gaussian keys itself (onesweep_kernel, DROP). A key takes part if it is not the sentinel and,
+// when the side way is taken, has the main top byte. A workgroup walks many chunks and adds to the global counters once.
+__global__ __launch_bounds__(256) void depth_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ hist,
+                                                         const DepthSide side) {
+    __shared__ uint32_t lds[(3 + kByte2Copies) * 256];   // bytes 0, 1, 3, then the copies of byte 2's counters (see visible_compact_kernel)
+    __shared__ uint32_t s_below;
+    for (int i = threadIdx.x; i < (3 + kByte2Copies) * 256; i += 256) lds[i] = 0;
+    if (threadIdx.x == 0) s_below = 0;
+    __syncthreads();
+    const bool side_on = side.words != nullptr && side.words[0] != 0u;
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t vecs = (n + 3u) / 4u;
+    uint32_t top_main = 0;                               // (wave-uniform) keys of this wave with the main top byte, side way
+    constexpr int kInFlight = 4;                         // 16-byte loads per lane and round (a lane with one load in flight waits on latency: 170 us for 200 MB)
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t v0 = blockIdx.x * 256u + threadIdx.x; v0 < ((vecs + 255u) & ~255u); v0 += kInFlight * stride) {      // (whole workgroups take a round or leave: the ballots below)
+        uint4 q[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const uint32_t v = v0 + (uint32_t)u * stride;
+            q[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (4ull * v + 3ull < n) {
+                q[u] = *reinterpret_cast<const uint4*>(keys + 4u * (size_t)v);
+            } else if (4ull * v < n) {
+                uint32_t t[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                for (int j = 0; j < 4; ++j) if (4ull * v + (uint32_t)j < n) t[j] = keys[4u * (size_t)v + j];
+                q[u] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const uint32_t k[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool vis = k[j] != 0xFFFFFFFFu && (!side_on || (k[j] >> 24) == side.main_top);
+                // (side way: the keys that will go to the side list and sort in FRONT of the stream — side.words[2], which the host reads)
+                if (side_on && k[j] != 0xFFFFFFFFu && (k[j] >> 24) < side.main_top) atomicAdd(&s_below, 1u);
+                if (vis) {
+                    atomicAdd(&lds[k[j] & 255u], 1u);
+                    atomicAdd(&lds[256 + ((k[j] >> 8) & 255u)], 1u);
+                    atomicAdd(&lds[768 + (lane & (kByte2Copies - 1)) * 256 + ((k[j] >> 16) & 255u)], 1u);
+                }
+                // (on the side way every key that takes part has the main top byte)
+                if (side_on) top_main += (uint32_t)__popcll(__ballot(vis));
+                else wave_count_digit(lds + 512, k[j] >> 24, vis);
+            }
+        }
+    }
+    if (lane == 0 && top_main) atomicAdd(&lds[512 + side.main_top], top_main);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) {
+        uint32_t c;
+        if (i < 512) c = lds[i];
+        else if (i < 768) { c = 0; for (int r = 0; r < kByte2Copies; ++r) c += lds[768 + r * 256 + (i - 512)]; }
+        else c = lds[512 + (i - 768)];
+        if (c) atomicAdd(&hist[i], c);
+    }
+    if (threadIdx.x == 0 && s_below) atomicAdd(&side.words[2], s_below);
 }
 }  // namespace
 
@@ -754,14 +884,32 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
     return GSR_OK;
 }
 
+// The same without the compaction (scenes beyond 16 M Gaussians): only the digit counts of the keys that take part; the first
+// pass then reads keys_in itself (sort_u32_passes with `drop_side`).
+int sort_u32_prepare_counts(const uint32_t* keys_in, uint32_t n, const SweepScratch* sc4, uint32_t* info, hipStream_t stream,
+                            uint32_t* host_top, const DepthSide* side) {
+    if (n == 0) return GSR_OK;
+    DepthSide no_side;
+    const uint32_t wgs = std::min<uint32_t>((n + 4095u) / 4096u, 2048u);
+    hipLaunchKernelGGL(depth_hist_kernel, dim3(wgs), dim3(256), 0, stream, keys_in, n, sc4[0].hist, side ? *side : no_side);
+    GSR_LAUNCH_CHECK("depth_hist_kernel");
+    hipLaunchKernelGGL(top_digit_count_kernel, dim3(1), dim3(256), 0, stream, sc4[0].hist + 3 * 256, info, host_top,
+                       side ? side->words : nullptr);
+    GSR_LAUNCH_CHECK("top_digit_count_kernel");
+    return GSR_OK;
+}
+
 // Passes [first, last) of the stable sort of n (key, value) u32 pairs: in -> a -> b -> a -> b. After P
 // passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
 // n_dev (may be null): the true key count on the device, n then being an upper bound that only sizes the grids.
 // second_in / a_s / b_s (all null, or none): a second value per key that takes the same path (in -> a -> b -> ...).
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream, const uint32_t* n_dev,
-                    const uint32_t* second_in, uint32_t* a_s, uint32_t* b_s) {
+                    const uint32_t* second_in, uint32_t* a_s, uint32_t* b_s, const DepthSide* drop_side) {
     if (n == 0) return GSR_OK;
+    // drop_side (pass 0 only): keys_in is the per-Gaussian array of n keys with sentinels (sort_u32_prepare_counts); vals_in must
+    // be null, second_in the per-Gaussian second values, n_dev the number of keys that take part
+    if (drop_side && (vals_in || !second_in || !n_dev)) return GSR_ERR_INVALID_ARG;
     for (int p = first; p < last; ++p) {
         const uint32_t* src_k = (p == 0) ? keys_in : ((p % 2 == 1) ? a_k : b_k);
         const uint32_t* src_v = (p == 0) ? vals_in : ((p % 2 == 1) ? a_v : b_v);
@@ -774,7 +922,15 @@ int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n
         SweepScratch sc = sc4[p];
         sc.error_word = sc4[0].error_word;
         sc.error_value = sc4[0].error_value;
-        const int rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev, src_s, dst_s);
+        int rc;
+        if (p == 0 && drop_side) {
+            DropSpec drop;
+            drop.n_out = n_dev;
+            drop.side = *drop_side;
+            rc = launch_pass<uint32_t>(src_k, nullptr, dst_k, dst_v, n, spec, sc4[0].hist, sc, stream, true, nullptr, src_s, dst_s, &drop);
+        } else {
+            rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev, src_s, dst_s);
+        }
         if (rc != GSR_OK) return rc;
     }
     return GSR_OK;

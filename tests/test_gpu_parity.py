@@ -486,6 +486,55 @@ def test_depth_keys_outside_the_main_top_byte(near, extra):
     _compare_all(r, img, exp, n)
 
 
+@pytest.mark.parametrize("case", ["top_byte_side_way", "top_byte_fallback", "anisotropic", "ragged_tail", "trained_like_far"])
+def test_first_depth_pass_without_the_compaction(case, monkeypatch):
+    """Scenes beyond 16 M Gaussians skip the compaction of the visible keys: the first depth pass reads the per-Gaussian keys
+    itself and leaves out what has no tile (onesweep_kernel, DROP; GSR_FUSED_DEPTH=1 forces that route at any size). Same
+    lists, ranges and pixels as the oracle's — with keys on the side list, with the four-pass fallback, with a last tile
+    that is mostly padding, and with culled Gaussians between the visible ones."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    monkeypatch.setenv("GSR_FUSED_DEPTH", "1")
+    bg = (0.1, 0.2, 0.3)
+    if case in ("top_byte_side_way", "top_byte_fallback"):
+        n, w, h = 3000, 320, 200
+        near = 0.5 if case == "top_byte_side_way" else 1.3
+        scene = scenes.garden_like_scene(n, seed=8100)
+        scene["means3D"][:, :3] *= 0.25
+        scene["scales"][:, :3] *= 2.0
+        if case == "top_byte_side_way":
+            rng = np.random.default_rng(8101)
+            sel = rng.choice(n, 12, replace=False)
+            d = rng.uniform(near * 2.2, near * 3.6, 12)
+            scene["means3D"][sel, 0] = rng.uniform(-0.05, 0.05, 12) * d
+            scene["means3D"][sel, 1] = rng.uniform(-0.05, 0.05, 12) * d
+            scene["means3D"][sel, 2] = -5.0 + d
+            scene["scales"][sel, :3] = 0.01
+        cam = camera.default_camera(w, h, near=near, far=100.0)
+    elif case == "anisotropic":
+        n = 20000
+        scene = scenes.garden_like_scene(n, seed=11)
+        scene["means3D"][:, :3] *= 0.25
+        cam = camera.default_camera(333, 257, near=0.05, far=50.0)
+    elif case == "ragged_tail":
+        n = 8192 + 37                                   # (a second tile of 37 keys; half the scene behind the camera: culled)
+        scene = scenes.garden_like_scene(n, seed=12)
+        scene["means3D"][:, :3] *= 0.5
+        cam = camera.default_camera(200, 120, near=0.05, far=50.0, position=(0.0, 0.0, -0.5))
+    else:
+        n = 60_000
+        scene = scenes.trained_like(n, seed=46)
+        cam = camera.default_camera(640, 368, near=0.02, far=120.0, position=(0.0, 0.0, -48.0))
+    exp = cpu_oracle.forward(scene, cam, bg, threads=8)
+    vis = exp["tilesTouched"] != 0
+    assert 0 < int(vis.sum()) < n                        # (some Gaussians to leave out)
+    if case == "top_byte_side_way":
+        others = int(((exp["depths"].view(np.uint32)[vis] >> 24) != 0x3F).sum())
+        assert 2 <= others <= 16
+    r, img = _run(scene, cam, bg)
+    _compare_all(r, img, exp, n)
+
+
 def test_four_waves_per_tile_blend_matches_one_wave_per_tile():
     """Calls with few tiles blend with four waves per tile (one 16 x 4 strip each) unless the staged records are
     counted; both forms must give the same pixels, nContrib and finalT bit for bit."""
