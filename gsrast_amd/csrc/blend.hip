@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void bl
 // order except every fourth call, which looks again). A frame before without any times (the history is new, or was
 // cleared) counts as similar.
 // (bench scene, 1920 x 1080, scripts/history_similarity.py, `profiles/r05_history_similarity.txt`)
-// along bench.py's camera path (0.31 units a frame) 0.85 to 0.97, median 0.91; between unrelated views 0.51 to 0.90, median 0.77
+// along bench.py's camera path (0.31 units a frame) 0.84 to 0.97, median 0.90; between unrelated views 0.46 to 0.90, median 0.81
 constexpr uint32_t kMinSimilarity = 800;         // of 1000
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ticks, const uint32_t* __restrict__ ticks_before,
                                                           uint32_t* __restrict__ order,

@@ -217,7 +217,9 @@ typedef struct gsr_forward_receipt {
     const volatile uint32_t* async_words;   /* host memory (pinned, never freed): {N-sized sort gave up, R-sized sort gave up
                                                (each: 0, or the serial of the call whose kernel gave up), serial of the call
                                                that owns the words, 0} — see gsr_poll_async_error */
-    gsr_tile_history* tile_history;         /* gsr_forward_args.tile_history of the call (NULL: one of the library's own) */
+    gsr_tile_history* tile_history;         /* gsr_forward_args.tile_history of the call (NULL: one of the library's own). A caller's
+                                               history must outlive the receipts that name it (gsr_backward looks into it for
+                                               the forward blend's tile order) */
 } gsr_forward_receipt;
 
 /* Arguments of one forward call. Fields up to box_max are, in order, the parameters of
