@@ -46,9 +46,19 @@ def timed(cam, kw):
     return float(np.median(ts))
 
 
+def plans_agree(cam):
+    """sorted lists, ranges, T, nContrib and pixels of the two binning plans, bit for bit (scripts/stress_plans_check.py's check, per pose)"""
+    out = []
+    for plan in ("sort", "blocks"):
+        img = r.draw(cam, plan=plan).clone()
+        b, im = r.map_binning_state(), r.map_image_state()
+        out.append((img.view(torch.int32), b["keys"].clone(), b["values"].clone(), im["ranges"].clone(), im["finalT"].view(torch.int32).clone(), im["nContrib"].clone()))
+    return all(torch.equal(x, y) for x, y in zip(*out))
+
+
 print(f"# {which}, N={n}, {W}x{H}, {poses} poses; times in ms")
 print("# pose  R/V     R          auto: plan feed overlapped |   sort  blocks  blocks+overlap   auto | best      auto/best")
-within, rows = 0, 0
+within, rows, agree, checked = 0, 0, 0, 0
 for i in range(poses):
     eye = rng.normal(size=3) * np.array([3.0, 0.6, 3.0])
     if i % 5 == 4:
@@ -72,6 +82,9 @@ for i in range(poses):
     ratio = t["auto"] / t[best]
     rows += 1
     within += int(ratio <= 1.05)
+    if i % 4 == 0:                                   # (every fourth pose: the 267 M-pair frames take a while to compare)
+        checked += 1
+        agree += int(plans_agree(cam))
     print(f"{i:5d} {r.last_num_rendered / max(V, 1):6.1f} {r.last_num_rendered:10d}  {auto_state[0]:6s} {'lists ' if auto_state[1] else 'blocks'} {int(auto_state[2])}"
           f"          | {t['sort']:6.3f} {t['blocks']:6.3f} {t['blocks+overlap']:6.3f}          {t['auto']:6.3f} | {best:14s} {ratio:5.3f}"
           f" | serial blocks: emit {stages['blocks'].get('duplicate', 0):.3f} blend {stages['blocks'].get('blend', 0):.3f}", flush=True)
@@ -79,3 +92,4 @@ for i in range(poses):
         for k, st in stages.items():
             print(f"#        {k:14s} " + " ".join(f"{n}={v:.3f}" for n, v in st.items() if v > 0), flush=True)
 print(f"# auto within 5 % of the best forced variant on {within} of {rows} poses ({100.0 * within / max(rows, 1):.0f} %)")
+print(f"# sort plan and block plan bit-equal (sorted keys / values, ranges, finalT, nContrib, pixels) on {agree} of {checked} poses checked")
