@@ -44,6 +44,42 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     r.draw(cam)                                                             # still usable afterwards
 
 
+def test_tile_history_handles_are_checked_and_their_statistics_readable():
+    """gsr_tile_history_*: a handle that is not one (no magic) is refused before anything is launched, NULL means the
+    library's own, statistics are host-side and start empty, destroy(NULL) is a no-op."""
+    import torch
+    from gsrast_amd import _capi
+    L = _capi.lib()
+    assert L.gsr_tile_history_destroy(None) == _capi.GSR_OK
+    assert L.gsr_tile_history_stats(None, (C.c_uint32 * 6)()) == _capi.GSR_ERR_INVALID_ARG
+    assert L.gsr_tile_history_create(None) == _capi.GSR_ERR_INVALID_ARG
+    scene, cam, bg, _ = load_golden()
+    r = _rast(cam.width, cam.height)
+    r.configure_from_scene(scene)
+    st = r.tile_history_stats()
+    assert st["calls"] == 0 and st["mean_ticks"] == 0 and not st["order_dropped"]
+    ref = r.draw(cam, tile_history=False).clone()
+    for _ in range(3):
+        assert torch.equal(r.draw(cam), ref)
+    assert r.tile_history_stats()["calls"] == 3
+    # not a history: 512 zero bytes where the handle should be
+    fake = (C.c_uint8 * 512)()
+    good, r._history = r._history, C.c_void_p(C.addressof(fake))
+    with pytest.raises(_capi.GsrError) as e:
+        r.draw(cam)
+    assert e.value.code == _capi.GSR_ERR_INVALID_ARG
+    r._history = good
+    assert torch.equal(r.draw(cam), ref)                                    # still usable afterwards
+    # a second handle, created and destroyed around one frame
+    h = C.c_void_p()
+    assert L.gsr_tile_history_create(C.byref(h)) == _capi.GSR_OK and h.value
+    r._history = h
+    assert torch.equal(r.draw(cam), ref)
+    torch.cuda.synchronize()
+    r._history = good
+    assert L.gsr_tile_history_destroy(h) == _capi.GSR_OK
+
+
 def test_runs_on_a_non_default_stream_and_interleaves_two_rasterizers():
     import torch
     from gsrast_amd import camera, scenes
