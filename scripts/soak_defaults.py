@@ -2,7 +2,7 @@
 depth sort or the blend, the slow tiles of the frame before first — against the same call with every kernel on the caller's
 stream in patch order (GSR_FLAG_SERIAL_EMIT | GSR_FLAG_NO_TILE_HISTORY): a camera that walks, jumps and looks away, sizes
 that alternate; image, finalT, nContrib, geomState.rgb, numRendered and the sorted lists bit for bit.
-python scripts/soak_defaults.py [frames] [splats]"""
+python scripts/soak_defaults.py [frames] [splats] [garden_like | trained_like]"""
 import os
 import sys
 
@@ -14,8 +14,10 @@ from gsrast_amd.rasterizer import SplatRasterizer
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-scene = scenes.garden_like_scene(n, seed=91)
-span = float(np.max(scene["means3D"][:, :3].max(0) - scene["means3D"][:, :3].min(0)))
+which = sys.argv[3] if len(sys.argv) > 3 else "garden_like"
+scene = scenes.trained_like(n, seed=91) if which == "trained_like" else scenes.garden_like_scene(n, seed=91)
+inner = np.abs(scene["means3D"][:, :3]).max(1) < 20.0          # (not the trained-like scene's background shell)
+span = float(np.max(scene["means3D"][inner, :3].max(0) - scene["means3D"][inner, :3].min(0)))
 big = dict(scene, scales=scene["scales"].copy())
 big["scales"][:, :3] *= 5.0                               # dense frames: 48 and more instances per visible Gaussian, the block-fed blend
 rs = []
@@ -49,7 +51,7 @@ for i in range(frames):
     d = (pos if away else -pos) / max(np.linalg.norm(pos), 1e-6)
     yaw, pitch = float(np.arctan2(d[0], d[2])), float(np.arcsin(np.clip(d[1], -1, 1)))
     r = rs[(i // 11) % 4]
-    cam = camera.first_person_camera(tuple(float(x) for x in pos), yaw, pitch, float(np.radians(45.0)), 0.001 * span, span, r.width, r.height, True)
+    cam = camera.first_person_camera(tuple(float(x) for x in pos), yaw, pitch, float(np.radians(45.0)), 0.001 * span, 4.0 * span, r.width, r.height, True)
     scale = np.float32(0.1 if i % 17 == 16 else 1.0)
     r.opacities = torch.from_numpy((r.base_opacities * scale).astype(np.float32)).to(r.device)
     plan = "blocks" if i % 5 == 4 else "auto"
@@ -72,4 +74,4 @@ for i in range(frames):
     bad += int(not same)
     if i % 40 == 0:
         print(f"frame {i}: {r.width}x{r.height} R={R} plan={r.last_plan} reordered={r.last_tiles_reordered} overlapped={r.last_emit_overlapped} same={same}", flush=True)
-print(f"{counts} frames, {bad} differing; second-stream work seen: {seen}")
+print(f"{which}: {counts} frames, {bad} differing; second-stream work seen: {seen}")
