@@ -575,11 +575,12 @@ int gsr_forward(gsr_forward_args* a) {
             for (gsr_tile_history* h : g_rb.default_histories)
                 if (h->last_stream == stream) { hist = h; break; }
             if (!hist && g_rb.default_histories.size() < kMaxDefaultHistories) {
-                GSR_STEP(tile_history_new(&hist));
-                g_rb.default_histories.push_back(hist);
+                // (a history is an accelerator: if the device has no memory left for one, the call runs without)
+                if (tile_history_new(&hist) == GSR_OK) g_rb.default_histories.push_back(hist);
+                else { hist = nullptr; (void)hipGetLastError(); g_hip_error[0] = 0; }
             }
         }
-        if (hist) { hist->last_stream = stream; hist->used = true; GSR_STEP(g_rb.ensure_side()); }
+        if (hist) { hist->last_stream = stream; hist->used = true; GSR_STEP(g_rb.ensure_side()); }       // (the stream the sort of the order runs on)
     }
     const bool history = hist != nullptr;
     // The order costs a launch on the second stream and the host a few microseconds, and it pays on frames that END on a
