@@ -31,45 +31,60 @@ constexpr int kCols = 256;         // tile columns / rows the tables are laid ou
 // rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
 // rect_packed: the visible Gaussians' rectangles in depth order (they travel through the depth sort with the indices;
 // gathering them by index here cost 0.93 ms on 50 M Gaussians)
+constexpr int kCountChunks = 4;    // chunks per workgroup of column_count_kernel: their loads are all issued before the first is
+                                   // waited for (one round trip to memory for four chunks: at 50 M Gaussians 90 K workgroups of one
+                                   // chunk each spent their 2.2 us mostly on that trip, 0.20 ms in all)
 __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint32_t* __restrict__ rect_packed, int stride_x,
-                                                              int stride_y, uint32_t* __restrict__ table) {
+                                                              int stride_y, uint32_t* __restrict__ table, uint32_t chunks) {
     // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows
     // likewise); one prefix sum per array (the first 256 threads) then gives the per-column / per-row key counts.
     __shared__ uint32_t lds_hx[kCols + 1], lds_hy[kCols + 1];
     __shared__ uint32_t s_ws[2][kCols / kWave];
-    if (threadIdx.x <= kCols) {
-        lds_hx[threadIdx.x] = 0;
-        lds_hy[threadIdx.x] = 0;
+    uint32_t packed_of[kCountChunks];
+#pragma unroll
+    for (int c = 0; c < kCountChunks; ++c) {
+        const uint32_t chunk = blockIdx.x * kCountChunks + (uint32_t)c;
+        const long long r = (long long)chunk * kChunk + threadIdx.x;
+        packed_of[c] = (chunk < chunks && r < n) ? rect_packed[r] : 0u;
     }
-    __syncthreads();
-    const int r = blockIdx.x * kChunk + threadIdx.x;
-    const uint32_t packed = (r < n) ? rect_packed[r] : 0u;
-    if (packed) {
-        const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
-        atomicAdd(&lds_hx[x0], h);
-        atomicSub(&lds_hx[x0 + w], h);
-        atomicAdd(&lds_hy[y0], w);
-        atomicSub(&lds_hy[y0 + h], w);
-    }
-    __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const bool scans = threadIdx.x < kCols;
-    uint32_t ix = scans ? lds_hx[threadIdx.x] : 0u, iy = scans ? lds_hy[threadIdx.x] : 0u;
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t ox = __shfl_up(ix, off, kWave), oy = __shfl_up(iy, off, kWave);
-        if (lane >= off) { ix += ox; iy += oy; }
+    for (int c = 0; c < kCountChunks; ++c) {
+        const uint32_t chunk = blockIdx.x * kCountChunks + (uint32_t)c;
+        if (chunk >= chunks) break;                          // (uniform over the workgroup)
+        if (threadIdx.x <= kCols) {
+            lds_hx[threadIdx.x] = 0;
+            lds_hy[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        const uint32_t packed = packed_of[c];
+        if (packed) {
+            const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
+            atomicAdd(&lds_hx[x0], h);
+            atomicSub(&lds_hx[x0 + w], h);
+            atomicAdd(&lds_hy[y0], w);
+            atomicSub(&lds_hy[y0 + h], w);
+        }
+        __syncthreads();
+        uint32_t ix = scans ? lds_hx[threadIdx.x] : 0u, iy = scans ? lds_hy[threadIdx.x] : 0u;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t ox = __shfl_up(ix, off, kWave), oy = __shfl_up(iy, off, kWave);
+            if (lane >= off) { ix += ox; iy += oy; }
+        }
+        if (scans && lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
+        __syncthreads();
+        if (scans) {
+            for (int ww = 0; ww < wave; ++ww) { ix += s_ws[0][ww]; iy += s_ws[1][ww]; }
+            // one table row per chunk: [keys per tile column | keys per tile row]. The row counts are summed
+            // down the chunks by the column scan below (its totals are the digit histogram of the tile-row
+            // pass); adding them with global atomics instead would serialise every chunk on the same words.
+            uint32_t* row = table + (size_t)chunk * (stride_x + stride_y);
+            if ((int)threadIdx.x < stride_x) row[threadIdx.x] = ix;
+            if ((int)threadIdx.x < stride_y) row[stride_x + threadIdx.x] = iy;
+        }
     }
-    if (scans && lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
-    __syncthreads();
-    if (!scans) return;
-    for (int ww = 0; ww < wave; ++ww) { ix += s_ws[0][ww]; iy += s_ws[1][ww]; }
-    // one table row per chunk: [keys per tile column | keys per tile row]. The row counts are summed
-    // down the chunks by the column scan below (its totals are the digit histogram of the tile-row
-    // pass); adding them with global atomics instead would serialise every chunk on the same words.
-    uint32_t* row = table + (size_t)blockIdx.x * (stride_x + stride_y);
-    if ((int)threadIdx.x < stride_x) row[threadIdx.x] = ix;
-    if ((int)threadIdx.x < stride_y) row[stride_x + threadIdx.x] = iy;
 }
 
 // ---- exclusive prefix of table[row][x] down the rows, for every column x ---------------------
@@ -264,7 +279,8 @@ int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sor
     uint32_t* partial = reinterpret_cast<uint32_t*>(scratch + align128((size_t)chunks * 512 * 4));
     uint32_t* colbase = reinterpret_cast<uint32_t*>(scratch + align128((size_t)chunks * 512 * 4) + align128((size_t)blocks * 512 * 4));
     GSR_HIP_TRY(hipMemsetAsync(hist_y, 0, 256 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(column_count_kernel, dim3(chunks), dim3(kChunk), 0, stream, n, rect_packed, stride_x, stride_y, table);
+    hipLaunchKernelGGL(column_count_kernel, dim3((chunks + kCountChunks - 1) / kCountChunks), dim3(kChunk), 0, stream, n, rect_packed, stride_x,
+                       stride_y, table, chunks);
     GSR_LAUNCH_CHECK("column_count_kernel");
     hipLaunchKernelGGL(colscan_reduce_kernel, dim3(blocks), dim3(stride), 0, stream, table, chunks, stride, partial);
     GSR_LAUNCH_CHECK("colscan_reduce_kernel");
