@@ -98,11 +98,17 @@ __global__ __launch_bounds__(kMaxBlocks) void blockscan_partials_kernel(uint32_t
     __shared__ uint32_t s_ws[kMaxBlocks / kWave];
     const int nbp = meta.nbp;
     uint32_t running = 0;
-#pragma unroll 8
-    for (uint32_t g = 0; g < groups; ++g) {
-        const uint32_t v = partial[(size_t)g * nbp + threadIdx.x];
-        partial[(size_t)g * nbp + threadIdx.x] = running;
-        running += v;
+    // (32 rows' loads are issued before the first of their stores: the compiler cannot know that a store does not touch the next
+    // row, and a row at a time is a round trip each — 47 of them on the bench frame)
+    for (uint32_t g0 = 0; g0 < groups; g0 += 32u) {
+        uint32_t v[32];
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) v[k] = (g0 + k < groups) ? partial[(size_t)(g0 + k) * nbp + threadIdx.x] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) {
+            if (g0 + k < groups) partial[(size_t)(g0 + k) * nbp + threadIdx.x] = running;
+            running += v[k];
+        }
     }
     const uint32_t len = ((int)threadIdx.x < nb) ? running : 0u;
     uint32_t total_entries, total_units;
@@ -124,12 +130,15 @@ __global__ __launch_bounds__(kMaxBlocks) void blockscan_apply_kernel(uint32_t* _
                                                                      const uint32_t* __restrict__ list_start) {
     const uint32_t r0 = blockIdx.x * kScanRows, r1 = min(rows, r0 + kScanRows);
     uint32_t running = partial[(size_t)blockIdx.x * nbp + threadIdx.x] + list_start[threadIdx.x];
-#pragma unroll 8
-    for (uint32_t r = r0; r < r1; ++r) {
-        const size_t cell = (size_t)r * nbp + threadIdx.x;
-        const uint32_t v = table[cell];
-        table[cell] = running;
-        running += v;
+    for (uint32_t b0 = r0; b0 < r1; b0 += 32u) {          // (loads of 32 rows before their stores, as above)
+        uint32_t v[32];
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) v[k] = (b0 + k < r1) ? table[(size_t)(b0 + k) * nbp + threadIdx.x] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) {
+            if (b0 + k < r1) table[(size_t)(b0 + k) * nbp + threadIdx.x] = running;
+            running += v[k];
+        }
     }
 }
 
@@ -391,11 +400,15 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(BlockMeta meta, int n
         if (w < wave) running += s_sum[w][lane];
         total += s_sum[w][lane];
     }
-#pragma unroll 8
-    for (uint32_t u = a; u < z; ++u) {
-        const uint32_t v = cnt[(size_t)u * 64 + lane];
-        cnt[(size_t)u * 64 + lane] = running;
-        running += v;
+    for (uint32_t u0b = a; u0b < z; u0b += 32u) {          // (loads of 32 units before their stores: cnt is read and written)
+        uint32_t v[32];
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) v[k] = (u0b + k < z) ? cnt[(size_t)(u0b + k) * 64 + lane] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) {
+            if (u0b + k < z) cnt[(size_t)(u0b + k) * 64 + lane] = running;
+            running += v[k];
+        }
     }
     const uint32_t tx = (b % (uint32_t)nbx) * kBW + (uint32_t)(lane & 7), ty = (b / (uint32_t)nbx) * kBH + (uint32_t)(lane >> 3);
     if (wave == 0 && tx < (uint32_t)gx && ty < (uint32_t)gy) tile_count[ty * gx + tx] = total;

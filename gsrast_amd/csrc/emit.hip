@@ -104,11 +104,17 @@ __global__ __launch_bounds__(512) void colscan_partials_kernel(uint32_t* __restr
                                                                uint32_t* __restrict__ hist_y) {
     __shared__ uint32_t s_ws[8];
     uint32_t running = 0;
-#pragma unroll 8
-    for (uint32_t b = 0; b < blocks; ++b) {
-        const uint32_t v = partial[(size_t)b * stride + threadIdx.x];
-        partial[(size_t)b * stride + threadIdx.x] = running;
-        running += v;
+    // (32 rows' loads are issued before the first of their stores — the compiler cannot know that the stores do not touch the
+    // next row — : one workgroup walks 352 rows at 50 M Gaussians, 43 us a row at a time)
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 32u) {
+        uint32_t v[32];
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) v[k] = (b0 + k < blocks) ? partial[(size_t)(b0 + k) * stride + threadIdx.x] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) {
+            if (b0 + k < blocks) partial[(size_t)(b0 + k) * stride + threadIdx.x] = running;
+            running += v[k];
+        }
     }
     // columns >= stride_x hold the per-tile-row counts: their totals are the row histogram
     if ((int)threadIdx.x >= stride_x) hist_y[(int)threadIdx.x - stride_x] = running;
@@ -133,12 +139,16 @@ __global__ __launch_bounds__(256) void colscan_apply_kernel(uint32_t* __restrict
                                                             const uint32_t* __restrict__ colbase) {
     const uint32_t r0 = blockIdx.x * kRowsPerBlock, r1 = min(rows, r0 + kRowsPerBlock);
     uint32_t running = partial[(size_t)blockIdx.x * stride + threadIdx.x] + colbase[threadIdx.x];
-#pragma unroll 8
-    for (uint32_t r = r0; r < r1; ++r) {
-        const size_t cell = (size_t)r * stride + threadIdx.x;
-        const uint32_t v = table[cell];
-        table[cell] = running;
-        running += v;
+    // (32 rows' loads before the first of their stores, as in colscan_partials_kernel)
+    for (uint32_t b0 = r0; b0 < r1; b0 += 32u) {
+        uint32_t v[32];
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) v[k] = (b0 + k < r1) ? table[(size_t)(b0 + k) * stride + threadIdx.x] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) {
+            if (b0 + k < r1) table[(size_t)(b0 + k) * stride + threadIdx.x] = running;
+            running += v[k];
+        }
     }
 }
 
