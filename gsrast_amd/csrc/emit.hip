@@ -154,26 +154,48 @@ __global__ __launch_bounds__(256) void colscan_apply_kernel(uint32_t* __restrict
 
 // ---- emission ----------------------------------------------------------------------------------
 // The keys of a chunk leave in (column, position) order, one key per lane: consecutive lanes write consecutive keys of
-// one column's run, so a wave's stores are a few whole lines. (One lane per Gaussian walking its own tiles — the
-// version before — sent every key to a different place: two store requests per key, 250 M on the 50 M frame, which
-// is what its 1.2 ms were made of.)
+// one column's run, so a wave's stores are a few whole lines. (One lane per Gaussian walking its own tiles and storing
+// to memory — the first version — sent every key to a different place: two store requests per key, 250 M on the 50 M
+// frame, which is what its 1.2 ms were made of.)
 //   masks : per column, which of the chunk's Gaussians cover it (bit g of word g / 32) and, per word, the rows they
 //           add there; prefix over the words -> where a word's keys start in the column's run of this chunk
-//   keys  : key j of the chunk -> its column (search in the columns' starts), the word (search in the word prefix), the
-//           Gaussian (walk over the word's set bits, subtracting heights) and the row inside its rectangle
+// then one of two ways, chosen per chunk:
+//   light chunks (at most kStage keys, no Gaussian with more than kLightKeys: the frames of small splats this plan is for)
+//     place : every Gaussian works out where ITS keys go among the chunk's — per column of its rectangle: the column's
+//             start, the rows of the words below, the rows of the set bits below its own in its word — and files them
+//             (column, row, Gaussian: 25 bits) in an LDS image of the chunk's key sequence
+//     keys  : lane j reads slot j and writes key and value
+//   heavy chunks
+//     keys  : key j of the chunk -> its column (search in the columns' starts), the word (search in the word prefix), the
+//             Gaussian (walk over the word's set bits, subtracting heights) and the row inside its rectangle: 141 wave
+//             instructions per 64 keys whatever the Gaussians' sizes (the placement is a loop over a lane's own keys: a
+//             splat of a thousand tiles holds its wave for a thousand rounds — 0.15 -> 1.2 ms on a frame of such)
+// At 50 M Gaussians (2.7 keys each) the search took 0.757 ms at 59 % vector-busy; the placement takes a third of the
+// instructions.
+constexpr int kStage = 2048;       // light chunks: keys at most (the LDS image)
+constexpr uint32_t kLightKeys = 32;    // ... and keys per Gaussian at most
+
+// SX: the grid's columns rounded up to 64 (the table's stride_x)
+template <int SX>
 __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_t* __restrict__ sorted_depth,
                                                             const uint32_t* __restrict__ sorted_idx,
                                                             const uint32_t* __restrict__ rect_packed,
-                                                            const uint32_t* __restrict__ table, int stride, int stride_x, int grid_x,
+                                                            const uint32_t* __restrict__ table, int stride, int grid_x,
                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ values) {
     constexpr int W = kChunk / 32;                       // mask words per column
+    constexpr int stride_x = SX;
+    constexpr uint32_t sx = (uint32_t)SX;
+    // Sized by the grid's columns: 33 KB in all up to 128 columns — four workgroups a CU.
     // [word][column]: the lanes of the build address one word of different columns, those of the prefix one column each
-    __shared__ uint32_t s_mask[W][kCols];
-    __shared__ uint32_t s_wpre[W + 1][kCols];           // rows added by the words below; [W] = the column's keys in this chunk
+    __shared__ uint32_t s_dyn[(2 * W + 2) * SX];
+    uint32_t* s_mask = s_dyn;                            // [W][sx]
+    uint32_t* s_wpre = s_mask + W * sx;                  // [W + 1][sx] rows added by the words below; [W] = the column's keys in this chunk
+    uint32_t* s_delta = s_wpre + (W + 1) * sx;           // [sx] output index of a key of the column minus its place among the chunk's
+    __shared__ uint32_t s_cstart[kCols];                 // where the column's keys start among the chunk's (chunk_total past the grid's columns)
     __shared__ uint32_t s_rect[kChunk], s_depth[kChunk], s_idx[kChunk];
-    __shared__ uint32_t s_cstart[kCols];                 // where the column's keys start among the chunk's
-    __shared__ uint32_t s_col[kCols];                    // output index of the chunk's first key in column x
+    __shared__ uint32_t s_stage[kStage];
     __shared__ uint32_t s_ws[kChunk / kWave];
+    __shared__ uint32_t s_big;                           // some Gaussian of the chunk has more than kLightKeys keys
     const int g = threadIdx.x;
     // Which chunk: workgroup b runs on XCD b % 8. Consecutive chunks write adjacent pieces of every column's run, so 32
     // consecutive chunks go to ONE XCD: the pieces of a line then meet in that XCD's L2 and leave as whole lines.
@@ -191,30 +213,28 @@ __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_
     s_rect[g] = rect;
     s_depth[g] = depth_in;
     s_idx[g] = idx_in;
-    if (g < kCols) s_col[g] = col_in;
-    // (only the columns of this grid: stride_x of them, a multiple of 64; 16 bytes per lane and store)
-    for (int i = g; i < W * (stride_x / 4); i += kChunk) {
-        const int k = i / (stride_x / 4), q = i - k * (stride_x / 4);
-        reinterpret_cast<uint4*>(&s_mask[k][0])[q] = make_uint4(0u, 0u, 0u, 0u);
-        reinterpret_cast<uint4*>(&s_wpre[k][0])[q] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    if (g == 0) s_big = 0;
+    // (s_mask and the first W rows of s_wpre are one run of 2 W sx words; 16 bytes per lane and store)
+    for (uint32_t i = (uint32_t)g; i < 2u * W * sx / 4u; i += kChunk) reinterpret_cast<uint4*>(s_dyn)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, h = rect >> 24;
+    const uint32_t x0 = rect & 0xFFu, w = (rect >> 8) & 0xFFu, y0 = (rect >> 16) & 0xFFu, h = rect >> 24;
+    const uint32_t word = (uint32_t)g >> 5, bit = 1u << (g & 31);
     for (uint32_t c = 0; c < w; ++c) {
-        atomicOr(&s_mask[g >> 5][x0 + c], 1u << (g & 31));
-        atomicAdd(&s_wpre[g >> 5][x0 + c], h);
+        atomicOr(&s_mask[word * sx + x0 + c], bit);
+        atomicAdd(&s_wpre[word * sx + x0 + c], h);
     }
+    if (w * h > kLightKeys) s_big = 1;
     __syncthreads();
     // per column: the words' row counts -> exclusive prefix, total in [W]
     uint32_t col_total = 0;
     if (g < stride_x) {
 #pragma unroll
         for (int k = 0; k < W; ++k) {
-            const uint32_t v = s_wpre[k][g];
-            s_wpre[k][g] = col_total;
+            const uint32_t v = s_wpre[k * sx + g];
+            s_wpre[k * sx + g] = col_total;
             col_total += v;
         }
-        s_wpre[W][g] = col_total;
+        s_wpre[W * sx + g] = col_total;
     }
     uint32_t chunk_total;
     {
@@ -235,9 +255,36 @@ __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_
             tot += s_ws[ww];
         }
         chunk_total = tot;
-        if (g < kCols) s_cstart[g] = base + incl - col_total;      // (columns past stride_x: col_total = 0, start = chunk_total)
+        const uint32_t start = base + incl - col_total;  // (columns past stride_x: col_total = 0, start = chunk_total)
+        if (g < kCols) s_cstart[g] = start;
+        if (g < stride_x) s_delta[g] = col_in - start;   // (mod 2^32)
     }
     __syncthreads();
+    if (chunk_total <= (uint32_t)kStage && s_big == 0) {
+        // ---- light chunk: every Gaussian files its own keys
+        for (uint32_t c = 0; c < w; ++c) {
+            const uint32_t x = x0 + c;
+            // the rows of the Gaussians below in the same word (set bits, their heights)
+            uint32_t below = s_mask[word * sx + x] & (bit - 1u), at = s_cstart[x] + s_wpre[word * sx + x];
+            while (below) {
+                at += s_rect[(word << 5) + (uint32_t)__ffs((int)below) - 1u] >> 24;
+                below &= below - 1u;
+            }
+            const uint32_t e = x | (y0 << 8) | ((uint32_t)g << 16);
+            for (uint32_t row = 0; row < h; ++row) s_stage[at + row] = e + (row << 8);
+        }
+        __syncthreads();
+        for (uint32_t j = (uint32_t)g; j < chunk_total; j += kChunk) {
+            const uint32_t e = s_stage[j];
+            const uint32_t x = e & 0xFFu, gg = e >> 16;
+            const uint32_t tile = __umul24((e >> 8) & 0xFFu, (uint32_t)grid_x) + x;
+            const uint32_t pos = j + s_delta[x];
+            keys[pos] = ((uint64_t)tile << 32) | (uint64_t)s_depth[gg];
+            values[pos] = s_idx[gg];
+        }
+        return;
+    }
+    // ---- heavy chunk: every key looks for its Gaussian
     const uint32_t top = stride_x > 128 ? 128u : (stride_x > 64 ? 64u : 32u);
     for (uint32_t j = (uint32_t)g; j < chunk_total; j += kChunk) {
         // the last column that starts at or before j (of columns sharing a start, the last one is the one with keys)
@@ -248,9 +295,9 @@ __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_
         uint32_t k = 0;
 #pragma unroll
         for (uint32_t step = W / 2; step >= 1; step >>= 1)
-            if (s_wpre[k + step][x] <= t) k += step;
+            if (s_wpre[(k + step) * sx + x] <= t) k += step;
         // inside the word: Gaussian after Gaussian (set bits, ascending), each with the rows of its rectangle
-        uint32_t rem = t - s_wpre[k][x], m = s_mask[k][x], gg = 0, gr = 0;
+        uint32_t rem = t - s_wpre[k * sx + x], m = s_mask[k * sx + x], gg = 0, gr = 0;
         for (;;) {
             gg = (k << 5) + (uint32_t)__ffs((int)m) - 1u;
             gr = s_rect[gg];
@@ -260,7 +307,7 @@ __global__ __launch_bounds__(kChunk) void emit_chunk_kernel(int n, const uint32_
             rem -= gh;
         }
         const uint32_t tile = __umul24(((gr >> 16) & 0xFFu) + rem, (uint32_t)grid_x) + x;
-        const uint32_t pos = s_col[x] + t;
+        const uint32_t pos = j + s_delta[x];
         keys[pos] = ((uint64_t)tile << 32) | (uint64_t)s_depth[gg];
         values[pos] = s_idx[gg];
     }
@@ -300,8 +347,16 @@ int launch_emit_columns(int n, const uint32_t* sorted_depth, const uint32_t* sor
     GSR_LAUNCH_CHECK("colscan_apply_kernel");
     if (mark_prep_end) GSR_HIP_TRY(hipEventRecord(mark_prep_end, stream));
     if (mark_emit_begin) GSR_HIP_TRY(hipEventRecord(mark_emit_begin, stream));
-    hipLaunchKernelGGL(emit_chunk_kernel, dim3(chunks), dim3(kChunk), 0, stream, n, sorted_depth, sorted_idx, rect_packed, table,
-                       stride, stride_x, grid_x, keys, values);
+#define GSR_EMIT_CHUNK(SX)                                                                                                     \
+    hipLaunchKernelGGL(emit_chunk_kernel<SX>, dim3(chunks), dim3(kChunk), 0, stream, n, sorted_depth, sorted_idx, rect_packed, table, \
+                       stride, grid_x, keys, values)
+    switch (stride_x) {
+        case 64: GSR_EMIT_CHUNK(64); break;
+        case 128: GSR_EMIT_CHUNK(128); break;
+        case 192: GSR_EMIT_CHUNK(192); break;
+        default: GSR_EMIT_CHUNK(256); break;
+    }
+#undef GSR_EMIT_CHUNK
     GSR_LAUNCH_CHECK("emit_chunk_kernel");
     return GSR_OK;
 }
