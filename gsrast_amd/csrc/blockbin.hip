@@ -28,6 +28,8 @@
 // R-sized traffic: 12 R bytes written once (the reference's emit + 6-pass sort moves > 150 R).
 #include <stdlib.h>
 
+#include <map>
+
 #include "blend_core.hpp"
 #include "blockbin.hpp"
 
@@ -888,19 +890,30 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
                        t.meta.list_start());
     GSR_LAUNCH_CHECK("blockscan_apply_kernel");
     const size_t mask_bytes = ((size_t)t.nb * (t.chunk / 32 + 1) * 2 + kMaxBlocks + t.nbp + 3 * (size_t)t.chunk) * 4;
+    // More than the default 48 KB of dynamic LDS: asked for once per device and host thread (the most a grid of kMaxBlocks
+    // blocks can need), not on every call.
+#define GSR_STEP_LDS(kernel, chunk_)                                                                                          \
+    do {                                                                                                                      \
+        static thread_local std::map<int, bool> asked;                                                                        \
+        int dev_ = 0;                                                                                                         \
+        GSR_HIP_TRY(hipGetDevice(&dev_));                                                                                     \
+        if (!asked[dev_]) {                                                                                                   \
+            const size_t most_ = ((size_t)kMaxBlocks * ((chunk_) / 32 + 1) * 2 + kMaxBlocks + kMaxBlocks + 3 * (size_t)(chunk_)) * 4; \
+            GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)(most_ < 160 * 1024 ? most_ : 160 * 1024)));                                 \
+            asked[dev_] = true;                                                                                               \
+        }                                                                                                                     \
+    } while (0)
     if (t.chunk == kCoarse) {
-        if (mask_bytes > 48 * 1024)
-            GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel<kCoarse>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
+        if (mask_bytes > 48 * 1024) GSR_STEP_LDS(coarse_emit_kernel<kCoarse>, kCoarse);
         hipLaunchKernelGGL(coarse_emit_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), mask_bytes, stream, n, sorted_depth,
                            sorted_idx, sorted_rect, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
     } else {
-        if (mask_bytes > 48 * 1024)
-            GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_emit_kernel<kCoarseSmall>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes));
+        if (mask_bytes > 48 * 1024) GSR_STEP_LDS(coarse_emit_kernel<kCoarseSmall>, kCoarseSmall);
         hipLaunchKernelGGL(coarse_emit_kernel<kCoarseSmall>, dim3(t.chunks), dim3(kCoarseSmall), mask_bytes, stream, n, sorted_depth,
                            sorted_idx, sorted_rect, t.table, t.nbx, t.nb, t.nbp, ent_rd, ent_idx);
     }
+#undef GSR_STEP_LDS
     GSR_LAUNCH_CHECK("coarse_emit_kernel");
     if (ev_coarse_end) GSR_HIP_TRY(hipEventRecord(ev_coarse_end, stream));
 

@@ -31,15 +31,16 @@ constexpr int kCols = 256;         // tile columns / rows the tables are laid ou
 // rect packed as x0 | w << 8 | y0 << 16 | h << 24 (all < 256); 0 = culled / empty
 // rect_packed: the visible Gaussians' rectangles in depth order (they travel through the depth sort with the indices;
 // gathering them by index here cost 0.93 ms on 50 M Gaussians)
-constexpr int kCountChunks = 4;    // chunks per workgroup of column_count_kernel: their loads are all issued before the first is
-                                   // waited for (one round trip to memory for four chunks: at 50 M Gaussians 90 K workgroups of one
-                                   // chunk each spent their 2.2 us mostly on that trip, 0.20 ms in all)
+constexpr int kCountChunks = 4;    // chunks per workgroup of column_count_kernel: one round trip to memory, two barriers and one
+                                   // wave-wide scan per table row for four chunks (a chunk a workgroup, at 50 M Gaussians: 90 K
+                                   // workgroups of 2.2 us, 0.20 ms in all; four chunks one after the other: 0.19)
+static_assert(kCountChunks * 2 == kChunk / kWave, "one wave per (chunk, columns | rows) array");
 __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint32_t* __restrict__ rect_packed, int stride_x,
                                                               int stride_y, uint32_t* __restrict__ table, uint32_t chunks) {
-    // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows
-    // likewise); one prefix sum per array (the first 256 threads) then gives the per-column / per-row key counts.
-    __shared__ uint32_t lds_hx[kCols + 1], lds_hy[kCols + 1];
-    __shared__ uint32_t s_ws[2][kCols / kWave];
+    // Difference arrays: a w x h rectangle adds h at column x0 and takes it back at x0 + w (rows likewise); one prefix sum
+    // per array then gives the per-column / per-row key counts. Array (c, a) — chunk c of the workgroup's four, a = 0
+    // columns / 1 rows — is summed by wave 2 c + a alone: four consecutive entries a lane, one wave-wide scan, no barrier.
+    __shared__ __attribute__((aligned(16))) uint32_t lds_h[kCountChunks][2][kCols + 4];
     uint32_t packed_of[kCountChunks];
 #pragma unroll
     for (int c = 0; c < kCountChunks; ++c) {
@@ -47,44 +48,38 @@ __global__ __launch_bounds__(kChunk) void column_count_kernel(int n, const uint3
         const long long r = (long long)chunk * kChunk + threadIdx.x;
         packed_of[c] = (chunk < chunks && r < n) ? rect_packed[r] : 0u;
     }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const bool scans = threadIdx.x < kCols;
+    for (int i = threadIdx.x; i < kCountChunks * 2 * (kCols + 4); i += kChunk) (&lds_h[0][0][0])[i] = 0u;
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < kCountChunks; ++c) {
-        const uint32_t chunk = blockIdx.x * kCountChunks + (uint32_t)c;
-        if (chunk >= chunks) break;                          // (uniform over the workgroup)
-        if (threadIdx.x <= kCols) {
-            lds_hx[threadIdx.x] = 0;
-            lds_hy[threadIdx.x] = 0;
-        }
-        __syncthreads();
         const uint32_t packed = packed_of[c];
         if (packed) {
             const uint32_t x0 = packed & 0xFFu, w = (packed >> 8) & 0xFFu, y0 = (packed >> 16) & 0xFFu, h = packed >> 24;
-            atomicAdd(&lds_hx[x0], h);
-            atomicSub(&lds_hx[x0 + w], h);
-            atomicAdd(&lds_hy[y0], w);
-            atomicSub(&lds_hy[y0 + h], w);
-        }
-        __syncthreads();
-        uint32_t ix = scans ? lds_hx[threadIdx.x] : 0u, iy = scans ? lds_hy[threadIdx.x] : 0u;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t ox = __shfl_up(ix, off, kWave), oy = __shfl_up(iy, off, kWave);
-            if (lane >= off) { ix += ox; iy += oy; }
-        }
-        if (scans && lane == kWave - 1) { s_ws[0][wave] = ix; s_ws[1][wave] = iy; }
-        __syncthreads();
-        if (scans) {
-            for (int ww = 0; ww < wave; ++ww) { ix += s_ws[0][ww]; iy += s_ws[1][ww]; }
-            // one table row per chunk: [keys per tile column | keys per tile row]. The row counts are summed
-            // down the chunks by the column scan below (its totals are the digit histogram of the tile-row
-            // pass); adding them with global atomics instead would serialise every chunk on the same words.
-            uint32_t* row = table + (size_t)chunk * (stride_x + stride_y);
-            if ((int)threadIdx.x < stride_x) row[threadIdx.x] = ix;
-            if ((int)threadIdx.x < stride_y) row[stride_x + threadIdx.x] = iy;
+            atomicAdd(&lds_h[c][0][x0], h);
+            atomicSub(&lds_h[c][0][x0 + w], h);
+            atomicAdd(&lds_h[c][1][y0], w);
+            atomicSub(&lds_h[c][1][y0 + h], w);
         }
     }
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int c = wave >> 1, a = wave & 1;
+    uint4 v = *reinterpret_cast<const uint4*>(&lds_h[c][a][4 * lane]);
+    v.y += v.x; v.z += v.y; v.w += v.z;
+    uint32_t incl = v.w;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t below = incl - v.w;
+    v.x += below; v.y += below; v.z += below; v.w += below;
+    // one table row per chunk: [keys per tile column | keys per tile row]. The row counts are summed down the chunks by the
+    // column scan below (its totals are the digit histogram of the tile-row pass); adding them with global atomics
+    // instead would serialise every chunk on the same words.
+    const uint32_t chunk = blockIdx.x * kCountChunks + (uint32_t)c;
+    if (chunk < chunks && 4 * lane < (a ? stride_y : stride_x))
+        *reinterpret_cast<uint4*>(table + (size_t)chunk * (stride_x + stride_y) + (a ? stride_x : 0) + 4 * lane) = v;
 }
 
 // ---- exclusive prefix of table[row][x] down the rows, for every column x ---------------------

@@ -30,6 +30,9 @@ constexpr int kWaves = kThreads / kWave;
 #ifndef GSR_SORT_ITEMS
 #define GSR_SORT_ITEMS 16
 #endif
+#ifndef GSR_SORT_WAVES
+#define GSR_SORT_WAVES 4                                // waves per SIMD the pass kernels are compiled for (two workgroups per CU)
+#endif
 constexpr int kItems = GSR_SORT_ITEMS;                  // keys per lane (measured: 8192-key tiles beat 4096 and 2048)
 constexpr int kSortTile = kThreads * kItems;            // keys per workgroup
 constexpr int kWaveSpan = kWave * kItems;
@@ -197,7 +200,7 @@ struct DropSpec {
     DepthSide side;
 };
 template <typename KeyT, int BITS, bool SECOND, bool DROP = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_SORT_WAVES))) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             const uint32_t* __restrict__ vals2_in, uint32_t* __restrict__ vals2_out,
                                                             uint32_t n_host, const uint32_t* __restrict__ n_dev, const DigitSpec spec,
