@@ -615,7 +615,7 @@ int gsr_forward(gsr_forward_args* a) {
         hist->cur ^= 1;
     }
     // geomState.rgb (GSCuda.cu:362-366) is a strided read nothing needs before the blend: by default it is written by a kernel
-    // of its own on the second stream while the depth sort runs (launch_colors_visible, preprocess.hip). Whatever way the
+    // of its own on the second stream while the scan and the depth sort run (launch_colors_visible, preprocess.hip). Whatever way the
     // call ends, the caller's stream has waited for it (the chunk is the caller's).
     // Up to 16 M Gaussians beside the depth sort: there its kernels wait on latency and the colours cost them 0.05 ms for the
     // 0.10 ms the preprocess saves — bench frame 1.315 -> 1.268 ms. At 50 M they are bound by HBM themselves and lose what
@@ -653,6 +653,19 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave,
                                    colors_mode != 0));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
+    if (colors_beside) {
+        // Forked right behind the preprocess (tilesTouched is final there): the scan's and the compaction's small launches
+        // leave most of the chip idle, and what the colours kernel gets done beside them it does not take from the depth passes
+        // (forked behind the read-back's event instead — no event of its own on the caller's stream — the three passes took
+        // 151 us for their 108: bench frame 1.215 -> 1.205 ms, from outside the cloud 1.52 -> 1.49, (0,0,-30) 1.42 -> 1.39).
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_pre_blend, stream));
+        GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_pre_blend, 0));
+        colors_join.tail = true;
+        GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
+        GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
+        colors_join.pending = g_rb.ev_colors;
+        colors_join.tail = false;
+    }
     GSR_BEGIN(GSR_STAGE_SCAN);
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
     // Its first launch also clears the depth order's four scratch areas (look-back words, tickets, the digit histograms:
@@ -704,15 +717,6 @@ int gsr_forward(gsr_forward_args* a) {
     // (no copy command: the kernels that computed the three figures wrote them into the pinned words as well; numRendered
     // is the low word of the un-wrapped instance count)
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
-    if (colors_beside) {
-        // (behind the read-back's event: tilesTouched is final there, and nothing is added to the caller's stream)
-        GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_r, 0));
-        colors_join.tail = true;
-        GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
-        GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
-        colors_join.pending = g_rb.ev_colors;
-        colors_join.tail = false;
-    }
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
     if (fused_depth)

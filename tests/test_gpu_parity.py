@@ -139,6 +139,28 @@ def test_trained_like_scene_against_oracle(eye):
     _compare_all(r, img, exp, 60_000)
 
 
+@pytest.mark.parametrize("scale,big_every", [(0.008, 0), (0.012, 0), (0.012, 700), (0.015, 0), (0.035, 0)])
+def test_chunks_around_the_sort_plans_placement_limits(scale, big_every):
+    """emit_chunk_kernel (sort plan) writes a chunk of 512 depth-consecutive Gaussians one of two ways: up to 2048 keys, none
+    of its Gaussians with more than 32, every Gaussian places its own keys; otherwise every key looks for its Gaussian. Isotropic
+    splats of a size that puts the chunks' key counts on either side of 2048 (a frame's chunks differ: near ones are
+    heavier), with and without a splat of hundreds of tiles in some chunks — lists against the oracle bit for bit."""
+    from gsrast_amd import camera, scenes
+    from oracle import cpu_oracle
+    n = 12_000
+    scene = scenes.isotropic_scene(n, seed=51)
+    scene["scales"][:, :3] = scale
+    if big_every:
+        scene["scales"][::big_every, :3] = 0.6
+    cam = camera.default_camera(640, 368, near=0.05, far=50.0, position=(0.0, 0.0, -3.0))
+    bg = (0.0, 0.1, 0.0)
+    exp = cpu_oracle.forward(scene, cam, bg, threads=8)
+    tt = exp["tilesTouched"]
+    assert exp["num_rendered"] > 2 * int((tt > 0).sum())
+    r, img = _run(scene, cam, bg)
+    _compare_all(r, img, exp, n)
+
+
 def test_a_few_huge_splats_send_a_frame_of_small_ones_to_the_block_plan():
     """The plan follows the instances per visible Gaussian — of the splats that are small: with an eighth of the frame's
     instances in splats of 256 tiles and more (the scan counts them) the block plan is taken whatever the average
