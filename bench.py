@@ -279,6 +279,21 @@ class Runner:
 
     def measure(self, cam, steps, warmup, **kw):
         rast, exch = self.rast, self.exch
+
+        def counted_frame():
+            # (one untimed frame with GSR_FLAG_COUNT_STAGED and the reads of the frame's figures)
+            rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None, **kw)
+            o = {"plan": rast.last_plan, "lists_written": rast.last_lists_written, "blend_from_lists": rast.last_blend_from_lists,
+                 "records_staged": rast.last_records_staged, "num_rendered": rast.last_num_rendered}
+            geo = rast.map_geometry_state()
+            o["visible_band"] = int((geo["tilesTouched"] != 0).sum().item())
+            o["visible"] = int((geo["radii"] > 0).sum().item())
+            return o
+
+        # Single GPU: the frame's figures are read BEFORE the warm-up steps, so that those run straight into the timed ones
+        # (the chip's clocks take ~10 frames to come back after a few milliseconds of idling: scripts/tmp/per_step.py). Sharded:
+        # after them — the warm-up is what settles the bands the figures describe.
+        out = counted_frame() if not exch else None
         for w in range(warmup):                     # warm-up (also converges the row-band balance when sharded)
             self.step(cam, **kw)
             if exch and not self.args.no_rebalance and w < warmup - 1:
@@ -288,13 +303,8 @@ class Runner:
                 mine = np.zeros(self.grid_y)
                 mine[b0:b1] = per_tile[b0:b1]
                 exch.rebalance(mine, floor_cost=0.02 * float(per_tile[b0:b1].mean() if b1 > b0 else 0.0) + 1.0)
-        rast.draw(cam, count_staged=True, tile_rows=exch.my_tile_rows() if exch else None, **kw)
-        out = {"plan": rast.last_plan, "lists_written": rast.last_lists_written, "blend_from_lists": rast.last_blend_from_lists,
-               "records_staged": rast.last_records_staged,
-               "num_rendered": rast.last_num_rendered}
-        geo = rast.map_geometry_state()
-        out["visible_band"] = int((geo["tilesTouched"] != 0).sum().item())
-        out["visible"] = int((geo["radii"] > 0).sum().item())
+        if out is None:
+            out = counted_frame()
         self.sync_all()
         t0 = time.perf_counter()
         stamps = [t0]
