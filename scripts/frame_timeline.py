@@ -19,7 +19,7 @@ fr = frames[len(frames) // 2]
 t0 = int(fr[0]["Start_Timestamp"])
 queues = {}
 print("# One frame of the traced bench command (rocprofv3 --kernel-trace): start and duration of every kernel in microseconds.")
-print("# Queue 1 = the caller's stream, queue 2 = the library's second stream: the colours beside the depth sort, the tile order")
+print("# Queue 1 = the caller's stream, queue 2 = the library's second stream: the colours forked behind the preprocess, the tile order")
 print("# behind them, the blend beside the emission.")
 for r in fr:
     q = queues.setdefault(r["Queue_Id"], len(queues) + 1)
