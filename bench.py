@@ -51,6 +51,10 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=30)
     p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--spinup", type=int, default=16,
+                   help="untimed frames rendered before anything is measured (before the W warm-up steps): the chip's clocks take "
+                        "about ten frames to come back after the idle milliseconds of allocation and set-up (scripts/clock_ramp.py, "
+                        "profiles/r05_clock_ramp.txt); reported as config.spinup_frames; 0 = none")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--splats", type=int, default=DEFAULT_SPLATS)
@@ -290,9 +294,13 @@ class Runner:
             o["visible"] = int((geo["radii"] > 0).sum().item())
             return o
 
-        # Single GPU: the frame's figures are read BEFORE the warm-up steps, so that those run straight into the timed ones
-        # (the chip's clocks take ~10 frames to come back after a few milliseconds of idling: scripts/tmp/per_step.py). Sharded:
-        # after them — the warm-up is what settles the bands the figures describe.
+        # The chip's clocks take about ten frames (12 ms) to come back after a few milliseconds of idling — allocations, the
+        # scene's upload, a host-side read — whatever the library does (profiles/r05_clock_ramp.txt): `spinup` untimed frames
+        # bring them up before anything is measured (config.spinup_frames says how many), and on a single GPU the frame's
+        # figures are read BEFORE the W warm-up steps, so that those run straight into the K timed ones. Sharded: after
+        # them — the warm-up is what settles the bands the figures describe.
+        for _ in range(max(0, int(getattr(self.args, "spinup", 0)))):
+            self.step(cam, **kw)
         out = counted_frame() if not exch else None
         for w in range(warmup):                     # warm-up (also converges the row-band balance when sharded)
             self.step(cam, **kw)
@@ -755,7 +763,7 @@ def main() -> int:
                                          if distributed else None),
                        "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "slow_tiles_first": m.get("tiles_reordered", False), "emit_overlapped": m.get("emit_overlapped", False),
-                       "colors_beside_depth_sort": m.get("colors_beside", False),
+                       "colors_beside_depth_sort": m.get("colors_beside", False), "spinup_frames": max(0, int(args.spinup)),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists"

@@ -131,7 +131,7 @@ def main():
     if os.path.exists(f"{SRC}/band_projection.json"):
         shutil.copy(f"{SRC}/band_projection.json", f"{DST}/band_projection.json")
     for txt in ("band_timings", "band_timings_4k", "parity", "soak", "history_similarity", "soak_trained_like", "micro_gather_dc",
-                "micro_scatter_records", "micro_xcd_placement"):
+                "micro_scatter_records", "micro_xcd_placement", "micro_event_gap", "clock_ramp"):
         if os.path.exists(f"{SRC}/{txt}.txt"):
             shutil.copy(f"{SRC}/{txt}.txt", f"{DST}/{ROUND}_{txt}.txt")
     thr = sorted(glob.glob(f"{SRC}/thresholds_*.txt"))

@@ -89,5 +89,7 @@ if [ "$PART" = "e" ]; then
   ./scripts/micro/gather_dc > $OUT/micro_gather_dc.txt 2>&1
   ./scripts/micro/scatter_records > $OUT/micro_scatter_records.txt 2>&1
   ./scripts/micro/xcd_placement > $OUT/micro_xcd_placement.txt 2>&1
+  ./scripts/micro/event_gap > $OUT/micro_event_gap.txt 2>&1
+  python3 scripts/clock_ramp.py 2>/dev/null > $OUT/clock_ramp.txt
 fi
 ls -la $OUT | head -80
