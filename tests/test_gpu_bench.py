@@ -38,6 +38,9 @@ def test_single_gpu_line_has_the_contract_keys():
         assert k in r, k
     assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "workload" in j["config"] and j["config"]["frame_alg_gbs"] > 0
+    assert j["config"]["spinup_frames"] == 16            # (untimed frames in front of the warm-up steps are said in the line)
+    j0 = _run_bench({}, "--spinup", "0", "--no-extras")
+    assert j0["config"]["spinup_frames"] == 0 and j0["steps"] == 3 and j0["warmup"] == 2
 
 
 def test_sharded_path_forced_onto_one_rank():
