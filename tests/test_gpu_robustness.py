@@ -416,3 +416,60 @@ def test_the_librarys_rccl_communicator_comes_up_on_one_rank():
     assert torch.equal(dst, src)
     assert L.gsr_exchange_loopback(handle, None, dst.data_ptr(), 16, 1, None) == _capi.GSR_ERR_INVALID_ARG
     assert L.gsr_exchange_destroy(handle) == _capi.GSR_OK
+
+
+def test_two_host_threads_render_at_the_same_time():
+    """Two host threads, a rasterizer and a stream each, no synchronisation between them (a viewer with two frames in flight; the
+    library's pinned words, events, second stream and default tile histories are per host thread and device): every frame of
+    either thread — image, finalT, nContrib, the sorted lists' checksum — is bit for bit the frame the same rasterizer renders
+    alone."""
+    import threading
+    import torch
+    from gsrast_amd import camera, scenes
+    W, H = 640, 368
+    scene = scenes.garden_like_scene(150_000, seed=77)
+    scene["means3D"][:, :3] *= 0.5
+    poses = [[(0.0, 0.0, -3.0 - 0.15 * i) for i in range(12)], [(0.3, -0.2, -5.0 + 0.1 * i) for i in range(12)]]
+    rasts = [_rast(W, H), _rast(W, H)]
+    for r in rasts:
+        r.configure_from_scene(scene)
+
+    def frame_state(r):
+        st = r.map_image_state()
+        b = r.map_binning_state()
+        return (r.out_color.clone(), st["finalT"].clone(), st["nContrib"].clone(), int(r.last_num_rendered),
+                int(b["keys"].view(torch.int64).sum().item()), int(b["values"].to(torch.int64).sum().item()))
+
+    alone = [[], []]
+    for t in range(2):
+        for p in poses[t]:
+            rasts[t].draw(camera.default_camera(W, H, near=0.05, far=60.0, position=p), tile_history="default")
+            alone[t].append(frame_state(rasts[t]))
+    together, errors = [[], []], []
+
+    def work(t):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for rep in range(3):
+                    got = []
+                    for p in poses[t]:
+                        rasts[t].draw(camera.default_camera(W, H, near=0.05, far=60.0, position=p), tile_history="default")
+                        got.append(frame_state(rasts[t]))
+                    together[t] = got
+        except Exception as e:                              # noqa: BLE001 (reported by the main thread)
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(2):
+        assert len(together[t]) == len(alone[t])
+        for i, (g, e) in enumerate(zip(together[t], alone[t])):
+            assert g[3:] == e[3:], (t, i, g[3:], e[3:])
+            for a, b in zip(g[:3], e[:3]):
+                assert torch.equal(a, b), (t, i)
