@@ -51,7 +51,7 @@ struct GeoScratch {
     uint32_t* vis_partial;    // per 4096-key chunk: visible keys before it (compaction)
     uint32_t* main_partial;   // the same for the keys with the main top byte only (the depth order's side way, radix_sort.hip)
     uint32_t* big_partial;    // per 4096 Gaussians: the instances of those that touch kBigSplatTiles tiles or more
-    uint32_t* others_per_wave;  // per 64 Gaussians: visible ones with another top byte (written by the preprocess, summed by the scan)
+    uint4* wave_sums;         // per 64 Gaussians: {tilesTouched summed, with a tile, instances of the big ones, with another top byte} (written by the preprocess, summed by the scan)
     uint32_t *side_k, *side_v, *side_r;   // the side list (kDepthSideMax entries); its words: sort_info[8..10]
     uint32_t *c_k, *c_v;      // the visible (depth key, index) pairs in index order: the sort's input
     uint32_t *a_k, *a_v;      // depth-sort ping (three passes end here; kDepthSideMax elements of room in front of each a_*)
@@ -73,7 +73,7 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.vis_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
     g.main_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
     g.big_partial = reinterpret_cast<uint32_t*>(base + off); off += depth_compact_scratch_bytes(n);
-    g.others_per_wave = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * ((n + 63) / 64));
+    g.wave_sums = reinterpret_cast<uint4*>(base + off); off += align128(16 * ((n + 63) / 64));
     g.side_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
     g.side_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
     g.side_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
@@ -648,10 +648,10 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_BEGIN(GSR_STAGE_PREPROCESS);
     const bool xy_plan = d.grid_x <= 255 && d.grid_y <= 255;
     if (inria)
-        GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave));
+        GSR_STEP(launch_preprocess_inria(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.wave_sums, kBigSplatTiles));
     else
-        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.others_per_wave,
-                                   colors_mode != 0));   // :744-768
+        GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.wave_sums,
+                                   colors_mode != 0, kBigSplatTiles));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
     if (colors_beside) {
         // Forked right behind the preprocess (tilesTouched is final there): the scan's and the compaction's small launches
@@ -675,7 +675,7 @@ int gsr_forward(gsr_forward_args* a) {
                                    gs.scan_temp, stream, reinterpret_cast<unsigned long long*>(gs.sort_info + 2),
                                    gs.vis_partial, gs.sort_info + 1, g_rb.host_dev + 4,
                                    gs.sweep.ticket, 4 * sweep_scratch_bytes((size_t)n),
-                                   gs.others_per_wave, gs.main_partial, kDepthSideMax, gs.sort_info + 8,
+                                   gs.wave_sums, gs.main_partial, kDepthSideMax, gs.sort_info + 8,
                                    gs.big_partial, kBigSplatTiles));
     GSR_END(GSR_STAGE_SCAN);
     // The sort of reference :794-797 is an LSD radix sort of (tile | depth) keys. Its low

@@ -34,6 +34,29 @@ int record_error(int code);
         }                                                   \
     } while (0)
 
+// What the scan wants to know of a preprocess wave's 64 Gaussians, left as ONE 16-byte record per wave so that its first
+// launch reads 0.25 bytes per Gaussian instead of re-reading tilesTouched (50 M Gaussians: 80 -> 13 us): {sum of tilesTouched,
+// Gaussians with a tile, the instances of those of big_from tiles and more, those with a tile whose depth key has another
+// top byte than the main one}. Lanes past the last Gaussian have left the kernel: the last wave sums by readlane.
+__device__ __forceinline__ void store_wave_sums(uint4* __restrict__ wave_sums, int idx, uint32_t tiles, bool other_top, uint32_t big_from) {
+    const unsigned long long active = __ballot(true);
+    const uint32_t z = (uint32_t)__popcll(__ballot(tiles != 0u)), o = (uint32_t)__popcll(__ballot(tiles != 0u && other_top));
+    uint32_t s = tiles, b = tiles >= big_from ? tiles : 0u;
+    if (active == ~0ull) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); b += __shfl_xor(b, off, 64); }
+    } else {
+        uint32_t ss = 0, bb = 0;
+        for (unsigned long long m = active; m != 0ull; m &= m - 1ull) {
+            const int l = __ffsll((long long)m) - 1;
+            ss += (uint32_t)__builtin_amdgcn_readlane((int)s, l);
+            bb += (uint32_t)__builtin_amdgcn_readlane((int)b, l);
+        }
+        s = ss; b = bb;
+    }
+    if ((threadIdx.x & 63) == 0) wave_sums[idx >> 6] = make_uint4(s, z, b, o);
+}
+
 struct FrameDims {
     int width, height;
     int grid_x, grid_y;            // tile grid of the whole image
@@ -43,24 +66,26 @@ struct FrameDims {
 // ---- stage launchers (each asynchronous on `stream`) ----
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
                       uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream,
-                      uint32_t* others_per_wave = nullptr, bool colors_elsewhere = false);
+                      uint4* wave_sums = nullptr, bool colors_elsewhere = false, uint32_t big_from = 0xFFFFFFFFu);   // wave_sums: store_wave_sums
 // geomState.rgb for the Gaussians with a tile (zeros for the others), as preprocess_kernel writes it — for a second stream
 int launch_colors_visible(int n, const uint32_t* tiles_touched, const float* shs, float* rgb, hipStream_t stream);
 
 int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t stream);
 
 int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
-                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint32_t* others_per_wave = nullptr);
+                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint4* wave_sums = nullptr,
+                            uint32_t big_from = 0xFFFFFFFFu);
 
 // nonzero (u32 per 4096 elements) / nonzero_total: optional — exclusive prefix of the per-tile counts of non-zero
 // elements and their total (the depth order's compaction offsets, radix_sort.hip)
 // host_words (mapped host memory, optional; needs total64): [0] = the non-zero total, [2..3] = the 64-bit total, written by the
 // scan itself. clear / clear_bytes (optional, 16-byte granules): device memory the first launch also zeroes.
-// others_per_wave / main_count / side_max / side_words (all or none; need nonzero): the depth order's side list, see scan.hip.
+// wave_sums / main_count / side_max / side_words (all or none; need nonzero and big): the preprocess's per-wave records
+// (store_wave_sums) — the first launch then reads those instead of `in` — and the depth order's side list, see scan.hip.
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
                           unsigned long long* total64 = nullptr, uint32_t* nonzero = nullptr, uint32_t* nonzero_total = nullptr,
                           uint32_t* host_words = nullptr, void* clear = nullptr, size_t clear_bytes = 0,
-                          const uint32_t* others_per_wave = nullptr, uint32_t* main_count = nullptr,
+                          const uint4* wave_sums = nullptr, uint32_t* main_count = nullptr,
                           uint32_t side_max = 0, uint32_t* side_words = nullptr,
                           uint32_t* big = nullptr, uint32_t big_from = 0);     // big (u32 per 4096 elements, needs host_words): host_words[10..11] = the 64-bit sum of the elements >= big_from
 size_t scan_temp_bytes(size_t n);

@@ -80,7 +80,8 @@ struct PreprocessParams {
     uint32_t* tiles_touched;
     uint32_t* depth_keys;          // depth bits of Gaussians with >= 1 tile in this call, else ~0
     uint32_t* rect_packed;         // x0 | w << 8 | y0 << 16 | h << 24 of the band-clipped rectangle (grids <= 255), else 0
-    uint32_t* others_per_wave;     // per 64 Gaussians: those with a tile whose depth key has another top byte than kDepthMainTop (may be null)
+    uint4* wave_sums;              // per 64 Gaussians: what the scan wants to know of them (store_wave_sums; may be null)
+    uint32_t big_from;
     int2* rects;
     FrameDims dims;
 };
@@ -266,8 +267,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     p.depth_keys[idx] = dkey;
     if (p.rect_packed) p.rect_packed[idx] = out_rect;
     // (the depth order's side way, radix_sort.hip: the scan wants to know how many visible keys are not "main" keys)
-    const unsigned long long others = __ballot(out_tiles != 0u && (dkey >> 24) != kDepthMainTop);
-    if (p.others_per_wave && (threadIdx.x & (kWave - 1)) == 0) p.others_per_wave[idx >> 6] = (uint32_t)__popcll(others);
+    if (p.wave_sums) store_wave_sums(p.wave_sums, idx, out_tiles, (dkey >> 24) != kDepthMainTop, p.big_from);
 }
 
 // colour = 0.5 + 0.4 DC (GSCuda.cu:362-366), the same two float32 operations as the preprocess kernel above (this file
@@ -317,8 +317,8 @@ int launch_colors_from_dc(int n, const float* shs, float* colors, hipStream_t st
 }
 
 int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii,
-                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint32_t* others_per_wave,
-                      bool colors_elsewhere) {
+                      uint32_t* depth_keys, uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint4* wave_sums,
+                      bool colors_elsewhere, uint32_t big_from) {
     PreprocessParams p;
     p.skip_colors = a.colors_precomp != nullptr || colors_elsewhere;
     p.n = a.num_gaussians;
@@ -344,7 +344,8 @@ int launch_preprocess(const gsr_forward_args& a, const gsr_geometry_state& g, in
     p.tiles_touched = g.tiles_touched;
     p.depth_keys = depth_keys;
     p.rect_packed = rect_packed;
-    p.others_per_wave = others_per_wave;
+    p.wave_sums = wave_sums;
+    p.big_from = big_from;
     p.rects = reinterpret_cast<int2*>(a.rects);
     p.dims = d;
     const unsigned blocks = (unsigned)((a.num_gaussians + 255) / 256);

@@ -72,7 +72,8 @@ struct InriaParams {
     uint32_t* tiles_touched;
     uint32_t* depth_keys;
     uint32_t* rect_packed;
-    uint32_t* others_per_wave;     // (as in preprocess.hip)
+    uint4* wave_sums;              // (as in preprocess.hip)
+    uint32_t big_from;
     FrameDims dims;
 };
 
@@ -271,14 +272,13 @@ __global__ __launch_bounds__(256) void preprocess_inria_kernel(const InriaParams
     const uint32_t dkey = out_tiles ? __float_as_uint(view_z) : 0xFFFFFFFFu;
     p.depth_keys[idx] = dkey;
     if (p.rect_packed) p.rect_packed[idx] = out_rect;
-    const unsigned long long others = __ballot(out_tiles != 0u && (dkey >> 24) != kDepthMainTop);
-    if (p.others_per_wave && (threadIdx.x & (kWave - 1)) == 0) p.others_per_wave[idx >> 6] = (uint32_t)__popcll(others);
+    if (p.wave_sums) store_wave_sums(p.wave_sums, idx, out_tiles, (dkey >> 24) != kDepthMainTop, p.big_from);
 }
 
 }  // namespace
 
 int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state& g, int32_t* radii, uint32_t* depth_keys,
-                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint32_t* others_per_wave) {
+                            uint32_t* rect_packed, const FrameDims& d, hipStream_t stream, uint4* wave_sums, uint32_t big_from) {
     InriaParams p;
     p.n = a.num_gaussians;
     p.deg = a.sh_dims < 0 ? 0 : (a.sh_dims > 3 ? 3 : a.sh_dims);
@@ -307,7 +307,8 @@ int launch_preprocess_inria(const gsr_forward_args& a, const gsr_geometry_state&
     p.tiles_touched = g.tiles_touched;
     p.depth_keys = depth_keys;
     p.rect_packed = rect_packed;
-    p.others_per_wave = others_per_wave;
+    p.wave_sums = wave_sums;
+    p.big_from = big_from;
     p.dims = d;
     hipLaunchKernelGGL(preprocess_inria_kernel, dim3((unsigned)((a.num_gaussians + 255) / 256)), dim3(256), 0, stream, p);
     GSR_LAUNCH_CHECK("preprocess_inria_kernel");

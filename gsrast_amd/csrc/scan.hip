@@ -72,32 +72,21 @@ __device__ __forceinline__ void load_items(const uint32_t* in, size_t n, size_t 
 // clear / clear_vecs (may be null / 0): 16-byte words this launch also zeroes, a slice per thread — gsr_forward's depth
 // order wants its look-back words cleared before its first pass, and a memset of its own is one more 5 us stop on a chain
 // of small launches.
-// others_per_wave / main_count (both or none): others_per_wave[i] = how many of elements [64 i, 64 i + 64) are non-zero but
-// NOT "main" (the depth order's keys with another top byte than the main one: the preprocess kernels count them, a word per
-// wave of theirs); main_count[tile] = the tile's non-zero elements minus those.
 __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                     uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero,
                                                                     uint4* __restrict__ clear, size_t clear_vecs,
-                                                                    const uint32_t* __restrict__ others_per_wave,
-                                                                    uint32_t* __restrict__ main_count,
                                                                     uint32_t* __restrict__ big, uint32_t big_from) {
     __shared__ uint32_t wave_sums[kScanThreads / kWave], wave_nz[kScanThreads / kWave], wave_big[kScanThreads / kWave];
     for (size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x; i < clear_vecs; i += (size_t)gridDim.x * kScanThreads)
         clear[i] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t v[kScanItems];
     load_items(in, n, blockIdx.x, v);
-    uint32_t others = 0;
-    if (others_per_wave && threadIdx.x < kScanTile / kWave) {          // (the first wave: kScanTile / 64 = 64 words per tile)
-        const size_t w = (size_t)blockIdx.x * (kScanTile / kWave) + threadIdx.x;
-        others = (w * kWave < n) ? others_per_wave[w] : 0u;
-    }
     uint32_t s = 0, z = 0, b = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) { s += v[k]; z += v[k] != 0u ? 1u : 0u; b += v[k] >= big_from ? v[k] : 0u; }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
-        s += __shfl_down(s, off, kWave); z += __shfl_down(z, off, kWave); others += __shfl_down(others, off, kWave);
-        b += __shfl_down(b, off, kWave);
+        s += __shfl_down(s, off, kWave); z += __shfl_down(z, off, kWave); b += __shfl_down(b, off, kWave);
     }
     if ((threadIdx.x & (kWave - 1)) == 0) { wave_sums[threadIdx.x / kWave] = s; wave_nz[threadIdx.x / kWave] = z; wave_big[threadIdx.x / kWave] = b; }
     __syncthreads();
@@ -108,7 +97,32 @@ __global__ __launch_bounds__(kScanThreads) void tile_reduce_kernel(const uint32_
         partial[blockIdx.x] = t;
         if (big) big[blockIdx.x] = tb;
         if (nonzero) nonzero[blockIdx.x] = tz;
-        if (main_count) main_count[blockIdx.x] = tz - others;             // (thread 0 holds the first wave's sum)
+    }
+}
+
+// The same from the preprocess's per-wave records (store_wave_sums, gsr_common.hpp: {sum, non-zero, big, others} per 64
+// elements): a wave per tile — its 64 records, one per lane —, four tiles a workgroup; `in` is not read again.
+__global__ __launch_bounds__(kScanThreads) void wave_sums_reduce_kernel(const uint4* __restrict__ wave_sums, size_t waves, size_t tiles,
+                                                                         uint32_t* __restrict__ partial, uint32_t* __restrict__ nonzero,
+                                                                         uint4* __restrict__ clear, size_t clear_vecs,
+                                                                         uint32_t* __restrict__ main_count, uint32_t* __restrict__ big) {
+    for (size_t i = (size_t)blockIdx.x * kScanThreads + threadIdx.x; i < clear_vecs; i += (size_t)gridDim.x * kScanThreads)
+        clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t tile = (size_t)blockIdx.x * (kScanThreads / kWave) + threadIdx.x / kWave;
+    if (tile >= tiles) return;                               // (whole waves)
+    const size_t w = tile * (kScanTile / kWave) + (size_t)lane;
+    uint4 v = w < waves ? wave_sums[w] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        v.x += __shfl_down(v.x, off, kWave); v.y += __shfl_down(v.y, off, kWave);
+        v.z += __shfl_down(v.z, off, kWave); v.w += __shfl_down(v.w, off, kWave);
+    }
+    if (lane == 0) {
+        partial[tile] = v.x;
+        nonzero[tile] = v.y;
+        big[tile] = v.z;
+        main_count[tile] = v.y - v.w;
     }
 }
 
@@ -255,17 +269,26 @@ size_t scan_temp_bytes(size_t n) {
 
 int launch_inclusive_scan(const uint32_t* in, uint32_t* out, size_t n, char* temp, hipStream_t stream,
                           unsigned long long* total64, uint32_t* nonzero, uint32_t* nonzero_total, uint32_t* host_words,
-                          void* clear, size_t clear_bytes, const uint32_t* others_per_wave, uint32_t* main_count,
+                          void* clear, size_t clear_bytes, const uint4* wave_sums, uint32_t* main_count,
                           uint32_t side_max, uint32_t* side_words, uint32_t* big, uint32_t big_from) {
     if (n == 0) return GSR_OK;
     const size_t tiles = (n + kScanTile - 1) / kScanTile;
     uint32_t* partial = reinterpret_cast<uint32_t*>(temp);
     if (clear_bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(clear) & 15) != 0 || (host_words && !total64)) return GSR_ERR_INVALID_ARG;
-    if ((others_per_wave != nullptr) != (main_count != nullptr) || (main_count && (!nonzero || !side_words))) return GSR_ERR_INVALID_ARG;
+    if ((wave_sums != nullptr) != (main_count != nullptr) || (main_count && (!nonzero || !side_words || !big))) return GSR_ERR_INVALID_ARG;
     if (big && !host_words) return GSR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero,
-                       reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, others_per_wave, main_count, big, big_from);
-    GSR_LAUNCH_CHECK("tile_reduce_kernel");
+    if (wave_sums) {
+        // (the preprocess has left the sums of every 64 elements: big_from is the one IT was given)
+        constexpr unsigned kTilesPerGroup = kScanThreads / kWave;
+        hipLaunchKernelGGL(wave_sums_reduce_kernel, dim3((unsigned)((tiles + kTilesPerGroup - 1) / kTilesPerGroup)), dim3(kScanThreads), 0, stream,
+                           wave_sums, (n + kWave - 1) / kWave, tiles, partial, nonzero, reinterpret_cast<uint4*>(clear),
+                           clear ? clear_bytes / 16 : (size_t)0, main_count, big);
+        GSR_LAUNCH_CHECK("wave_sums_reduce_kernel");
+    } else {
+        hipLaunchKernelGGL(tile_reduce_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, n, partial, nonzero,
+                           reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : (size_t)0, big, big_from);
+        GSR_LAUNCH_CHECK("tile_reduce_kernel");
+    }
     hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(1024), 0, stream, partial, tiles, total64, nonzero, nonzero_total, host_words,
                        main_count, side_max, side_words, big);
     GSR_LAUNCH_CHECK("partial_scan_kernel");
