@@ -137,7 +137,8 @@ enum {
 #define GSR_FLAG_SERIAL_EMIT 0x100u
 /* (Also by default, gscuda semantics without colors_precomp: geomState.rgb is written by a kernel of its own on the
  * library's second stream — a strided read nothing needs before the blend, 0.10 ms of the bench frame's preprocess. Up to
- * 16 M Gaussians while the depth sort runs (0.05 ms more there), and the call's stream waits for it before the blend; beyond,
+ * 16 M Gaussians right behind the preprocess, while the scan and the depth sort run (0.02-0.03 ms more there), and the
+ * call's stream waits for it before the blend; beyond,
  * where the depth sort is bound by HBM itself, beside the blend, which takes a record's colour straight from `shs` meanwhile
  * (50 M Gaussians: 6.3 -> 5.9 ms). The caller's stream has waited for it on every way out of the call. Same bits.
  * GSR_FLAG_SERIAL_EMIT keeps the colours in the preprocess kernel as well.) */
@@ -177,7 +178,7 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
        GSR_PLAN_TILES_REORDERED = 0x400 /* or-ed in: the blend started the slow tiles of the call before first
                                            (see GSR_FLAG_NO_TILE_HISTORY; informational) */,
        GSR_PLAN_EMIT_OVERLAPPED = 0x800 /* or-ed in: the blend ran beside the emission (see GSR_FLAG_OVERLAP_EMIT) */,
-       GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the depth sort, not by the preprocess */,
+       GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the scan / depth sort (or the blend), not by the preprocess */,
        GSR_PLAN_TILE_ORDER_DROPPED = 0x2000 /* or-ed in: the history's last frames did not resemble each other (another view
                                                every call): the blend took the patch order (informational) */ };
 
