@@ -13,6 +13,14 @@ ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC, DST = f"gpurun_out/{ROUND}", "profiles"
 
 
+HEADERS = {
+    "clock_ramp": ("# python scripts/clock_ramp.py on one MI355X: per-call host times of the headline frame in ms (o = blend beside the emission, r = tiles reordered).\n"
+                   "# The first dozen frames after a few milliseconds of idling run on lower clocks, whatever the tile history (settled after two calls):\n"
+                   "# bench.py renders --spinup (16) untimed frames before its warm-up steps (config.spinup_frames).\n"),
+    "micro_event_gap": ("# scripts/micro/event_gap.hip on one MI355X: kernel A, [event], kernel B on one stream; a second stream waits for the event and runs kernel C\n"),
+}
+
+
 def bench_line(path):
     try:
         lines = [ln for ln in open(path) if ln.startswith('{"metric')]
@@ -133,7 +141,12 @@ def main():
     for txt in ("band_timings", "band_timings_4k", "parity", "soak", "history_similarity", "soak_trained_like", "micro_gather_dc",
                 "micro_scatter_records", "micro_xcd_placement", "micro_event_gap", "clock_ramp"):
         if os.path.exists(f"{SRC}/{txt}.txt"):
-            shutil.copy(f"{SRC}/{txt}.txt", f"{DST}/{ROUND}_{txt}.txt")
+            head = HEADERS.get(txt)
+            if head:
+                with open(f"{DST}/{ROUND}_{txt}.txt", "w") as o:
+                    o.write(head + open(f"{SRC}/{txt}.txt").read())
+            else:
+                shutil.copy(f"{SRC}/{txt}.txt", f"{DST}/{ROUND}_{txt}.txt")
     thr = sorted(glob.glob(f"{SRC}/thresholds_*.txt"))
     if thr:
         with open(f"{DST}/{ROUND}_trained_like.txt", "w") as o:
