@@ -299,7 +299,8 @@ class Runner:
         # bring them up before anything is measured (config.spinup_frames says how many), and on a single GPU the frame's
         # figures are read BEFORE the W warm-up steps, so that those run straight into the K timed ones. Sharded: after
         # them — the warm-up is what settles the bands the figures describe.
-        for _ in range(max(0, int(getattr(self.args, "spinup", 0)))):
+        spin = max(0, int(getattr(self.args, "spinup", 0)))
+        for _ in range(spin):
             self.step(cam, **kw)
         out = counted_frame() if not exch else None
         for w in range(warmup):                     # warm-up (also converges the row-band balance when sharded)
@@ -313,6 +314,7 @@ class Runner:
                 exch.rebalance(mine, floor_cost=0.02 * float(per_tile[b0:b1].mean() if b1 > b0 else 0.0) + 1.0)
         if out is None:
             out = counted_frame()
+        out["untimed_frames"] = spin + 1 + warmup
         self.sync_all()
         t0 = time.perf_counter()
         stamps = [t0]
@@ -744,6 +746,7 @@ def main() -> int:
             "unit": "Msplats/s",
             "fps": round(1e3 / ms_per_step, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_effective": m["untimed_frames"],      # spin-up + the counted frame + the W warm-up steps: every frame rendered before the timed region
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_step_median": round(m["ms_median"], 4), "ms_per_step_p99": round(m["ms_p99"], 4),   # (BASELINE.md section 2 defines the median)
             "higher_is_better": True,
@@ -751,19 +754,24 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "f32",
             "data": label.split(" ")[0] if label.startswith("ply:") else "synthetic",
-            "config": {"workload": f"{label}, {W}x{H} forward, camera at {tuple(round(v, 3) for v in pos)}"
+            # (the driver's record keeps the first 24 keys of `config`, flat scalars only: the measured figures come first —
+            # filled in below, in this order — and what describes the run without measuring anything is under "detail")
+            "config": {"workload": f"{label}, {W}x{H} forward, {args.semantics} semantics"
+                                   + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)")
+                                   + (", colours passed as colorsPrecomp" if args.colors_precomp else "")
+                                   + f", camera at {tuple(round(v, 3) for v in pos)}"
                                    + (" (the reference's default pose)" if not args.pose and args.scene != "stress" else ""),
-                       "width": W, "height": H, "splats": n_splats, "visible": m["visible"], "num_rendered": m["num_rendered_total"],
-                       "records_staged": m["records_staged_total"],
+                       "splats": n_splats, "num_rendered": m["num_rendered_total"], "records_staged": m["records_staged_total"],
+                       "binning_plan": m["plan"], "ms_median": round(m["ms_median"], 4), "ms_p99": round(m["ms_p99"], 4),
+                       "untimed_frames": m["untimed_frames"]},
+            "detail": {"width": W, "height": H, "visible": m["visible"],
                        "minstances_per_s": round(m["num_rendered_total"] / (ms_per_step * 1e-3) / 1e6, 2),
-                       "semantics": args.semantics + (f" (SH degree {args.sh_degree})" if inria else " (DC colour)")
-                                    + (", colours passed as colorsPrecomp" if args.colors_precomp else ""),
-                       "parallelism": f"tile-rows x{world}" if distributed else "single GPU", "rccl_ranks": world if distributed else 0,
-                       "band_exchange": ({"transport": run.exch.transport, "gather": args.gather, "note": run.exch.transport_note}
-                                         if distributed else None),
-                       "binning_plan": m["plan"], "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
+                       "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "slow_tiles_first": m.get("tiles_reordered", False), "emit_overlapped": m.get("emit_overlapped", False),
                        "colors_beside_depth_sort": m.get("colors_beside", False), "spinup_frames": max(0, int(args.spinup)),
+                       "deep_tiles": m.get("deep_tiles", 0),
+                       "band_exchange": ({"transport": run.exch.transport, "gather": args.gather, "note": run.exch.transport_note}
+                                         if distributed else None),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_meaning": ({"depth_order": "visible-key compaction + depth sort + block lists"
@@ -784,29 +792,42 @@ def main() -> int:
             "kernels": kernels,
         }
         # what the driver keeps of this line is its head: the representative frames and the whole-frame rate go into `config`
-        cfg = out["config"]
-        cfg["frame_alg_gbs"] = round(sum(v["alg_bytes"] for v in kernels.values()) / (ms_per_step * 1e-3) / 1e9, 1)   # all stages' algorithmic bytes / frame time
-        # (flat scalars only: the driver's record keeps nothing nested)
-        for key, name in (("pose_outside", "ms_pose_outside"), ("pose_far", "ms_pose_far"), ("blend_bound", "ms_faint"),
-                          ("no_sorted_lists", "ms_no_sorted_lists"), ("serial_emit", "ms_serial"), ("no_tile_history", "ms_no_tile_history"),
-                          ("colors_precomp", "ms_colors_precomp"), ("forward_backward", "ms_forward_backward"), ("config3_4k", "ms_config3_4k")):
+        # (flat scalars only; at most 24 keys: tests/test_gpu_bench.py)
+        cfg, detail = out["config"], out["detail"]
+        for key, name in (("no_sorted_lists", "ms_no_sorted_lists"), ("serial_emit", "ms_serial"), ("no_tile_history", "ms_no_tile_history"),
+                          ("blend_bound", "ms_faint"), ("pose_outside", "ms_pose_outside"), ("pose_far", "ms_pose_far"),
+                          ("forward_backward", "ms_forward_backward"), ("config3_4k", "ms_config3_4k")):
             if key in extras:
                 cfg[name] = extras[key]["ms_per_step"]
+        if "colors_precomp" in extras:
+            detail["ms_colors_precomp"] = extras["colors_precomp"]["ms_per_step"]
         if "path" in extras:
             pth, rv = extras["path"], extras["random_views"]
-            cfg.update({"path_ms_p50": pth["ms_p50"], "path_ms_p99": pth["ms_p99"], "path_ms_mean": pth["ms_mean"],
-                        "path_ms_nohist_p50": pth["nohist_ms_p50"], "path_ms_nohist_p99": pth["nohist_ms_p99"],
-                        "path_hist_over_nohist": pth["hist_over_nohist"], "randview_hist_over_nohist": rv["hist_over_nohist"],
-                        "path_plan_flips": pth["plan_flips"], "path_overlapped_frames": pth["overlapped_frames"],
-                        "path_order_dropped_frames": pth["order_dropped_frames"],
-                        "randview_ms": rv["ms_mean"], "randview_ms_nohist": rv["nohist_ms_mean"], "randview_ms_p50": rv["ms_p50"],
-                        "randview_ms_nohist_p50": rv["nohist_ms_p50"], "randview_order_dropped_frames": rv["order_dropped_frames"]})
+            cfg.update({"path_ms_p50": pth["ms_p50"], "path_ms_p99": pth["ms_p99"], "path_ms_nohist_p50": pth["nohist_ms_p50"],
+                        "randview_ms": rv["ms_mean"], "randview_ms_nohist": rv["nohist_ms_mean"]})
+            detail.update({"path_ms_mean": pth["ms_mean"], "path_ms_nohist_p99": pth["nohist_ms_p99"],
+                           "path_hist_over_nohist": pth["hist_over_nohist"], "randview_hist_over_nohist": rv["hist_over_nohist"],
+                           "path_plan_flips": pth["plan_flips"], "path_overlapped_frames": pth["overlapped_frames"],
+                           "path_order_dropped_frames": pth["order_dropped_frames"], "randview_ms_p50": rv["ms_p50"],
+                           "randview_ms_nohist_p50": rv["nohist_ms_p50"], "randview_order_dropped_frames": rv["order_dropped_frames"]})
+        cfg["frame_alg_gbs"] = round(sum(v["alg_bytes"] for v in kernels.values()) / (ms_per_step * 1e-3) / 1e9, 1)   # all stages' algorithmic bytes / frame time
+        if "valu_frac" in rb:
+            cfg["blend_valu_frac"] = rb["valu_frac"]
+        cfg["parallelism"] = f"tile-rows x{world}" if distributed else "single GPU"
+        cfg["rccl_ranks"] = world if distributed else 0
+        if distributed:
+            # (sharded runs measure few of the frames above: room for what tells an imbalance from a slow transport, as strings)
+            cfg["bands"] = ",".join(f"{a}-{b}" for a, b in zip(m["bands"][:-1], m["bands"][1:])) if m["bands"] else ""
+            cfg["per_rank_render_ms"] = ",".join(str(r["render_ms"]) for r in (m["per_rank"] or []))
+            cfg["per_rank_exchange_ms"] = ",".join(str(r["exchange_ms"]) for r in (m["per_rank"] or []))
+            cfg["band_exchange"] = run.exch.transport
         if distributed:
             proj, src = load_profile_json("band_projection.json")
             key = f"{W}x{H}"
             if default_frame and key in proj and str(world) in proj[key].get("recut_ms", {}):
-                cfg["projected_ms"] = {"slowest_band_ms": proj[key]["recut_ms"][str(world)], "one_gpu_ms": proj[key]["recut_ms"].get("1"),
-                                       "source": f"{src}: one GPU rendering each band of the re-cut frame in turn; exchange not included"}
+                cfg["projected_ms"] = proj[key]["recut_ms"][str(world)]       # (the slowest band of the re-cut frame on one GPU; exchange not included)
+                detail["projected_ms"] = {"slowest_band_ms": proj[key]["recut_ms"][str(world)], "one_gpu_ms": proj[key]["recut_ms"].get("1"),
+                                          "source": f"{src}: one GPU rendering each band of the re-cut frame in turn; exchange not included"}
         elif default_frame and not args.no_extras:
             cpp = cpp_caller(cam, n_splats, 43, max(5, min(args.steps, 30)), 5)
             out["cpp_caller_ms"] = cpp.get("ms_per_step")

@@ -31,12 +31,15 @@ GSR_FLAG_OVERLAP_EMIT = 0x20
 GSR_FLAG_NO_SORTED_LISTS = 0x40
 GSR_FLAG_NO_TILE_HISTORY = 0x80
 GSR_FLAG_SERIAL_EMIT = 0x100
+GSR_FLAG_NO_DEEP_TILES = 0x200
+GSR_FLAG_DEEP_TILES_ALL = 0x400
 GSR_PLAN_LISTS_SKIPPED = 0x100
 GSR_PLAN_BLEND_FROM_LISTS = 0x200
 GSR_PLAN_TILES_REORDERED = 0x400
 GSR_PLAN_EMIT_OVERLAPPED = 0x800
 GSR_PLAN_COLORS_BESIDE = 0x1000
 GSR_PLAN_TILE_ORDER_DROPPED = 0x2000
+GSR_PLAN_DEEP_TILES = 0x4000
 GSR_SH_LAYOUT_FILE, GSR_SH_LAYOUT_COEFFICIENT_MAJOR = 0, 1
 PLAN_NAMES = {0: "none", 1: "sort", 2: "blocks", 3: "generic"}
 GSR_NUM_STAGES = 8
@@ -149,6 +152,9 @@ SIGNATURES = {
     "gsr_tile_history_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gsr_tile_history_destroy": (C.c_int, [C.c_void_p]),
     "gsr_tile_history_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "gsr_tile_history_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]),
+    "gsr_thread_release": (C.c_int, []),
+    "gsr_device_shape": (None, [C.c_int, C.POINTER(C.c_uint32)]),
     "gsr_higher_msb": (C.c_uint32, [C.c_uint32]),
     "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),
     "gsr_inclusive_scan_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -129,6 +129,7 @@ struct gsr_tile_history {
     int device = -1;
     uint32_t* ticks[2] = {nullptr, nullptr};  // device: tile times (10 ns) of the two last frames; ticks[cur] receives the next one's
     uint32_t* order = nullptr;                // device: the blend's workgroup order
+    uint32_t* deep = nullptr;                 // device word: how many leading entries of the order are DEEP tiles (blend.hip)
     uint32_t* stats = nullptr;                // pinned host words, written by tile_order_kernel: [0] fresh, [1] longest tile, [2] mean,
     uint32_t* stats_dev = nullptr;            //   [3] similarity of the two frames x 1000, [4] order dropped (they do not resemble each other)
     int cur = 0;
@@ -171,8 +172,8 @@ int tile_history_new(gsr_tile_history** out) {
     hipError_t e;
     if ((e = hipGetDevice(&h->device)) != hipSuccess) return fail_with(e, "hipGetDevice");
     uint32_t* dev = nullptr;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&dev), sizeof(uint32_t) * 3 * kTileOrderMax)) != hipSuccess) return fail_with(e, "hipMalloc (tile history)");
-    h->ticks[0] = dev; h->ticks[1] = dev + kTileOrderMax; h->order = dev + 2 * kTileOrderMax;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&dev), sizeof(uint32_t) * (3 * kTileOrderMax + 32))) != hipSuccess) return fail_with(e, "hipMalloc (tile history)");
+    h->ticks[0] = dev; h->ticks[1] = dev + kTileOrderMax; h->order = dev + 2 * kTileOrderMax; h->deep = dev + 3 * kTileOrderMax;
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->stats), 64, hipHostMallocMapped)) != hipSuccess) return fail_with(e, "hipHostMalloc (tile history)");
     memset(h->stats, 0, 64);
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->stats_dev), h->stats, 0)) != hipSuccess) return fail_with(e, "hipHostGetDevicePointer");
@@ -253,14 +254,74 @@ struct Readback {
         return GSR_OK;
     }
 };
-static thread_local std::map<int, Readback> g_rb_by_device;
+// Everything the calling thread owns, per device; given back by gsr_thread_release and when the thread ends.
+struct ThreadResources {
+    std::map<int, Readback> by_device;
+    void release();
+    ~ThreadResources() { release(); }
+};
+static thread_local ThreadResources g_thread;
+
+// What the environment asks for, read once per process (A/B runs and the tests set these before the first call).
+struct EnvKnobs {
+    bool tile_history;         // GSR_TILE_HISTORY=0: no call reads or writes a tile history
+    int colors_beside;         // GSR_COLORS_BESIDE=0|1|2: geomState.rgb inside the preprocess / beside the depth sort / beside the blend; -1: by size
+    int fused_depth;           // GSR_FUSED_DEPTH=0|1: the depth order with / without the compaction whatever the size; -1: by size
+};
+const EnvKnobs& env_knobs() {
+    static const EnvKnobs k = [] {
+        EnvKnobs e;
+        const char* h = getenv("GSR_TILE_HISTORY");
+        e.tile_history = !(h && h[0] == '0');
+        const char* c = getenv("GSR_COLORS_BESIDE");
+        e.colors_beside = c && c[0] >= '0' && c[0] <= '2' ? c[0] - '0' : -1;
+        const char* f = getenv("GSR_FUSED_DEPTH");
+        e.fused_depth = f && (f[0] == '0' || f[0] == '1') ? f[0] - '0' : -1;
+        return e;
+    }();
+    return k;
+}
 
 // The calling thread's resources for the CURRENT device.
 int current_readback(Readback*& out) {
     int dev = 0;
     GSR_HIP_TRY(hipGetDevice(&dev));
-    out = &g_rb_by_device[dev];
+    out = &g_thread.by_device[dev];
     return GSR_OK;
+}
+
+void destroy_history(gsr_tile_history* h) {
+    h->magic = 0;
+    (void)hipFree(h->ticks[0]);
+    (void)hipHostFree(h->stats);
+    (void)hipEventDestroy(h->ev_order);
+    (void)hipEventDestroy(h->ev_switch);
+    delete h;
+}
+
+// Gives back what the calling thread's calls have made the library allocate, for every device: the second stream (drained
+// first: nothing of the library's is in flight afterwards — work on the CALLER's streams is the caller's to wait for before
+// it frees the chunks), the pinned words, every event, the staged-record counter and the histories the library kept for
+// calls without one of their own. A later call of the thread starts from nothing again.
+void ThreadResources::release() {
+    if (by_device.empty()) return;
+    int before = -1;
+    const bool have_device = hipGetDevice(&before) == hipSuccess;
+    for (auto& kv : by_device) {
+        Readback& rb = kv.second;
+        if (hipSetDevice(kv.first) != hipSuccess) { (void)hipGetLastError(); continue; }     // (the runtime is gone: nothing left to free)
+        if (rb.side) { (void)hipStreamSynchronize(rb.side); (void)hipStreamDestroy(rb.side); }
+        for (gsr_tile_history* h : rb.default_histories) destroy_history(h);
+        if (rb.events) for (auto& e : rb.ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {rb.ev_r, rb.ev_fork, rb.ev_join, rb.ev_colors, rb.ev_pre_blend})
+            if (e) (void)hipEventDestroy(e);
+        if (rb.staged_dev) (void)hipFree(rb.staged_dev);
+        if (rb.host) (void)hipHostFree(rb.host);
+        (void)hipGetLastError();
+    }
+    by_device.clear();
+    if (have_device) (void)hipSetDevice(before);
+    (void)hipGetLastError();
 }
 
 }  // namespace
@@ -277,6 +338,29 @@ const uint32_t* tile_order_of_call(const gsr_forward_receipt& r, int row_begin, 
     for (const gsr_tile_history* h : rb->default_histories)
         if (fits(h)) return h->order;
     return nullptr;
+}
+
+DeviceShape device_shape_of(int cus) {
+    DeviceShape s;
+    s.cus = cus > 0 ? cus : 1;
+    s.blend_slots = (uint32_t)s.cus * 4u * 5u;
+    s.blend_slots_beside = (uint32_t)s.cus * 4u * 3u;
+    s.light_frame_ticks = 25000ull * (unsigned long long)s.blend_slots;
+    return s;
+}
+
+int current_device_shape(DeviceShape* out) {
+    static thread_local std::map<int, DeviceShape> cache;
+    int dev = 0;
+    GSR_HIP_TRY(hipGetDevice(&dev));
+    auto it = cache.find(dev);
+    if (it == cache.end()) {
+        int cus = 0;
+        GSR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        it = cache.emplace(dev, device_shape_of(cus)).first;
+    }
+    *out = it->second;
+    return GSR_OK;
 }
 
 // What a gsr_backward call may read of the forward call that issued `r` (see gsr_backward_args.receipt): derived from
@@ -434,13 +518,19 @@ int gsr_tile_history_destroy(gsr_tile_history* h) {
     g_hip_error[0] = 0;
     if (!h) return fail(GSR_OK);
     if (h->magic != kHistoryMagic) return fail(GSR_ERR_INVALID_ARG);
-    h->magic = 0;
-    (void)hipFree(h->ticks[0]);
-    (void)hipHostFree(h->stats);
-    (void)hipEventDestroy(h->ev_order);
-    (void)hipEventDestroy(h->ev_switch);
-    delete h;
+    destroy_history(h);
     return fail(GSR_OK);
+}
+
+int gsr_thread_release(void) {
+    g_hip_error[0] = 0;
+    g_thread.release();
+    return fail(GSR_OK);
+}
+
+void gsr_device_shape(int cus, uint32_t out[4]) {
+    const DeviceShape s = device_shape_of(cus);
+    out[0] = (uint32_t)s.cus; out[1] = s.blend_slots; out[2] = s.blend_slots_beside; out[3] = (uint32_t)(s.light_frame_ticks / 25000ull);
 }
 
 int gsr_tile_history_stats(const gsr_tile_history* h, uint32_t out[6]) {
@@ -451,6 +541,16 @@ int gsr_tile_history_stats(const gsr_tile_history* h, uint32_t out[6]) {
     out[3] = (h->stats[0] != 0u ? h->stats[4] != 0u : h->decorrelated) ? 1u : 0u;
     out[4] = h->calls;
     out[5] = h->overlapped ? 1u : 0u;
+    return fail(GSR_OK);
+}
+
+int gsr_tile_history_times(const gsr_tile_history* h, uint32_t* times, int count, uint32_t* deep_tiles) {
+    g_hip_error[0] = 0;
+    if (!h || h->magic != kHistoryMagic || !times || count < 0 || count > kTileOrderMax) return fail(GSR_ERR_INVALID_ARG);
+    // (a tool's call: it synchronises the device — the history's calls may be on any stream)
+    GSR_HIP_TRY(hipDeviceSynchronize());
+    GSR_HIP_TRY(hipMemcpy(times, h->ticks[h->cur ^ 1], sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost));
+    if (deep_tiles) GSR_HIP_TRY(hipMemcpy(deep_tiles, h->deep, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return fail(GSR_OK);
 }
 
@@ -556,9 +656,11 @@ int gsr_forward(gsr_forward_args* a) {
     // Slow tiles first (TileOrder, blend_core.hpp): the order of this call's blend workgroups is sorted from the tile times of
     // the history's last frame while the depth sort runs, on the library's second stream. Which history: the caller's, or
     // this thread's own for the call's stream (a call of another size starts from zeros = patch order).
-    static const bool history_env = [] { const char* e = getenv("GSR_TILE_HISTORY"); return !(e && e[0] == '0'); }();
+    DeviceShape shape;
+    GSR_STEP(current_device_shape(&shape));
+    const EnvKnobs& env = env_knobs();
     gsr_tile_history* hist = nullptr;
-    if (history_env && !(a->flags & GSR_FLAG_NO_TILE_HISTORY) && tile_order_workgroups(d) <= kTileOrderMax &&
+    if (env.tile_history && !(a->flags & GSR_FLAG_NO_TILE_HISTORY) && tile_order_workgroups(d) <= kTileOrderMax &&
         d.grid_x * d.grid_y <= kTileOrderMax) {
         if (a->tile_history) {
             int dev_now = -1;
@@ -600,8 +702,8 @@ int gsr_forward(gsr_forward_args* a) {
         }
         if (hist->stats[0] != 0u) {
             const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
-            hist->wanted = 2ull * 5120ull * hist->stats[1] > 5ull * tiles * hist->stats[2] ||
-                           (hist->stats[2] != 0u && tiles * hist->stats[2] < kLightFrameTicks);      // (or a light frame: tile_order_kernel)
+            hist->wanted = 2ull * (unsigned long long)shape.blend_slots * hist->stats[1] > 5ull * tiles * hist->stats[2] ||
+                           (hist->stats[2] != 0u && tiles * hist->stats[2] < shape.light_frame_ticks);      // (or a light frame: tile_order_kernel)
             hist->mean = hist->stats[2];
             hist->longest = hist->stats[1];
             hist->decorrelated = hist->stats[4] != 0u;
@@ -622,8 +724,7 @@ int gsr_forward(gsr_forward_args* a) {
     // the preprocess gains (6.10 -> 6.19 ms): there the colours are written beside the BLEND — vector-bound —, which takes a
     // record's colour straight from the SH array meanwhile (TileFeed::dc_stride). GSR_COLORS_BESIDE = 0 / 1 / 2 (environment,
     // for A/B runs and the tests): inside the preprocess / beside the depth sort / beside the blend, whatever the size.
-    const char* const colors_env = getenv("GSR_COLORS_BESIDE");
-    const int colors_forced = colors_env && colors_env[0] >= '0' && colors_env[0] <= '2' ? colors_env[0] - '0' : -1;
+    const int colors_forced = env.colors_beside;
     const bool colors_movable = !inria && !a->colors_precomp && !(a->flags & GSR_FLAG_SERIAL_EMIT);
     const int colors_mode = !colors_movable ? 0 : (colors_forced >= 0 ? colors_forced : (n <= (1 << 24) ? 1 : 2));
     const bool colors_beside = colors_mode == 1;
@@ -703,8 +804,7 @@ int gsr_forward(gsr_forward_args* a) {
     // nothing where nearly every Gaussian is visible (50 M: 0.20 ms). The digit counts come from a pass over the keys alone
     // and the first depth pass reads the per-Gaussian arrays itself, leaving out what has no tile (onesweep_kernel, DROP).
     // (GSR_FUSED_DEPTH = 0 / 1 in the environment, for A/B runs and the tests: never / whatever the size)
-    const char* const fused_env = getenv("GSR_FUSED_DEPTH");
-    const bool fused_depth = xy_plan && (fused_env && (fused_env[0] == '0' || fused_env[0] == '1') ? fused_env[0] == '1' : n > (1 << 24));
+    const bool fused_depth = xy_plan && (env.fused_depth >= 0 ? env.fused_depth == 1 : n > (1 << 24));
     if (fused_depth)
         GSR_STEP(sort_u32_prepare_counts(gs.depth_key, (uint32_t)n, four, gs.sort_info, stream, g_rb.host_dev + 3, &side));
     else
@@ -733,7 +833,7 @@ int gsr_forward(gsr_forward_args* a) {
         hist->order_serial = 0;
         GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_r, 0));
         bool sorted = false;
-        GSR_STEP(launch_tile_order(d, hist->ticks[hist->cur], t_ticks, hist->order, hist->stats_dev, g_rb.side, &sorted));
+        GSR_STEP(launch_tile_order(d, hist->ticks[hist->cur], t_ticks, hist->order, hist->stats_dev, g_rb.side, &sorted, hist->deep, shape));
         if (sorted) GSR_HIP_TRY(hipEventRecord(hist->ev_order, g_rb.side));
         else order_now = false;                               // (no room for the sort on this device: patch order)
     }
@@ -816,7 +916,7 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, R, gs.block_scratch,
                                       bin.keys_unsorted, bin.values_unsorted, bin.sorting_space, img.ranges, inria, stream,
                                       profile ? g_rb.ev[2 * GSR_STAGE_DEPTH_ORDER + 1] : nullptr, gs.sort_info + 4,
-                                      (a->flags & GSR_FLAG_NO_SORTED_LISTS) ? bin.values : nullptr));
+                                      (a->flags & GSR_FLAG_NO_SORTED_LISTS) ? bin.values : nullptr, shape.cus));
         if (profile) {
             // depth order + block lists | unit masks + prefixes + ranges (recorded as "sort_pass1") | emission
             g_rb.ev_alias_begin(GSR_STAGE_SORT_PASS1, GSR_STAGE_DEPTH_ORDER);
@@ -839,7 +939,8 @@ int gsr_forward(gsr_forward_args* a) {
             // how long the blend will take: the tiles' times spread over the chip's 5 120 wave slots — beside the emission, whose
             // persistent workgroups keep their registers, over the 3 072 it gets there —, but never less than the longest tile
             // (frames of small splats end on a few lone waves: the mean alone said 0.16 ms for a blend of 0.36)
-            unsigned long long blend_ticks = std::max((unsigned long long)hist->mean * tiles / (hist->overlapped ? 3072ull : 5120ull),
+            unsigned long long blend_ticks = std::max((unsigned long long)hist->mean * tiles /
+                                                          (unsigned long long)(hist->overlapped ? shape.blend_slots_beside : shape.blend_slots),
                                                       (unsigned long long)hist->longest);
             // (times of a blend fed from the SORTED lists: out of the block lists a tile walks every unit of its block for its
             // entries — measured on the stand-in, block feed over sorted-list feed: 1.1 at 88 instances per visible Gaussian,
@@ -900,7 +1001,7 @@ int gsr_forward(gsr_forward_args* a) {
         } else {
             if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE], emit_stream));
             GSR_STEP(launch_block_emit(nv, d.grid_x, d.grid_y, R, gs.block_scratch, bin.keys_unsorted, bin.values_unsorted,
-                                       bin.sorting_space, bin.keys, bin.values, emit_stream, forked));
+                                       bin.sorting_space, bin.keys, bin.values, emit_stream, forked, shape.cus));
             if (profile) {
                 GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_DUPLICATE + 1], emit_stream));
                 g_rb.recorded[GSR_STAGE_DUPLICATE] = true;
@@ -989,6 +1090,9 @@ int gsr_forward(gsr_forward_args* a) {
         colors_join.tail = false;
     }
     if (colors_late) { colors = a->shs; a->plan_used |= GSR_PLAN_COLORS_BESIDE; }
+    // (deep tiles, blend.hip: the leading entries of an order sorted for THIS call; the block-fed blend has none)
+    const bool deep_wanted = t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES) && !(use_blocks && !blend_from_lists);
+    if (deep_wanted || ((a->flags & GSR_FLAG_DEEP_TILES_ALL) && !(use_blocks && !blend_from_lists))) a->plan_used |= GSR_PLAN_DEEP_TILES;
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)
         GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
@@ -997,7 +1101,8 @@ int gsr_forward(gsr_forward_args* a) {
     else
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
-                              t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks, colors_late));       // :804-810
+                              t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks, colors_late,
+                              deep_wanted ? hist->deep : nullptr, (a->flags & GSR_FLAG_DEEP_TILES_ALL) != 0));   // :804-810
     if (order_now) hist->order_serial = serial;               // (the blend that takes the order is in its stream: a backward of this call may take it too)
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is

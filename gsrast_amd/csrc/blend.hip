@@ -12,6 +12,9 @@
 // Differences that do not change any pixel: a record no lane of the wave can see (power > 0 or below the
 // 1/255 cut for every lane) is skipped after the power evaluation by one ballot.
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
 #include <type_traits>
@@ -39,6 +42,8 @@ struct BlendParams {
     int base_workgroups;           // workgroups of one wave per tile; the launch holds four times as many when nonempty is given
     uint32_t num_rendered;         // R of the call (the lists' total length)
     TileOrder history;             // longest tiles first (blend_core.hpp)
+    const uint32_t* deep_count;    // device word: leading entries of the order that are DEEP tiles (four waves, one walk), or null
+    int deep_all;                  // every tile is one (GSR_FLAG_DEEP_TILES_ALL)
     uint32_t dc_stride;            // 0, or 48: `colors` is the SH array (TileFeed::dc_stride)
 };
 
@@ -64,42 +69,68 @@ constexpr uint32_t kPriorityMeanList = 8192;     // entries per tile with a list
 // a time, one per lane, in wave-private LDS: no workgroup barrier anywhere. The batch size of the
 // reference (256) only survives as the granularity of the "whole tile done" test and of the
 // staged-record count R_f, which therefore stay identical to the reference's.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) {
-    __shared__ StagedRecords s_staged;
-    exp_table_init(s_staged.exp_tab, (int)threadIdx.x);      // (wave-private LDS: ordered inside the wave)
+//
+// ---- DEEP tiles: four waves per tile, ONE walk ------------------------------------------------
+// A frame's blend lasts as long as its slowest tiles, and a wave alone on its SIMD issues a vector instruction every five
+// cycles where the SIMD could take one every two (scripts/micro/valu_issue.hip): from (0,0,-30) a tenth of the tiles runs
+// beyond 335 us, one wave each, while the rest of the chip has long finished (`profiles/r04_blend_tile_times.txt`). The
+// tiles the history expects to be that slow (tile_order_kernel: `deep_count` leading entries of the order) get the whole
+// workgroup: the four waves WALK the list together — a round is 256 list entries, wave w fetches, culls and stages entries
+// [64 w, 64 w + 64) of it into segment w of the shared staging area, with every survivor the strips it can reach at all —
+// and each wave COMPOSITES one 16 x 4 strip over the four segments in list order, taking only the slots that can reach its
+// strip. The list is read once and culled once per tile; per record a wave pays the filter and one strip's evaluation
+// instead of four. T, nContrib and every decision are those of one wave per tile (same functions, same order per pixel);
+// the staged-record count follows from WHERE the tile finished: the reference stages a batch of 256 when its first
+// position is reached with some pixel unfinished, i.e. every batch that starts before the record the last pixel
+// finished on. Two barriers a round. Workgroups of the launch: [0, base) one DEEP tile each (those beyond the deep count
+// leave at once), then groups of four ordinary tiles, a wave each (no barrier there: the waves never meet).
+// The frames that have few tiles with a list (`strips`) take the same way for every tile.
+constexpr int kGroupWaves = 4;
+constexpr uint32_t kDeepGainX16 = 40;            // a deep tile takes 1 / 2.5 of one wave's time (tile_order_kernel, DeepRule)
+constexpr uint32_t kDeepFracX16 = 6;             // deep from 3/8 of the longest estimate
+constexpr uint32_t kDeepFloorTicks = 4000;       // ... but never below 40 us
+constexpr uint32_t kDeepFlag = 0x80000000u;      // in a tile's recorded time: it was composited by four waves
+__global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) {
+    // (one area, two uses: a wave's own staging records in the ordinary mode; two rounds of four segments in the deep one)
+    constexpr size_t kStageBytes = sizeof(DeepSegment) * 2 * kGroupWaves > sizeof(StagedRecords) * kGroupWaves ? sizeof(DeepSegment) * 2 * kGroupWaves
+                                                                                                            : sizeof(StagedRecords) * kGroupWaves;
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[kStageBytes];
+    __shared__ unsigned long long s_exp[kGroupWaves][32];  // exp_ref's table, a copy per wave
+    __shared__ uint32_t s_count[2][kGroupWaves];           // deep: survivors per segment of a round
+    __shared__ uint32_t s_done[kGroupWaves], s_done_at[kGroupWaves];   // deep: strip finished, and on which record
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;     // (wave: a scalar)
+    unsigned long long* const exp_tab = s_exp[wave];
+    exp_table_init(exp_tab, lane);           // (written and read by that wave only)
 
-    // workgroups [k * base, (k + 1) * base) are strip k of the tiles: the three extra sets leave at once unless the frame
-    // has few tiles with a list (they are the END of the launch, and a tile's four waves run on one XCD)
-    const int strip = (int)blockIdx.x / p.base_workgroups;
     bool strips = false, prioritise = false;
     if (p.nonempty != nullptr) {
         const uint32_t ne = *p.nonempty;
         strips = ne <= kStripTilesAny || (ne <= kStripTilesShort && (unsigned long long)p.num_rendered <= (unsigned long long)kStripMeanList * ne);
         prioritise = !strips && (unsigned long long)p.num_rendered >= (unsigned long long)kPriorityMeanList * ne;    // (see set_tile_priority)
     }
-    if (strip != 0 && !strips) return;
+    const int base = p.base_workgroups;
+    const int deep_tiles = (strips || p.deep_all) ? base : (p.deep_count ? (int)min(*p.deep_count, (uint32_t)base) : 0);
+    const bool deep = (int)blockIdx.x < base;
+    int entry;
+    if (deep) {
+        entry = (int)blockIdx.x;
+        if (entry >= deep_tiles) return;
+    } else {
+        entry = deep_tiles + kGroupWaves * ((int)blockIdx.x - base) + wave;
+        if (strips || p.deep_all || entry >= base) return;
+    }
     const uint32_t clock_begin = tile_clock();
-    const int wg = (int)blockIdx.x - strip * p.base_workgroups;
-    const int tile_local = tile_of_workgroup(p.history.order ? (int)p.history.order[wg] : wg, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
+    const int tile_local = tile_of_workgroup(p.history.order ? (int)p.history.order[entry] : entry, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
     if (tile_local < 0) return;
     const int tile = p.dims.row_begin * p.dims.grid_x + tile_local;
     const int tx = tile % p.dims.grid_x, ty = tile / p.dims.grid_x;
-    const int lane = threadIdx.x;
-    TileLanes s;
-    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height, strips ? strip : -1);
     const uint2 range = p.ranges[tile];
     const uint32_t total = range.y - range.x;          // unsigned wrap as in the reference
-    unsigned long long staged = 0;
-    bool all_done = tile_lanes_all_done(s);
 
     TileFeed feed;
     feed.means2D = p.means2D; feed.colors = p.colors; feed.conic_opacity = p.conic_opacity;
     feed.dc_stride = p.dc_stride;
     feed.box = tile_box(tx, ty, p.dims.width, p.dims.height);
-    if (strips) {
-        feed.box.y_lo = (float)(ty * kTile + 4 * strip);
-        feed.box.y_hi = (float)min(ty * kTile + 4 * strip + 3, p.dims.height - 1);
-    }
     feed.total = total; feed.t_cutoff = p.t_cutoff;
     // batch k = list positions [64 k, 64 k + 64); ids are fetched two batches ahead, records one batch ahead
     auto next_batch = [&](uint32_t pos) {
@@ -113,6 +144,69 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void bl
         }
         return nb;
     };
+    if (deep) {
+        constexpr uint32_t kRound = kGroupWaves * kWave;
+        DeepSegment (*const segs)[kGroupWaves] = reinterpret_cast<DeepSegment (*)[kGroupWaves]>(s_stage);      // [round & 1][wave]
+        StripLanes s;
+        strip_lanes_init(s, tx, ty, wave, lane, p.dims.width, p.dims.height);
+        bool my_done = strip_lanes_all_done(s);            // (a strip below the image: finished from the start)
+        if (lane == 0) { s_done[wave] = my_done ? 1u : 0u; s_done_at[wave] = 0u; }
+        // Round r: stage r + 1 into the other half of the area (everybody left round r - 1, which read it, through the barrier
+        // before), composite r, one barrier.
+        RecordBatch b0 = next_batch((uint32_t)(wave * kWave));
+        fetch_records(b0, feed);
+        RecordBatch b1 = next_batch(kRound + (uint32_t)(wave * kWave));
+        fetch_records(b1, feed);
+        RecordBatch b2 = next_batch(2 * kRound + (uint32_t)(wave * kWave));
+        {
+            const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
+            if (lane == 0) s_count[0][wave] = kept;
+        }
+        __syncthreads();
+        for (uint32_t pos = 0, r = 0; pos < total; pos += kRound, ++r) {
+            // (b1: round r + 1, its records on their way since the round before; b2: round r + 2, its ids)
+            const uint32_t kept = b1.valid ? stage_batch_deep(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
+            if (lane == 0) s_count[(r + 1u) & 1u][wave] = kept;
+            fetch_records(b2, feed);
+            const RecordBatch b3 = next_batch(pos + 3 * kRound + (uint32_t)(wave * kWave));
+            if (!my_done) {
+#pragma nounroll
+                for (int g = 0; g < kGroupWaves; ++g) {
+                    const uint32_t cnt = s_count[r & 1u][g];
+                    if (cnt == 0u) continue;
+                    const DeepSegment& seg = segs[r & 1u][g];
+                    const unsigned long long slots = __ballot((uint32_t)lane < cnt && ((seg.touch[lane] >> wave) & 1u) != 0u);
+                    uint32_t at = 0;
+                    if (slots != 0ull && composite_strip(s, seg, slots, feed.t_cutoff, exp_tab, &at)) {
+                        my_done = true;
+                        if (lane == 0) { s_done[wave] = 1u; s_done_at[wave] = at; }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();                            // round r is composited, round r + 1 staged, the flags are visible
+            if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
+            b1 = b2;
+            b2 = b3;
+        }
+        strip_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
+        if (wave == 0 && lane == 0) {
+            if (p.staged_counter) {
+                // (the loop was left through a barrier: the flags are final)
+                const bool finished = (s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u;
+                const uint32_t last = max(max(s_done_at[0], s_done_at[1]), max(s_done_at[2], s_done_at[3]));
+                const unsigned long long batches = ((unsigned long long)last + (unsigned long long)kBatch - 1ull) / (unsigned long long)kBatch;
+                atomicAdd(p.staged_counter, finished ? min((unsigned long long)total, batches * (unsigned long long)kBatch) : (unsigned long long)total);
+            }
+            if (p.history.ticks) p.history.ticks[tile] = ((tile_clock() - clock_begin) & ~kDeepFlag) | kDeepFlag;
+        }
+        return;
+    }
+    StagedRecords& mine = reinterpret_cast<StagedRecords*>(s_stage)[wave];
+    TileLanes s;
+    tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height, -1);
+    unsigned long long staged = 0;
+    bool all_done = tile_lanes_all_done(s);
     // (two copies of the loop: the one without the priority updates is, instruction for instruction, the loop of the frames
     // that do not use them — with one loop and a flag tested inside it, eye (0,0,-30) ran 3 % slower for nothing)
     auto walk = [&](auto with_priority) {
@@ -123,7 +217,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void bl
         for (uint32_t pos = 2 * kWave; b0.valid && !all_done; pos += kWave) {
             fetch_records(b1, feed);
             RecordBatch b2 = next_batch(pos);
-            all_done = stage_and_composite(s, feed, s_staged, b0, staged);
+            all_done = stage_and_composite(s, feed, mine, b0, staged, exp_tab);
             b0 = b1;
             b1 = b2;
             if (with_priority.value) set_tile_priority(total - min(total, pos));
@@ -133,7 +227,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void bl
     else walk(std::false_type{});
     tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
-    if (p.history.ticks && lane == 0 && strip == 0) p.history.ticks[tile] = tile_clock() - clock_begin;
+    if (p.history.ticks && lane == 0) p.history.ticks[tile] = (tile_clock() - clock_begin) & ~kDeepFlag;
 }
 
 // Workgroup numbers of the patch order, the SLOW tiles of the frame before first — those that took more than twice the
@@ -156,38 +250,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void bl
 // (bench scene, 1920 x 1080, scripts/history_similarity.py, `profiles/r05_history_similarity.txt`)
 // along bench.py's camera path (0.31 units a frame) 0.84 to 0.97, median 0.90; between unrelated views 0.46 to 0.90, median 0.81
 constexpr uint32_t kMinSimilarity = 800;         // of 1000
+// Which of the slow tiles get four waves (blend_wave_kernel, DEEP tiles). A tile that was composited by four waves left its
+// time flagged (kDeepFlag): what it would take one wave is estimated as gain x that time, and every decision below is
+// taken on those estimates, so that a tile does not leave the class because the class made it faster. With the deep tiles
+// taking 1 / gain of their time, the launch lasts about max(longest / gain, longest ordinary tile, everybody's time spread
+// over the chip's wave slots): a tile is DEEP when its estimate lies beyond max(frac x longest estimate, that spread, floor)
+// — compared as quantised classes, so that the deep tiles are exactly the order's leading entries.
+struct DeepRule {
+    uint32_t gain_x16;        // one wave's time over four waves' (x 16)
+    uint32_t frac_x16;        // of the longest tile's estimate (x 16)
+    uint32_t floor_ticks;     // never below this (10 ns units): a short tile gains nothing from three barriers a round
+    uint32_t wave_slots;      // wave slots of the chip the frame's tile time is spread over (DeviceShape::blend_slots)
+    unsigned long long light_ticks;   // DeviceShape::light_frame_ticks
+};
+__device__ __forceinline__ uint32_t tile_estimate(uint32_t recorded, uint32_t gain_x16) {
+    const uint32_t t = recorded & ~kDeepFlag;
+    if (gain_x16 == 0u) return t;                // (no deep tiles wanted: GSR_DEEP=0)
+    return (recorded & kDeepFlag) ? (uint32_t)min(0x7FFFFFFFull, ((unsigned long long)t * gain_x16) >> 4) : t;
+}
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ticks, const uint32_t* __restrict__ ticks_before,
                                                           uint32_t* __restrict__ order,
                                                           int workgroups, int padded, int grid_x, int row_begin, int rows,
-                                                          uint32_t* __restrict__ stats) {
+                                                          uint32_t* __restrict__ stats, uint32_t* __restrict__ deep_count, const DeepRule rule) {
     extern __shared__ uint32_t s_key[];
-    __shared__ unsigned long long s_sum, s_common, s_before;
-    __shared__ uint32_t s_cnt, s_max;
-    if (threadIdx.x == 0) { s_sum = 0; s_cnt = 0; s_max = 0; s_common = 0; s_before = 0; }
+    __shared__ unsigned long long s_sum, s_common, s_before, s_est;
+    __shared__ uint32_t s_cnt, s_max, s_max_est, s_deep;
+    if (threadIdx.x == 0) { s_sum = 0; s_cnt = 0; s_max = 0; s_common = 0; s_before = 0; s_est = 0; s_max_est = 0; s_deep = 0; }
     __syncthreads();
-    unsigned long long sum = 0, sum_before = 0;
-    uint32_t cnt = 0, mx = 0;
+    unsigned long long sum = 0, sum_before = 0, sum_est = 0;
+    uint32_t cnt = 0, mx = 0, mx_est = 0;
     for (int i = threadIdx.x; i < workgroups; i += 1024) {
         const int tile_local = tile_of_workgroup(i, grid_x, rows);
         if (tile_local >= 0) {
-            const uint32_t t = ticks[row_begin * grid_x + tile_local];
+            const uint32_t rec = ticks[row_begin * grid_x + tile_local];
+            const uint32_t t = rec & ~kDeepFlag, est = tile_estimate(rec, rule.gain_x16);
             sum += t; mx = max(mx, t); ++cnt;
-            sum_before += ticks_before[row_begin * grid_x + tile_local];
+            sum_est += est; mx_est = max(mx_est, est);
+            sum_before += tile_estimate(ticks_before[row_begin * grid_x + tile_local], rule.gain_x16);
         }
     }
     atomicAdd(&s_sum, sum);
     atomicAdd(&s_cnt, cnt);
     atomicMax(&s_max, mx);
     atomicAdd(&s_before, sum_before);
+    atomicAdd(&s_est, sum_est);
+    atomicMax(&s_max_est, mx_est);
     __syncthreads();
     // shares in units of 2^-20 of the frame's total (a tile's time is below 2^32, times 2^20 fits 64 bits)
     unsigned long long common = 0;
-    const unsigned long long total = max(s_sum, 1ull), total_before = max(s_before, 1ull);
+    const unsigned long long total = max(s_est, 1ull), total_before = max(s_before, 1ull);
     for (int i = threadIdx.x; i < workgroups; i += 1024) {
         const int tile_local = tile_of_workgroup(i, grid_x, rows);
         if (tile_local >= 0) {
-            const unsigned long long a = ((unsigned long long)ticks[row_begin * grid_x + tile_local] << 20) / total;
-            const unsigned long long b = ((unsigned long long)ticks_before[row_begin * grid_x + tile_local] << 20) / total_before;
+            const unsigned long long a = ((unsigned long long)tile_estimate(ticks[row_begin * grid_x + tile_local], rule.gain_x16) << 20) / total;
+            const unsigned long long b = ((unsigned long long)tile_estimate(ticks_before[row_begin * grid_x + tile_local], rule.gain_x16) << 20) / total_before;
             common += min(a, b);
         }
     }
@@ -196,8 +312,11 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
     const uint32_t similarity = s_before == 0ull ? 1000u : (uint32_t)min(1000ull, (1000ull * s_common) >> 20);
     const bool dropped = similarity < kMinSimilarity;
     // (a LIGHT frame — less than 250 us of tile time per wave slot — is sorted whole: its lists are short, it lasts as long as
-    // its longest tiles whatever the neighbours do; see kLightFrameTicks)
-    const unsigned long long slow_from = s_sum < kLightFrameTicks ? 0ull : 2ull * s_sum / max(s_cnt, 1u);
+    // its longest tiles whatever the neighbours do; see DeviceShape::light_frame_ticks)
+    const unsigned long long slow_from = s_est < rule.light_ticks ? 0ull : 2ull * s_est / max(s_cnt, 1u);
+    const unsigned long long deep_from = max(max(((unsigned long long)s_max_est * rule.frac_x16) >> 4, s_est / max(rule.wave_slots, 1u)),
+                                             max((unsigned long long)rule.floor_ticks, slow_from));
+    const uint32_t deep_class = quantise_ticks((uint32_t)min(deep_from, 0x7FFFFFFFull));
     // what the host decides on whether the next calls need an order at all: {fresh, longest tile, mean, similarity, dropped}
     if (stats && threadIdx.x == 0) {
         stats[1] = s_max; stats[2] = (uint32_t)(s_sum / max(s_cnt, 1u)); stats[3] = similarity; stats[4] = dropped ? 1u : 0u;
@@ -206,20 +325,26 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
     }
     if (dropped) {                                   // (the patch order itself)
         for (int i = threadIdx.x; i < workgroups; i += 1024) order[i] = (uint32_t)i;
+        if (deep_count && threadIdx.x == 0) *deep_count = 0u;
         return;
     }
+    uint32_t deep = 0;
     for (int i = threadIdx.x; i < padded; i += 1024) {
         uint32_t key = 0xFFF00000u | (uint32_t)i;
         if (i < workgroups) {
             const int tile_local = tile_of_workgroup(i, grid_x, rows);
             if (tile_local >= 0) {
-                const uint32_t t = ticks[row_begin * grid_x + tile_local];
-                key = ((t > slow_from ? 511u - quantise_ticks(t) : 512u) << 20) | (uint32_t)i;
+                const uint32_t t = tile_estimate(ticks[row_begin * grid_x + tile_local], rule.gain_x16);
+                const uint32_t q = quantise_ticks(t);
+                key = ((t > slow_from ? 511u - q : 512u) << 20) | (uint32_t)i;
+                if (t > slow_from && q > deep_class) ++deep;
             }
         }
         s_key[i] = key;
     }
+    atomicAdd(&s_deep, deep);
     __syncthreads();
+    if (deep_count && threadIdx.x == 0) *deep_count = rule.gain_x16 != 0u ? s_deep : 0u;
     for (int k = 2; k <= padded; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < padded / 2; t += 1024) {
@@ -273,8 +398,11 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  const float* means2D, const float* colors, const float* conic_opacity,
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream, const uint32_t* nonempty_tiles,
-                 uint32_t num_rendered, const uint32_t* tile_order, uint32_t* tile_ticks, bool colors_are_shs) {
+                 uint32_t num_rendered, const uint32_t* tile_order, uint32_t* tile_ticks, bool colors_are_shs, const uint32_t* deep_count,
+                 bool deep_all) {
     BlendParams p;
+    p.deep_count = tile_order ? deep_count : nullptr;      // (the deep tiles are the order's leading entries)
+    p.deep_all = deep_all ? 1 : 0;
     p.dc_stride = colors_are_shs ? 48u : 0u;
     p.history.order = tile_order; p.history.ticks = tile_ticks;
     p.num_rendered = num_rendered;
@@ -295,7 +423,9 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     // (not when the staged records are counted: that count is per tile, the reference's "whole tile done" test)
     p.nonempty = staged_counter ? nullptr : nonempty_tiles;
     p.base_workgroups = patch_workgroups(d.grid_x, d.row_end - d.row_begin);
-    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups * (p.nonempty ? 4 : 1))), dim3(kWave), 0, stream, p);
+    // workgroups [0, base): a deep tile each (or nothing); behind them the ordinary tiles, four to a workgroup
+    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups + (p.base_workgroups + kGroupWaves - 1) / kGroupWaves)),
+                       dim3(kGroupWaves * kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;
 }
@@ -303,7 +433,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
 // (see TileOrder, blend_core.hpp) `order` receives patch_workgroups(...) entries; asynchronous on stream
 int tile_order_workgroups(const FrameDims& d) { return patch_workgroups(d.grid_x, d.row_end - d.row_begin); }
 int launch_tile_order(const FrameDims& d, const uint32_t* ticks, const uint32_t* ticks_before, uint32_t* order, uint32_t* stats,
-                      hipStream_t stream, bool* sorted) {
+                      hipStream_t stream, bool* sorted, uint32_t* deep_count, const DeviceShape& shape) {
     *sorted = false;
     const int workgroups = tile_order_workgroups(d);
     if (workgroups <= 0) return GSR_OK;
@@ -325,8 +455,23 @@ int launch_tile_order(const FrameDims& d, const uint32_t* ticks, const uint32_t*
         }
         if (!it->second) return GSR_OK;
     }
+    // (GSR_DEEP = "gain_x16,frac_x16,floor_ticks" in the environment, read once: A/B runs and the tests; gain 0: no deep tiles)
+    static const DeepRule env_rule = [] {
+        DeepRule r{kDeepGainX16, kDeepFracX16, kDeepFloorTicks, 0u, 0ull};
+        if (const char* e = getenv("GSR_DEEP")) {
+            unsigned g = r.gain_x16, f = r.frac_x16, fl = r.floor_ticks;
+            const int got = sscanf(e, "%u,%u,%u", &g, &f, &fl);
+            if (got >= 1) r.gain_x16 = g;
+            if (got >= 2) r.frac_x16 = f;
+            if (got >= 3) r.floor_ticks = fl;
+        }
+        return r;
+    }();
+    DeepRule rule = env_rule;
+    rule.wave_slots = shape.blend_slots;
+    rule.light_ticks = shape.light_frame_ticks;
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), (size_t)padded * sizeof(uint32_t), stream, ticks, ticks_before, order,
-                       workgroups, padded, d.grid_x, d.row_begin, d.row_end - d.row_begin, stats);
+                       workgroups, padded, d.grid_x, d.row_begin, d.row_end - d.row_begin, stats, deep_count, rule);
     GSR_LAUNCH_CHECK("tile_order_kernel");
     *sorted = true;
     return GSR_OK;

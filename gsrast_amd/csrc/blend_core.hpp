@@ -181,83 +181,89 @@ constexpr float kFilterSlack = 0.25f;      // in units of the power: covers the 
 // take a fused form, three multiply-adds on alpha T — they feed no test, and move the pixel by a few 1e-8.
 // (A record whose power terms are too large for the filter's slack is staged with a zero filter conic and no floor: every
 // unfinished pixel is its candidate, stage_and_composite.)
-__device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
-                                                 const float4* s_raw, uint32_t chunk, float t_cutoff,
+// One staged record (slot j) against the wave's pixels; true: some pixel finished on it (the caller then looks whether all have).
+__device__ __forceinline__ bool composite_record(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
+                                                 const float4* s_raw, uint32_t j, float t_cutoff,
                                                  const unsigned long long* exp_tab) {
     const float qnan = __builtin_nanf("");
     constexpr float kAlphaMin = 1.0f / 255.0f;
-    for (uint32_t j = 0; j < chunk; ++j) {
-        const float2 xy = s_xy[j];
-        const float4 q = s_co[j];
-        const float dx = xy.x - s.fx;
-        const float h0 = (q.x * dx) * dx;
-        const float g = q.y * dx;
-        f32x2 gy; gy.x = xy.y; gy.y = xy.y;
-        f32x2 gg; gg.x = g; gg.y = g;
-        f32x2 hh; hh.x = h0; hh.y = h0;
-        f32x2 cz; cz.x = q.z; cz.y = q.z;
-        const f32x2 dy01 = gy - s.fy01, dy23 = gy - s.fy23;
-        const f32x2 fw01 = __builtin_elementwise_fma(dy01, __builtin_elementwise_fma(cz, dy01, gg), hh);
-        const f32x2 fw23 = __builtin_elementwise_fma(dy23, __builtin_elementwise_fma(cz, dy23, gg), hh);
-        const float filter[4] = {fw01.x, fw01.y, fw23.x, fw23.y};
-        // A pixel can pass alpha >= 1/255 only if power >= -ln(255 opacity): the record's own floor (q.w, set at staging with
-        // its margins: a faint record's strips are candidates only where it is bright enough to count, and only candidates pay
-        // for the exponential). The filter's window is wider than the reference's tests at both ends by kFilterSlack: the two
-        // evaluations of the power differ by rounding, 6e-8 of the largest of three terms that may cancel — a record whose terms
-        // can exceed what the slack covers has a zero filter conic — and a pixel the reference would accept must never be
-        // filtered out. The reference's own "power > 0" and "alpha < 1/255" tests follow below, on its
-        // own arithmetic.
-        unsigned long long cand[4];       // lane masks (every lane of the wave is active here); false for a finished pixel: NaN
+    const float2 xy = s_xy[j];
+    const float4 q = s_co[j];
+    const float dx = xy.x - s.fx;
+    const float h0 = (q.x * dx) * dx;
+    const float g = q.y * dx;
+    f32x2 gy; gy.x = xy.y; gy.y = xy.y;
+    f32x2 gg; gg.x = g; gg.y = g;
+    f32x2 hh; hh.x = h0; hh.y = h0;
+    f32x2 cz; cz.x = q.z; cz.y = q.z;
+    const f32x2 dy01 = gy - s.fy01, dy23 = gy - s.fy23;
+    const f32x2 fw01 = __builtin_elementwise_fma(dy01, __builtin_elementwise_fma(cz, dy01, gg), hh);
+    const f32x2 fw23 = __builtin_elementwise_fma(dy23, __builtin_elementwise_fma(cz, dy23, gg), hh);
+    const float filter[4] = {fw01.x, fw01.y, fw23.x, fw23.y};
+    // A pixel can pass alpha >= 1/255 only if power >= -ln(255 opacity): the record's own floor (q.w, set at staging with
+    // its margins: a faint record's strips are candidates only where it is bright enough to count, and only candidates pay
+    // for the exponential). The filter's window is wider than the reference's tests at both ends by kFilterSlack: the two
+    // evaluations of the power differ by rounding, 6e-8 of the largest of three terms that may cancel — a record whose terms
+    // can exceed what the slack covers has a zero filter conic — and a pixel the reference would accept must never be
+    // filtered out. The reference's own "power > 0" and "alpha < 1/255" tests follow below, on its
+    // own arithmetic.
+    unsigned long long cand[4];       // lane masks (every lane of the wave is active here); false for a finished pixel: NaN
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            cand[k] = __ballot(filter[k] <= kFilterSlack * kLog2e) & __ballot(filter[k] >= q.w);
-        if ((cand[0] | cand[1] | cand[2] | cand[3]) == 0ull) continue;
-        const float4 col = s_rgb[j];
-        const float4 raw = s_raw[j];
-        const uint32_t contributor = __float_as_uint(col.w);
-        // the reference's operation order from here on (this file is compiled without contraction)
-        const float t1 = (raw.x * dx) * dx, bdx = raw.y * dx;
-        unsigned long long newly_done = 0ull;
+    for (int k = 0; k < 4; ++k)
+        cand[k] = __ballot(filter[k] <= kFilterSlack * kLog2e) & __ballot(filter[k] >= q.w);
+    if ((cand[0] | cand[1] | cand[2] | cand[3]) == 0ull) return false;
+    const float4 col = s_rgb[j];
+    const float4 raw = s_raw[j];
+    const uint32_t contributor = __float_as_uint(col.w);
+    // the reference's operation order from here on (this file is compiled without contraction)
+    const float t1 = (raw.x * dx) * dx, bdx = raw.y * dx;
+    unsigned long long newly_done = 0ull;
 #pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
-            if ((cand[2 * pair] | cand[2 * pair + 1]) == 0ull) continue;
-            // (finished pixels: their dy is NaN, and so is their power — they are no candidates)
-            const f32x2 dy = pair == 0 ? dy01 : dy23;
-            const f32x2 pw = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
-            // (the compiler sinks each into its strip's branch; forcing both up front, interleaved, measured slower on every
-            // frame: the loop is bound by instruction issue, not by the latency of the double chain)
-            const float e0 = exp_ref(pw.x, exp_tab), e1 = exp_ref(pw.y, exp_tab);
+    for (int pair = 0; pair < 2; ++pair) {
+        if ((cand[2 * pair] | cand[2 * pair + 1]) == 0ull) continue;
+        // (finished pixels: their dy is NaN, and so is their power — they are no candidates)
+        const f32x2 dy = pair == 0 ? dy01 : dy23;
+        const f32x2 pw = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
+        // (the compiler sinks each into its strip's branch; forcing both up front, interleaved, measured slower on every
+        // frame: the loop is bound by instruction issue, not by the latency of the double chain)
+        const float e0 = exp_ref(pw.x, exp_tab), e1 = exp_ref(pw.y, exp_tab);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = 2 * pair + h;
-                if (cand[k] == 0ull) continue;                // nobody in this strip sees the record
-                const float power = h == 0 ? pw.x : pw.y;
-                const float alpha = fminf(0.99f, raw.w * (h == 0 ? e0 : e1));
-                const unsigned long long live = cand[k] & ~__ballot(power > 0.0f) & ~__ballot(alpha < kAlphaMin);
-                const float test = s.T[k] * (1.0f - alpha);
-                const unsigned long long stop = live & __ballot(test < t_cutoff);
-                if (__builtin_amdgcn_inverse_ballot_w64(live & ~stop)) {
-                    const float w = alpha * s.T[k];
-                    s.cr[k] = __builtin_fmaf(col.x, w, s.cr[k]);
-                    s.cg[k] = __builtin_fmaf(col.y, w, s.cg[k]);
-                    s.cb[k] = __builtin_fmaf(col.z, w, s.cb[k]);
-                    s.T[k] = test;
-                    s.last[k] = contributor;
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * pair + h;
+            if (cand[k] == 0ull) continue;                // nobody in this strip sees the record
+            const float power = h == 0 ? pw.x : pw.y;
+            const float alpha = fminf(0.99f, raw.w * (h == 0 ? e0 : e1));
+            const unsigned long long live = cand[k] & ~__ballot(power > 0.0f) & ~__ballot(alpha < kAlphaMin);
+            const float test = s.T[k] * (1.0f - alpha);
+            const unsigned long long stop = live & __ballot(test < t_cutoff);
+            if (__builtin_amdgcn_inverse_ballot_w64(live & ~stop)) {
+                const float w = alpha * s.T[k];
+                s.cr[k] = __builtin_fmaf(col.x, w, s.cr[k]);
+                s.cg[k] = __builtin_fmaf(col.y, w, s.cg[k]);
+                s.cb[k] = __builtin_fmaf(col.z, w, s.cb[k]);
+                s.T[k] = test;
+                s.last[k] = contributor;
+            }
+            if (stop != 0ull) {
+                if (__builtin_amdgcn_inverse_ballot_w64(stop)) {
+                    s.done[k] = 1u;
+                    if (k == 0) s.fy01.x = qnan;
+                    if (k == 1) s.fy01.y = qnan;
+                    if (k == 2) s.fy23.x = qnan;
+                    if (k == 3) s.fy23.y = qnan;
                 }
-                if (stop != 0ull) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(stop)) {
-                        s.done[k] = 1u;
-                        if (k == 0) s.fy01.x = qnan;
-                        if (k == 1) s.fy01.y = qnan;
-                        if (k == 2) s.fy23.x = qnan;
-                        if (k == 3) s.fy23.y = qnan;
-                    }
-                    newly_done |= stop;
-                }
+                newly_done |= stop;
             }
         }
-        if (newly_done != 0ull && tile_lanes_all_done(s)) return true;
     }
+    return newly_done != 0ull;
+}
+
+__device__ __forceinline__ bool composite_staged(TileLanes& s, const float2* s_xy, const float4* s_co, const float4* s_rgb,
+                                                 const float4* s_raw, uint32_t chunk, float t_cutoff,
+                                                 const unsigned long long* exp_tab) {
+    for (uint32_t j = 0; j < chunk; ++j)
+        if (composite_record(s, s_xy, s_co, s_rgb, s_raw, j, t_cutoff, exp_tab) && tile_lanes_all_done(s)) return true;
     return false;
 }
 
@@ -353,8 +359,10 @@ __device__ __forceinline__ uint32_t stage_batch(const TileFeed& f, StagedRecords
     return (uint32_t)__popcll(m2);
 }
 
+// exp_tab: exp_ref's table in LDS (null: the one in `st`)
 __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed& f, StagedRecords& st,
-                                                    const RecordBatch& b, unsigned long long& staged) {
+                                                    const RecordBatch& b, unsigned long long& staged, const unsigned long long* exp_tab = nullptr) {
+    if (!exp_tab) exp_tab = st.exp_tab;
     uint32_t before = 0;
     const uint32_t kept = stage_batch(f, st, b, &before);
     const uint32_t pos = b.pos, count = b.count();
@@ -364,13 +372,144 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
     const uint32_t boundary = (pos + (uint32_t)kBatch - 1u) & ~((uint32_t)kBatch - 1u);   // first multiple of 256 >= pos
     if (boundary < pos + count) {
         // records in front of the boundary first; then the reference would test "whole tile done" and stage the next 256
-        if (before) all_done = composite_staged(s, st.xy, st.co, st.rgb, st.raw, before, f.t_cutoff, st.exp_tab);
+        if (before) all_done = composite_staged(s, st.xy, st.co, st.rgb, st.raw, before, f.t_cutoff, exp_tab);
         if (all_done) return true;
         staged += min((uint32_t)kBatch, f.total - boundary);
         first = before;
     }
-    if (kept > first) all_done = composite_staged(s, st.xy + first, st.co + first, st.rgb + first, st.raw + first, kept - first, f.t_cutoff, st.exp_tab);
+    if (kept > first) all_done = composite_staged(s, st.xy + first, st.co + first, st.rgb + first, st.raw + first, kept - first, f.t_cutoff, exp_tab);
     return all_done;
+}
+
+// ---- deep tiles: four waves per tile, one walk (blend.hip) -------------------------------------------------------------
+// A round is 256 list entries; wave w fetches, culls and stages entries [64 w, 64 w + 64) into segment w, and composites ONE
+// 16 x 4 strip — one pixel per lane — over the four segments in list order, taking the slots that can reach its strip.
+struct DeepSegment {               // the survivors of a wave's 64 list entries, compacted
+    float4 head[kWave];            // centre x, y | the filter's floor in units of log2 (NaN: the record goes unfiltered) | its 1-based list position (bits)
+    float4 raw[kWave];             // conic + opacity as fetched
+    float4 rgb[kWave];             // colour (w unused)
+    uint32_t touch[kWave];         // strips the record can reach at all (bit k: strip k)
+};
+// Which strips a record can reach: strip k is out of reach when even the power's maximum over dx, -0.5 dy^2 det / A, stays
+// below the record's floor for every row of the strip, |dy| > sqrt(2 (ln(255 opacity) + margin) A / det) — the margin of
+// record_misses_tile plus the rounding of the power's terms over the tile, the determinant rounded down; anything odd: all four.
+__device__ __forceinline__ uint32_t strips_in_reach(const float2 xy, const float4 co, float p0, float terms, bool filtered, float tile_y0, int height) {
+    const float A = co.x, B = co.y, C = co.z;
+    const float ac = A * C, det_lo = ac - B * B - 4e-7f * ac;
+    const float reach2 = 2.0f * (2e-3f + 1e-5f * terms - p0) * A / det_lo * 1.0001f;     // (p0 = -ln(255 opacity))
+    if (!(A > 0.0f && C > 0.0f && det_lo > 0.0f && reach2 >= 0.0f && reach2 < 1e12f && filtered)) return 0xFu;
+    const float reach = __builtin_sqrtf(reach2) + 0.01f;
+    const float y_lo = xy.y - reach, y_hi = xy.y + reach;
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float r_lo = tile_y0 + 4.0f * (float)k, r_hi = fminf(r_lo + 3.0f, (float)(height - 1));
+        if (y_lo <= r_hi && y_hi >= r_lo) bits |= 1u << k;
+    }
+    return bits;
+}
+// (the footprint test, the floor and the margins are stage_batch's)
+__device__ __forceinline__ uint32_t stage_batch_deep(const TileFeed& f, DeepSegment& seg, const RecordBatch& b, int height) {
+    const bool present = b.present();
+    const uint32_t rank = b.rank(), pos = b.pos;
+    const bool keep = present && !record_misses_tile(b.xy, b.co, f.box);
+    const unsigned long long m2 = __ballot(keep);
+    if (keep) {
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+        const float* c = f.colors + (f.dc_stride != 0u ? (size_t)f.dc_stride : (size_t)3) * (size_t)b.id;
+        const float dxm = fmaxf(fabsf(b.xy.x - f.box.x_lo), fabsf(b.xy.x - f.box.x_hi)), dym = fmaxf(fabsf(b.xy.y - f.box.y_lo), fabsf(b.xy.y - f.box.y_hi));
+        const float terms = fabsf(b.co.x) * dxm * dxm + fabsf(b.co.z) * dym * dym + 2.0f * fabsf(b.co.y) * dxm * dym;
+        const float p0 = -__logf(255.0f * b.co.w);
+        const float floor2 = b.co.w != b.co.w ? -__builtin_inff() : (b.co.w <= 0.0f ? __builtin_inff() : (p0 - 1e-3f - 1e-6f * terms) * kLog2e);
+        const bool filtered = terms < 1.0e6f;                                   // (NaN: not filtered)
+        seg.head[slot] = make_float4(b.xy.x, b.xy.y, filtered ? floor2 : __builtin_nanf(""), __uint_as_float(pos + rank + 1u));
+        seg.raw[slot] = b.co;
+        float c0 = c[0], c1 = c[1], c2 = c[2];
+        if (f.dc_stride != 0u) { c0 = 0.5f + 0.4f * c0; c1 = 0.5f + 0.4f * c1; c2 = 0.5f + 0.4f * c2; }
+        seg.rgb[slot] = make_float4(c0, c1, c2, 0.0f);
+        seg.touch[slot] = strips_in_reach(b.xy, b.co, p0, terms, filtered, f.box.y_lo, height);
+    }
+    return (uint32_t)__popcll(m2);
+}
+
+struct StripLanes {                // one pixel per lane: lane l owns (x = l & 15, y = 4 strip + (l >> 4)) of the tile
+    int px, py;
+    float fx, fy;                  // (fy: NaN once the pixel is finished, as TileLanes' row coordinates)
+    bool inside;
+    float T, cr, cg, cb;
+    uint32_t last;
+};
+__device__ __forceinline__ void strip_lanes_init(StripLanes& s, int tx, int ty, int strip, int lane, int width, int height) {
+    s.px = tx * kTile + (lane & 15);
+    s.py = ty * kTile + 4 * strip + (lane >> 4);
+    s.fx = (float)s.px;
+    s.inside = s.px < width && s.py < height;
+    s.fy = s.inside ? (float)s.py : __builtin_nanf("");
+    s.T = 1.0f; s.cr = s.cg = s.cb = 0.0f; s.last = 0u;
+}
+__device__ __forceinline__ bool strip_lanes_all_done(const StripLanes& s) { return __ballot(s.fy == s.fy) == 0ull; }
+// composite_record for one strip: the same filter, the same reference-order evaluation, the same tests, per pixel the same
+// floats in the same order (scalar single-precision operations round as the packed ones do; nothing here is contracted).
+__device__ __forceinline__ bool composite_strip_record(StripLanes& s, const DeepSegment& seg, uint32_t j, float t_cutoff,
+                                                       const unsigned long long* exp_tab) {
+    constexpr float kAlphaMin = 1.0f / 255.0f;
+    const float4 hd = seg.head[j];
+    const float4 raw = seg.raw[j];
+    const float dx = hd.x - s.fx, dy = hd.y - s.fy;
+    unsigned long long cand;
+    if (hd.z == hd.z) {                                    // (wave-uniform)
+        const float h0 = (((-0.5f * kLog2e) * raw.x) * dx) * dx, g = (-kLog2e * raw.y) * dx;
+        const float fw = __builtin_fmaf(dy, __builtin_fmaf((-0.5f * kLog2e) * raw.z, dy, g), h0);
+        cand = __ballot(fw <= kFilterSlack * kLog2e) & __ballot(fw >= hd.z);
+    } else {
+        cand = __ballot(s.fy == s.fy);                     // every unfinished pixel: the reference's own tests decide alone
+    }
+    if (cand == 0ull) return false;
+    const float t1 = (raw.x * dx) * dx, bdx = raw.y * dx;
+    const float power = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
+    const float alpha = fminf(0.99f, raw.w * exp_ref(power, exp_tab));
+    const unsigned long long live = cand & ~__ballot(power > 0.0f) & ~__ballot(alpha < kAlphaMin);
+    const float test = s.T * (1.0f - alpha);
+    const unsigned long long stop = live & __ballot(test < t_cutoff);
+    if (__builtin_amdgcn_inverse_ballot_w64(live & ~stop)) {
+        const float4 col = seg.rgb[j];
+        const float w = alpha * s.T;
+        s.cr = __builtin_fmaf(col.x, w, s.cr);
+        s.cg = __builtin_fmaf(col.y, w, s.cg);
+        s.cb = __builtin_fmaf(col.z, w, s.cb);
+        s.T = test;
+        s.last = __float_as_uint(hd.w);
+    }
+    if (stop != 0ull) {
+        if (__builtin_amdgcn_inverse_ballot_w64(stop)) s.fy = __builtin_nanf("");
+        return true;
+    }
+    return false;
+}
+// The slots of `slots` (a lane mask over the segment's slots), in order. *done_at: the list position of the record the strip's
+// last pixel finished on.
+__device__ __forceinline__ bool composite_strip(StripLanes& s, const DeepSegment& seg, unsigned long long slots, float t_cutoff,
+                                                const unsigned long long* exp_tab, uint32_t* done_at) {
+    while (slots != 0ull) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(slots);
+        slots &= slots - 1ull;
+        if (composite_strip_record(s, seg, j, t_cutoff, exp_tab) && strip_lanes_all_done(s)) {
+            *done_at = __float_as_uint(seg.head[j].w);
+            return true;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ void strip_lanes_write(const StripLanes& s, int width, int height, const float* __restrict__ background,
+                                                  float* __restrict__ final_t, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color) {
+    if (!s.inside) return;
+    const size_t plane = (size_t)width * (size_t)height;
+    const size_t pid = (size_t)s.py * (size_t)width + (size_t)s.px;
+    final_t[pid] = s.T;
+    n_contrib[pid] = s.last;
+    out_color[pid] = s.cr + s.T * background[0];
+    out_color[pid + plane] = s.cg + s.T * background[1];
+    out_color[pid + 2 * plane] = s.cb + s.T * background[2];
 }
 
 __device__ __forceinline__ void tile_lanes_write(const TileLanes& s, int width, int height, const float* __restrict__ background,

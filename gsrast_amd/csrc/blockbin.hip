@@ -873,7 +873,7 @@ BlockFeed block_feed(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
                          int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
-                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles, uint32_t* skipped_stamp) {
+                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles, uint32_t* skipped_stamp, int cus) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
     if (t.chunk == kCoarse)
         hipLaunchKernelGGL(coarse_count_kernel<kCoarse>, dim3(t.chunks), dim3(kCoarse), 0, stream, n, sorted_rect, t.nbx, t.nbp,
@@ -918,7 +918,7 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     if (ev_coarse_end) GSR_HIP_TRY(hipEventRecord(ev_coarse_end, stream));
 
     // persistent grid: enough waves to fill the chip, never more than there can be units
-    const uint32_t count_wgs = std::min<uint32_t>((t.max_units + 3) / 4, 256u * 8u);
+    const uint32_t count_wgs = std::min<uint32_t>((t.max_units + 3) / 4, (uint32_t)cus * 8u);
     hipLaunchKernelGGL(unit_masks_kernel, dim3(count_wgs), dim3(256), 0, stream, t.meta, t.nb, t.nbx, ent_rd, t.unit_masks, t.cnt);
     GSR_LAUNCH_CHECK("unit_masks_kernel");
     hipLaunchKernelGGL(block_prefix_kernel, dim3(t.nb), dim3(256), 0, stream, t.meta, t.nbx, grid_x, grid_y, t.cnt, t.tile_count);
@@ -931,7 +931,8 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
 
 // The emission: the sorted keys / values written from the tables launch_block_binning left.
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
-                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream, bool beside_blend) {
+                      const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream, bool beside_blend,
+                      int cus) {
     const PlanTables t = plan_tables(n, grid_x, grid_y, r_total, geo_scratch, bin_scratch);
     // Workgroups (of four waves) per CU: two where the Gaussians cover many tiles each (long, dense runs: three or four
     // measured 1.5 % slower on the bench frame and at 4K), four where they cover few (short runs, the waves wait more than
@@ -941,7 +942,7 @@ int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo
     // 0.45 alone, the frame 1.70 for 1.50.
     const uint32_t per_cu = ((uint64_t)r_total >= 48ull * (uint64_t)n || beside_blend) ? 2u : 4u;
     // (a unit may be dealt as four items, see the kernel: a wave per item on small frames)
-    const uint32_t emit_wgs = std::min<uint32_t>(t.max_units, 256u * per_cu);
+    const uint32_t emit_wgs = std::min<uint32_t>(t.max_units, (uint32_t)cus * per_cu);
     hipLaunchKernelGGL(block_emit_kernel, dim3(emit_wgs), dim3(kEmitWaves * kWave), 0, stream, t.meta, t.nb, t.nbx, grid_x, grid_y,
                        ent_rd, ent_idx, t.unit_masks, t.cnt, t.tile_start, keys, values, r_total);
     GSR_LAUNCH_CHECK("block_emit_kernel");

@@ -150,10 +150,12 @@ size_t blockbin_bin_bytes(size_t r);
 int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* sorted_idx, const uint32_t* sorted_rect,
                          int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, uint64_t* ent_rd,
                          uint32_t* ent_idx, char* bin_scratch, uint32_t* ranges, bool close_single, hipStream_t stream,
-                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles = nullptr, uint32_t* skipped_stamp = nullptr);
+                         hipEvent_t ev_coarse_end, uint32_t* nonempty_tiles = nullptr, uint32_t* skipped_stamp = nullptr,
+                         int cus = 256);
 int launch_block_emit(int n, int grid_x, int grid_y, uint32_t r_total, char* geo_scratch, const uint64_t* ent_rd,
                       const uint32_t* ent_idx, char* bin_scratch, uint64_t* keys, uint32_t* values, hipStream_t stream,
-                      bool beside_blend = false);          // (the blend runs on another stream meanwhile: leave it room)
+                      bool beside_blend = false,           // (the blend runs on another stream meanwhile: leave it room)
+                      int cus = 256);
 int launch_blend_blocks(int n, const FrameDims& d, uint32_t r_total, char* geo_scratch, const uint32_t* ent_idx, char* bin_scratch,
                         const uint32_t* ranges, const float* means2D, const float* colors, const float* conic_opacity,
                         float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
@@ -170,15 +172,29 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream,
                  const uint32_t* nonempty_tiles = nullptr, uint32_t num_rendered = 0,       // (both: see blend.hip, four waves per tile)
                  const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr,       // (longest tiles first: TileOrder, blend_core.hpp)
-                 bool colors_are_shs = false);                                               // (`colors` = the SH array: TileFeed::dc_stride)
+                 bool colors_are_shs = false,                                                // (`colors` = the SH array: TileFeed::dc_stride)
+                 const uint32_t* deep_count = nullptr,                                       // (device word: the order's leading entries that get four waves, blend.hip)
+                 bool deep_all = false);                                                     // (every tile gets four waves)
 // Longest tiles first: the order of this call's blend workgroups from the ticks the tiles of the call before left.
 constexpr int kTileOrderMax = 32768;      // workgroups (one per tile, patch grid padded) up to which the order is kept: 128 KB of LDS for its sort
-constexpr unsigned long long kLightFrameTicks = 25000ull * 5120ull;   // 250 us (in 10 ns) per wave slot of the chip, summed over the tiles
+// What the launch heuristics need to know about the chip, derived from its CU count (hipDeviceAttributeMultiprocessorCount,
+// read once per device: an MI355X in a partitioned mode shows fewer CUs per device, and every figure below follows).
+struct DeviceShape {
+    int cus;                                 // compute units of the device
+    uint32_t blend_slots;                    // wave slots of the blend kernels: 4 SIMDs x 5 waves (96 VGPRs) per CU — 5 120 on 256 CUs
+    uint32_t blend_slots_beside;             // ... beside the emission's persistent workgroups, which keep their registers: 3 per SIMD — 3 072
+    unsigned long long light_frame_ticks;    // 250 us (in 10 ns) per blend wave slot, summed over the tiles: below it a frame counts as LIGHT
+    uint32_t persistent_workgroups(uint32_t per_cu) const { return (uint32_t)cus * per_cu; }
+};
+DeviceShape device_shape_of(int cus);                      // (pure: include/gsrast_amd.h gsr_device_shape, tests/test_capi_cpu.py)
+int current_device_shape(DeviceShape* out);                // the current device's, cached per device (api.hip)
 int tile_order_workgroups(const FrameDims& d);
 // ticks / ticks_before: the tile times of the history's last frame and of the one before it; *sorted = false (and nothing
 // launched): this device has no room for the sort's LDS
+// deep_count (device word, optional): receives how many leading entries of the order are DEEP tiles (blend.hip);
+// wave_slots: the chip's wave slots for the blend kernels (device_shape)
 int launch_tile_order(const FrameDims& d, const uint32_t* ticks, const uint32_t* ticks_before, uint32_t* order, uint32_t* stats,
-                      hipStream_t stream, bool* sorted);
+                      hipStream_t stream, bool* sorted, uint32_t* deep_count, const DeviceShape& shape);
 
 int launch_exp_test(int n, const float* in, float* out, hipStream_t stream);
 int launch_footprint_test(int n, const float* xy, const float* conic_opacity, const int32_t* tile_xy, int width, int height,

@@ -138,7 +138,7 @@ class SplatRasterizer:
              tile_rows: tuple[int, int] | None = None, scale_modifier: float = 1.0,
              sync: bool = True, semantics: str = "gscuda", sh_degree: int = 3, plan: str = "auto",
              overlap_emit: "bool | None" = None, sorted_lists: bool = True, colors_precomp: bool = False,
-             tile_history: "bool | str" = True) -> torch.Tensor:
+             tile_history: "bool | str" = True, deep_tiles: "bool | str | None" = None) -> torch.Tensor:
         """One `forward` call on the current torch stream. Returns the planar (3,H,W) image
         tensor owned by this object. `sync` adds the device synchronise the reference's caller
         performs after every call (CudaBuffer.hpp:8-12). semantics="inria" selects the upstream
@@ -151,6 +151,9 @@ class SplatRasterizer:
         caller of the reference's signature gets); last_tile_order_dropped: the history's frames did not resemble each other.
         sorted_lists=False: GSR_FLAG_NO_SORTED_LISTS (forward-only callers; last_lists_written tells whether the
         binning chunk holds the sorted keys / values of this call).
+        deep_tiles: None = the library decides per tile from the history (four waves for the tiles it expects to be the frame's
+        slowest, csrc/blend.hip; last_deep_tiles tells whether the blend was launched with them enabled), False =
+        GSR_FLAG_NO_DEEP_TILES, "all" = GSR_FLAG_DEEP_TILES_ALL (every tile; a diagnostic).
         colors_precomp: pass the scene's colours as the reference's `colorsPrecomp` argument (GSCuda.cuh:111) — computed once
         per scene by gsr_colors_from_dc, bit-equal to what the preprocess writes to geomState.rgb per frame (gscuda semantics
         only: there the colour does not depend on the view)."""
@@ -165,7 +168,8 @@ class SplatRasterizer:
                    | {"auto": 0, "sort": _capi.GSR_FLAG_PLAN_SORT, "blocks": _capi.GSR_FLAG_PLAN_BLOCKS}[plan]
                    | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else (_capi.GSR_FLAG_SERIAL_EMIT if overlap_emit is False else 0))
                    | (0 if sorted_lists else _capi.GSR_FLAG_NO_SORTED_LISTS)
-                   | (0 if tile_history else _capi.GSR_FLAG_NO_TILE_HISTORY))
+                   | (0 if tile_history else _capi.GSR_FLAG_NO_TILE_HISTORY)
+                   | (_capi.GSR_FLAG_DEEP_TILES_ALL if deep_tiles == "all" else (_capi.GSR_FLAG_NO_DEEP_TILES if deep_tiles is False else 0)))
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
         a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()
@@ -205,6 +209,7 @@ class SplatRasterizer:
         self.last_tile_order_dropped = bool(int(a.plan_used) & _capi.GSR_PLAN_TILE_ORDER_DROPPED)
         self.last_emit_overlapped = bool(int(a.plan_used) & _capi.GSR_PLAN_EMIT_OVERLAPPED)
         self.last_colors_beside = bool(int(a.plan_used) & _capi.GSR_PLAN_COLORS_BESIDE)
+        self.last_deep_tiles = bool(int(a.plan_used) & _capi.GSR_PLAN_DEEP_TILES)
         self.last_stage_ms = {n: float(a.stage_ms[i]) for i, n in enumerate(_capi.STAGE_NAMES)} if profile else {}
         if sync:
             torch.cuda.current_stream(self.device).synchronize()
@@ -217,6 +222,16 @@ class SplatRasterizer:
         _capi.check(self.lib.gsr_tile_history_stats(self._history, out), "gsr_tile_history_stats")
         return {"mean_ticks": int(out[0]), "longest_ticks": int(out[1]), "similarity": int(out[2]) / 1000.0,
                 "order_dropped": bool(out[3]), "calls": int(out[4]), "overlapped": bool(out[5])}
+
+    def tile_history_times(self):
+        """(times, deep flags, deep count) of this object's history after its last call: numpy u32[tiles] in units of 10 ns,
+        bool[tiles] (composited by four waves), and the number of deep tiles of the last sorted order (gsr_tile_history_times)."""
+        import numpy as np
+        tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
+        out, deep = (C.c_uint32 * tiles)(), C.c_uint32(0)
+        _capi.check(self.lib.gsr_tile_history_times(self._history, out, tiles, C.byref(deep)), "gsr_tile_history_times")
+        raw = np.frombuffer(out, dtype=np.uint32).copy()
+        return raw & 0x7FFFFFFF, (raw >> 31).astype(bool), int(deep.value)
 
     def precomputed_colors(self) -> torch.Tensor:
         """vec3[N] = 0.5 + 0.4 DC (gsr_colors_from_dc), computed on first use and kept for the scene."""

@@ -14,7 +14,10 @@
  * thread and device, is listed here in full: 1 KB of pinned host memory (the numRendered read-back and the calls' error
  * words), a second stream of the lowest priority and a handful of events, an 8-byte device counter (GSR_FLAG_COUNT_STAGED
  * only), and per tile history (below: one per stream the thread calls on, at most eight, or the caller's own
- * gsr_tile_history) 384 KB of device memory and 64 bytes of pinned host memory. None of it influences any output.
+ * gsr_tile_history) 384 KB of device memory and 64 bytes of pinned host memory. None of it influences any output. The
+ * reference owns nothing (GSCuda.cu:723-784: caller chunks only), so all of it can be given back: gsr_thread_release()
+ * frees what the CALLING thread's calls have allocated, and the library does the same by itself when a thread that called
+ * it ends — a host that renders from short-lived worker threads keeps nothing behind.
  */
 #ifndef GSRAST_AMD_H
 #define GSRAST_AMD_H
@@ -162,15 +165,25 @@ enum {
  * another stream must have ordered that stream behind the last call's (the library adds an event wait when it sees the
  * switch, if the old stream still exists). A history whose frames stop resembling each other — a trainer that draws an
  * unrelated camera every call, two views alternating on one history — is noticed (the two last frames' tile times are
- * compared when the order is sorted: sum of minima over sum of maxima below 0.6) and the order is dropped, patch order
- * as without a history, until they do again: plan_used then carries GSR_PLAN_TILE_ORDER_DROPPED. The order is only sorted
- * when the statistics of the calls before say the frame ends on a few slow tiles or is a light one, and every fourth
- * call to keep them fresh. A history also carries the statistics by which the library decides, per call, whether the
+ * compared when the order is sorted: each tile's SHARE of its frame's total tile time, the smaller of its two shares summed
+ * over the tiles, below 0.8) and the order is dropped, patch order as without a history, until they do again: plan_used
+ * then carries GSR_PLAN_TILE_ORDER_DROPPED. The order is sorted when the statistics of the calls before say the frame ends
+ * on a few slow tiles or is a light one, on every call while the order is dropped (the sort is what looks whether the
+ * frames resemble each other again), and every fourth call otherwise, to keep the statistics fresh. A history also carries the statistics by which the library decides, per call, whether the
  * blend runs beside the emission (GSR_FLAG_OVERLAP_EMIT). This flag switches all of it off for the call: it neither reads
  * nor writes a history and uses no second stream for it (GSR_TILE_HISTORY=0 in the environment does the same for every
  * call of the process). Frames of more than 32 768 tiles (beyond 3840 x 2160) keep no tile times either: the order is
  * sorted by one workgroup in LDS. */
 #define GSR_FLAG_NO_TILE_HISTORY 0x80u
+/* Deep tiles (csrc/blend.hip). A blend fed from the sorted lists gives the tiles its history expects to be the slowest of
+ * the frame a workgroup of FOUR waves each: the waves walk the tile's list together (one fetch, one footprint test per
+ * entry) and composite one 16 x 4 strip each — a wave alone on its SIMD issues a vector instruction every five cycles, and
+ * a frame lasts as long as its slowest tile. Same pixels, finalT, nContrib, records_staged: every pixel sees the same
+ * records in the same order. Which tiles: decided on the device when the order is sorted (see above), so only calls that
+ * use a history's order have any (plan_used: GSR_PLAN_DEEP_TILES). GSR_FLAG_NO_DEEP_TILES: none, whatever the history says;
+ * GSR_FLAG_DEEP_TILES_ALL: every tile (a diagnostic, and what the tests compare the ordinary way against). */
+#define GSR_FLAG_NO_DEEP_TILES 0x200u
+#define GSR_FLAG_DEEP_TILES_ALL 0x400u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
        GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer
@@ -180,7 +193,9 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
        GSR_PLAN_EMIT_OVERLAPPED = 0x800 /* or-ed in: the blend ran beside the emission (see GSR_FLAG_OVERLAP_EMIT) */,
        GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the scan / depth sort (or the blend), not by the preprocess */,
        GSR_PLAN_TILE_ORDER_DROPPED = 0x2000 /* or-ed in: the history's last frames did not resemble each other (another view
-                                               every call): the blend took the patch order (informational) */ };
+                                               every call): the blend took the patch order (informational) */,
+       GSR_PLAN_DEEP_TILES = 0x4000 /* or-ed in: the blend was launched with deep tiles enabled — how many tiles got four
+                                       waves was decided on the device (see GSR_FLAG_NO_DEEP_TILES; informational) */ };
 
 /* A tile history (see GSR_FLAG_NO_TILE_HISTORY): opaque, created for the CURRENT device, owned by the caller, one per view.
  * gsr_tile_history_destroy: the streams it was used on must be idle. */
@@ -189,10 +204,29 @@ int gsr_tile_history_create(gsr_tile_history** out);
 int gsr_tile_history_destroy(gsr_tile_history* history);
 /* What the library last learnt about the history (host side, no device access; for tools and tests): out[0] = mean tile
  * time of its last sorted frame in units of 10 ns (0: none yet), [1] = that frame's longest tile, [2] = similarity of its two
- * last frames x 1000 (sum of minima over sum of maxima of the tiles' times), [3] = 1 if the order is dropped at present,
+ * last frames x 1000 (the smaller of a tile's two shares of its frame's tile time, summed over the tiles), [3] = 1 if the order is dropped at present,
  * [4] = calls since the history was last cleared (a new size), [5] = 1 if the last block-plan call ran its blend beside the
  * emission. */
 int gsr_tile_history_stats(const gsr_tile_history* history, uint32_t out[6]);
+
+/* For tools and tests: the tile times the history's LAST call recorded, times[tile] for the first `count` tiles of the frame
+ * (row-major tile index) in units of 10 ns — bit 31 set: the tile was composited by four waves (a deep tile) —, and in
+ * *deep_tiles (optional) how many leading entries of the last sorted order were deep tiles. Synchronises the device. */
+int gsr_tile_history_times(const gsr_tile_history* history, uint32_t* times, int count, uint32_t* deep_tiles);
+
+/* Gives back everything the library has allocated for the CALLING host thread, on every device (see the list at the top):
+ * the second stream is drained first, so nothing of the library's own is in flight afterwards; work the thread's calls put
+ * on the CALLER's streams is the caller's to wait for, as ever, before it frees the chunks. Receipts of the thread's
+ * earlier calls can no longer be polled (gsr_poll_async_error reads their pinned words: do not pass one afterwards), and a
+ * gsr_backward call for one of them runs without the forward's tile order. A later call of the thread starts from nothing
+ * again. Also run when the thread ends. Always GSR_OK. */
+int gsr_thread_release(void);
+
+/* The figures the launch heuristics derive from a device's compute-unit count (hipDeviceAttributeMultiprocessorCount, read
+ * once per device — an MI355X in a partitioned mode shows fewer): out[0] = CUs, [1] = wave slots of the blend kernels
+ * (4 SIMDs x 5 waves per CU), [2] = the same beside the emission's persistent workgroups (3 per SIMD), [3] = [1] again as
+ * the divisor of the light-frame rule (250 us of tile time per slot). Pure: no device needed (tests/test_capi_cpu.py). */
+void gsr_device_shape(int compute_units, uint32_t out[4]);
 
 /* Receipt of one gsr_forward call: everything a LATER call (gsr_backward, gsr_poll_async_error) needs to know about it.
  * The reference keeps all per-call state in the caller-owned chunks (GSCuda.cu:723-725,734-736,782-784); so does this

@@ -203,3 +203,21 @@ int main() {
                            _capi.LIB_PATH, "-Wl,-rpath," + os.path.dirname(_capi.LIB_PATH), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True)
     assert out.split()[0] == ("glm" if with_glm else "pod")
+
+
+def test_device_shape_follows_the_compute_unit_count():
+    """What the launch heuristics assume about the chip comes from its CU count (hipDeviceAttributeMultiprocessorCount), not
+    from constants: a whole MI355X (256 CUs) and one eighth of it (32 CUs, a CPX partition)."""
+    L = _capi.lib()
+    out = (C.c_uint32 * 4)()
+    L.gsr_device_shape(256, out)
+    assert list(out) == [256, 5120, 3072, 5120]
+    L.gsr_device_shape(32, out)
+    assert list(out) == [32, 640, 384, 640]
+    L.gsr_device_shape(0, out)                      # (never a division by zero downstream)
+    assert out[0] == 1 and out[1] == 20
+
+
+def test_thread_release_without_any_call_is_a_no_op():
+    L = _capi.lib()
+    assert L.gsr_thread_release() == _capi.GSR_OK and L.gsr_thread_release() == _capi.GSR_OK

@@ -16,6 +16,13 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "vs_baseline", "dtype", "data", "config", "roofline")
 
 
+# what VERDICT r5 asked the record to carry, in the order bench.py writes it (the first eight describe the headline frame)
+RECORD_KEYS = ("workload", "splats", "num_rendered", "records_staged", "binning_plan", "ms_median", "ms_p99", "untimed_frames",
+               "ms_no_sorted_lists", "ms_serial", "ms_no_tile_history", "ms_faint", "ms_pose_outside", "ms_pose_far",
+               "ms_forward_backward", "path_ms_p50", "path_ms_p99", "path_ms_nohist_p50", "randview_ms", "randview_ms_nohist",
+               "frame_alg_gbs", "parallelism", "rccl_ranks")
+
+
 def _run_bench(extra_env, *args):
     env = dict(os.environ, **extra_env)
     env.setdefault("MASTER_PORT", "29541")
@@ -37,21 +44,33 @@ def test_single_gpu_line_has_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert "workload" in j["config"] and j["config"]["frame_alg_gbs"] > 0
-    assert j["config"]["spinup_frames"] == 16            # (untimed frames in front of the warm-up steps are said in the line)
+    cfg = j["config"]
+    assert "workload" in cfg and cfg["frame_alg_gbs"] > 0
+    # the driver's record keeps the first 24 keys of `config`, flat scalars only: everything measured must be among them
+    assert len(cfg) <= 24, list(cfg)
+    assert all(isinstance(v, (int, float, str, bool)) for v in cfg.values()), cfg
+    for k in RECORD_KEYS:
+        assert k in cfg, k
+    assert list(cfg)[:8] == list(RECORD_KEYS[:8])
+    # every frame rendered before the timed region is said in the line: spin-up + the counted frame + the warm-up steps
+    assert cfg["untimed_frames"] == 16 + 1 + 2 == j["warmup_effective"] and j["detail"]["spinup_frames"] == 16
+    assert cfg["ms_median"] > 0 and cfg["ms_p99"] >= cfg["ms_median"] and cfg["path_ms_p99"] >= cfg["path_ms_p50"] > 0
     j0 = _run_bench({}, "--spinup", "0", "--no-extras")
-    assert j0["config"]["spinup_frames"] == 0 and j0["steps"] == 3 and j0["warmup"] == 2
+    assert j0["config"]["untimed_frames"] == 3 and j0["detail"]["spinup_frames"] == 0 and j0["steps"] == 3 and j0["warmup"] == 2
+    assert len(j0["config"]) <= 24
 
 
 def test_sharded_path_forced_onto_one_rank():
     j = _run_bench({"GSR_FORCE_DIST": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1"})
     for k in CONTRACT_KEYS:
         assert k in j, k
-    cfg = j["config"]
+    cfg, det = j["config"], j["detail"]
     assert j["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and cfg["parallelism"] == "tile-rows x1"
-    assert cfg["band_exchange"]["transport"] in ("rccl", "torch") and cfg["bands"][0] == 0
-    (pr,) = cfg["per_rank"]
-    assert pr["rank"] == 0 and pr["tile_rows"] == [cfg["bands"][0], cfg["bands"][1]]
+    assert len(cfg) <= 24 and all(isinstance(v, (int, float, str, bool)) for v in cfg.values()), cfg
+    assert cfg["band_exchange"] in ("rccl", "torch") and det["band_exchange"]["transport"] == cfg["band_exchange"] and det["bands"][0] == 0
+    assert cfg["bands"] == f"{det['bands'][0]}-{det['bands'][1]}" and float(cfg["per_rank_render_ms"]) > 0.0
+    (pr,) = det["per_rank"]
+    assert pr["rank"] == 0 and pr["tile_rows"] == [det["bands"][0], det["bands"][1]]
     # the split a poor N-GPU number would be attributed with: device time of the render and of the exchange behind it
     assert pr["render_ms"] > 0.0 and pr["exchange_ms"] >= 0.0 and pr["render_ms"] <= 1.5 * pr["ms_per_step"] + 0.2
     assert pr["num_rendered"] == cfg["num_rendered"] > 0

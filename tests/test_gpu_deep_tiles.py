@@ -1,0 +1,128 @@
+"""GPU: deep tiles (csrc/blend.hip, GSR_FLAG_DEEP_TILES_ALL / GSR_FLAG_NO_DEEP_TILES) — a tile composited by four waves that
+walk its list together, one 16 x 4 strip each. Every pixel must see the same records in the same order as with one wave per
+tile: out_color, finalT, nContrib bit for bit, and the staged-record count R_f (which the deep way derives from WHERE the tile
+finished, not from counting batches). Against the ordinary way, against the oracle, on ragged sizes, bands of tile rows, the
+upstream semantics, faint splats (every list walked to its end), and with the history choosing the tiles by itself."""
+import numpy as np
+import pytest
+
+from helpers import assert_blend_parity, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(r):
+    st = r.map_image_state()
+    return r.out_color.clone(), st["finalT"].clone(), st["nContrib"].clone()
+
+
+def _poison(r):
+    r.out_color.fill_(float("nan"))
+    st = r.map_image_state()
+    st["finalT"].fill_(-7.0)
+    st["nContrib"].fill_(-7)
+
+
+def _same(a, b):
+    import torch
+    return all(torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
+               for x, y in zip(a, b))
+
+
+def test_config1_by_four_waves_per_tile_against_the_golden_fixture():
+    from gsrast_amd.rasterizer import SplatRasterizer
+    scene, cam, bg, exp = load_golden()
+    r = SplatRasterizer(cam.width, cam.height, background=bg)
+    r.configure_from_scene(scene)
+    for plan in ("sort", "blocks"):
+        # (the block plan blends a frame this sparse from the sorted lists: the same kernel)
+        r.draw(cam, plan=plan, tile_history=False, deep_tiles="all", count_staged=True)
+        assert r.last_deep_tiles
+        st = r.map_image_state()
+        assert_blend_parity(r.out_color.cpu().numpy(), st["finalT"].cpu().numpy().reshape(cam.height, cam.width),
+                            st["nContrib"].cpu().numpy().reshape(cam.height, cam.width), exp, f"config 1, deep tiles, plan {plan}", bitwise_t=False)
+        assert r.last_records_staged == exp["records_staged"], (plan, r.last_records_staged, exp["records_staged"])
+
+
+@pytest.mark.parametrize("size,n,pos,opacity_scale", [((640, 368), 150_000, (0.0, 0.0, -6.0), 1.0),
+                                                        ((333, 217), 60_000, (0.2, -0.1, -4.0), 1.0),       # ragged: 21 x 14 tiles, last row and column partial
+                                                        ((640, 368), 150_000, (0.0, 0.0, -12.0), 0.1),      # faint splats: the lists are walked to their ends
+                                                        ((1280, 720), 400_000, (0.0, 0.0, -9.0), 1.0)])
+def test_deep_and_ordinary_tiles_give_the_same_bits(size, n, pos, opacity_scale):
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    from oracle import cpu_oracle
+    w, h = size
+    scene = scenes.garden_like_scene(n, seed=77)
+    scene["means3D"][:, :3] *= 0.35
+    scene["opacities"] = (scene["opacities"] * opacity_scale).astype(np.float32)
+    cam = camera.default_camera(w, h, near=0.05, far=60.0, position=pos)
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    r.draw(cam, plan="sort", tile_history=False, deep_tiles=False, count_staged=True)
+    ref, ref_staged = _state(r), r.last_records_staged
+    assert not r.last_deep_tiles
+    _poison(r)
+    r.draw(cam, plan="sort", tile_history=False, deep_tiles="all", count_staged=True)
+    assert r.last_deep_tiles
+    got, got_staged = _state(r), r.last_records_staged
+    assert _same(got, ref)
+    assert got_staged == ref_staged, (got_staged, ref_staged)
+    # ... and both are the oracle's
+    exp = cpu_oracle.forward(scene, cam, background=(0.1, 0.2, 0.3))
+    assert_blend_parity(got[0].cpu().numpy(), got[1].cpu().numpy().reshape(h, w), got[2].cpu().numpy().reshape(h, w), exp,
+                        f"deep tiles {w}x{h} n={n} opacities x {opacity_scale}")
+    assert got_staged == exp["records_staged"]
+    # a band of tile rows (what a rank of a sharded frame renders)
+    rows = (3, 11)
+    band_ref = r.draw(cam, plan="sort", tile_rows=rows, tile_history=False, deep_tiles=False).clone()
+    r.out_color.fill_(float("nan"))
+    band = r.draw(cam, plan="sort", tile_rows=rows, tile_history=False, deep_tiles="all")
+    y0, y1 = rows[0] * 16, min(rows[1] * 16, h)
+    import torch
+    assert torch.equal(band[:, y0:y1].view(torch.int32), band_ref[:, y0:y1].view(torch.int32))
+
+
+def test_deep_tiles_under_the_upstream_semantics():
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 480, 272
+    scene = scenes.garden_like_scene(80_000, seed=79)
+    scene["means3D"][:, :3] *= 0.35
+    cam = camera.default_camera(w, h, near=0.05, far=60.0, position=(0.0, 0.0, -5.0))
+    r = SplatRasterizer(w, h, background=(0.3, 0.2, 0.1))
+    r.configure_from_scene(scene)            # (SH degree 0: the DC triple leads either layout)
+    r.draw(cam, plan="sort", semantics="inria", sh_degree=0, tile_history=False, deep_tiles=False, count_staged=True)
+    ref, ref_staged = _state(r), r.last_records_staged
+    _poison(r)
+    r.draw(cam, plan="sort", semantics="inria", sh_degree=0, tile_history=False, deep_tiles="all", count_staged=True)
+    assert _same(_state(r), ref) and r.last_records_staged == ref_staged
+
+
+def test_the_history_picks_deep_tiles_and_nothing_changes():
+    """The same view again and again: the order is sorted from the tile times, its leading entries go to four waves (which
+    ones is decided on the device), and every frame is the bits of a frame without a history. Then the camera jumps."""
+    import torch
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    w, h = 640, 368
+    scene = scenes.garden_like_scene(150_000, seed=71)
+    scene["means3D"][:, :3] *= 0.35
+    r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
+    r.configure_from_scene(scene)
+    cams = [camera.default_camera(w, h, near=0.05, far=60.0, position=p) for p in ((0.0, 0.0, -6.0), (0.0, 0.0, -6.3), (0.3, -0.2, -3.0))]
+    refs = []
+    for c in cams:
+        r.draw(c, plan="sort", tile_history=False, count_staged=True)
+        refs.append((_state(r), r.last_records_staged))
+    deep_calls = 0
+    for c in (0,) * 8 + (1,) * 4 + (2,) * 5 + (0,) * 3:
+        _poison(r)
+        r.draw(cams[c], plan="sort", tile_history=True, count_staged=True)
+        deep_calls += int(r.last_deep_tiles)
+        assert _same(_state(r), refs[c][0]), c
+        assert r.last_records_staged == refs[c][1], c
+    # (a frame of 920 tiles cannot fill the chip: its longest tile always counts as slow, the order — and with it the deep
+    # class — is in use on most calls)
+    assert deep_calls >= 8, deep_calls
+    assert torch.isfinite(r.out_color).all()

@@ -473,3 +473,52 @@ def test_two_host_threads_render_at_the_same_time():
             assert g[3:] == e[3:], (t, i, g[3:], e[3:])
             for a, b in zip(g[:3], e[:3]):
                 assert torch.equal(a, b), (t, i)
+
+
+def test_short_lived_threads_leave_nothing_behind():
+    """200 host threads, one after the other, each renders two frames the way a caller of the reference's signature does (no
+    tile history of its own: the library then keeps one per host thread, device and stream — 384 KB of device memory —, a
+    second stream, events, pinned words) and ends. The reference owns nothing (GSCuda.cu:723-784); here everything a thread
+    made the library allocate goes back when the thread ends (gsr_thread_release): the device's free memory stays flat, and
+    every frame is the frame the main thread renders. gsr_thread_release by hand, then another call: starts from nothing."""
+    import threading
+    import torch
+    from gsrast_amd import _capi, camera, scenes
+    W, H = 320, 192
+    scene = scenes.garden_like_scene(20_000, seed=5)
+    scene["means3D"][:, :3] *= 0.4
+    r = _rast(W, H)
+    r.configure_from_scene(scene)
+    cam = camera.default_camera(W, H, near=0.05, far=60.0, position=(0.0, 0.0, -4.0))
+    ref = r.draw(cam, tile_history="default").clone()
+    errors = []
+
+    def work():
+        try:
+            for _ in range(2):
+                img = r.draw(cam, tile_history="default")
+                if not torch.equal(img.view(torch.int32), ref.view(torch.int32)):
+                    errors.append("frame differs")
+        except Exception as e:                              # noqa: BLE001 (reported by the main thread)
+            errors.append(repr(e))
+
+    def burst(n):
+        for _ in range(n):
+            th = threading.Thread(target=work)
+            th.start()
+            th.join()
+
+    burst(8)                                                # (whatever the runtimes set up per process is set up)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    burst(200)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert not errors, errors[:3]
+    # (200 histories alone would be 77 MB)
+    assert free0 - free1 < 8 * 1024 * 1024, (free0, free1)
+    L = _capi.lib()
+    assert L.gsr_thread_release() == _capi.GSR_OK
+    img = r.draw(cam, tile_history="default")
+    assert torch.equal(img.view(torch.int32), ref.view(torch.int32))
+    assert L.gsr_thread_release() == _capi.GSR_OK
