@@ -531,18 +531,52 @@ def load_profile_json(*names):
     return {}, None
 
 
+# SIMD cycles one wave-instruction of a class holds a gfx950 SIMD for once several waves share it (scripts/micro/valu_issue.hip,
+# profiles/r06_micro_valu_issue.txt: kernel wall time at 4 and 8 waves per SIMD, the launch's ends included): the THROUGHPUT
+# cost an issue roofline is made of. (A wave ALONE on its SIMD issues every 5 cycles whatever the class — 8 for the
+# transcendentals and the conversions, 25 to 33 for a compare whose mask a scalar instruction then reads: what a frame's last,
+# lone waves run at, and what the blend's deep tiles are there to avoid. That figure is `valu_frac_one_wave`, not a roofline.)
+VALU_CYCLES = {"f32": 2.7, "trans_f32": 7.5, "f64": 4.3, "cvt": 4.1, "int": 2.7, "other": 4.0, "mix": 3.1}
+VALU_CLASS_COUNTERS = {"f32": ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"), "trans_f32": ("SQ_INSTS_VALU_TRANS_F32",),
+                       "f64": ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"), "cvt": ("SQ_INSTS_VALU_CVT",),
+                       "int": ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64")}
+
+
 def blend_issue_fractions(pmc, blend_ms):
-    """VALU issue fraction of the blend kernel from a committed PMC pass (profiles/): SQ_INSTS_VALU wave-instructions
-    x 4 cycles (what one wave's stream holds its SIMD for per vector instruction, MI355X_MICROARCH.md) over the
-    1024 SIMDs x clock x the live launch time. The counters are per launch of the same kernel on the same frame."""
-    if not pmc or blend_ms <= 0:
+    """Vector-issue fraction of the blend kernel from a committed PMC pass (profiles/): the wave-instructions of every class
+    (SQ_INSTS_VALU_* per launch; what no class counter claims — compares into scalar masks, selects, packed operations, moves —
+    is priced as "other") x the class's throughput cycles, over the 1024 SIMDs x clock x the LIVE launch time. Without the class
+    counters (an older pass): SQ_INSTS_VALU x the measured mean of the blend's own mix. The counters are per launch of the same
+    kernel on the same frame."""
+    if not pmc or blend_ms <= 0 or "SQ_INSTS_VALU" not in pmc:
         return {}
     clock_hz = float(pmc.get("clock_ghz", 2.4)) * 1e9
-    valu, salu = float(pmc["SQ_INSTS_VALU"]), float(pmc["SQ_INSTS_SALU"])
+    valu, salu = float(pmc["SQ_INSTS_VALU"]), float(pmc.get("SQ_INSTS_SALU", 0.0))
     avail = N_SIMD * clock_hz * blend_ms * 1e-3
-    return {"valu_frac": round(valu * 4.0 / avail, 4), "scalar_share": round(salu / max(valu + salu, 1.0), 4),
-            "valu_insts": int(valu), "salu_insts": int(salu), "clock_ghz": float(pmc.get("clock_ghz", 2.4)),
-            "valu_frac_formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x launch time); counters from the committed PMC pass, time live"}
+    classes = {c: sum(float(pmc.get(n, 0.0)) for n in names) for c, names in VALU_CLASS_COUNTERS.items()}
+    have_classes = any(n in pmc for names in VALU_CLASS_COUNTERS.values() for n in names)
+    if have_classes:
+        classes["other"] = max(0.0, valu - sum(classes.values()))
+        cycles = sum(classes[c] * VALU_CYCLES[c] for c in classes)
+        model = "sum over classes of SQ_INSTS_VALU_* x throughput cycles (VALU_CYCLES: profiles/r06_micro_valu_issue.txt)"
+    else:
+        cycles = valu * VALU_CYCLES["mix"]
+        model = "SQ_INSTS_VALU x 3.1 cycles, the measured throughput cost of the blend's instruction mix (profiles/r06_micro_valu_issue.txt)"
+    out = {"valu_frac": round(cycles / avail, 4), "valu_frac_one_wave": round(valu * 5.1 / avail, 4),
+           "scalar_share": round(salu / max(valu + salu, 1.0), 4), "valu_insts": int(valu), "salu_insts": int(salu),
+           "clock_ghz": float(pmc.get("clock_ghz", 2.4)),
+           "valu_frac_formula": model + " / (1024 SIMDs x clock x launch time); counters from the committed PMC pass, time live; "
+                                "valu_frac_one_wave: the same instructions at the 5.1 cycles a wave ALONE on its SIMD needs per instruction "
+                                "(no roofline: what the kernel would take if every wave ran alone)"}
+    if have_classes:
+        out["valu_classes"] = {c: int(v) for c, v in classes.items()}
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+        if k in pmc and pmc[k] is not None:
+            out[k.lower()] = float(pmc[k])
+    if pmc.get("SQ_WAVE_CYCLES"):
+        # (quad-cycles summed over the waves: waves resident per SIMD on average while the kernel runs; the kernels are built for five)
+        out["mean_waves_per_simd"] = round(float(pmc["SQ_WAVE_CYCLES"]) * 4.0 / avail, 3)
+    return out
 
 
 def main() -> int:
@@ -721,7 +755,7 @@ def main() -> int:
         # same command (profiles/): valid only for the default single-GPU workload they were taken on.
         traffic, traffic_src, blend_pmc = {}, None, {}
         if default_frame and not distributed:
-            tj, traffic_src = load_profile_json("pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json")
+            tj, traffic_src = load_profile_json("pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json")
             traffic = tj.get("blocks" if blocks else "sort", {})
             blend_pmc = tj.get("blend_insts", {})
 

@@ -156,6 +156,13 @@ constexpr uint64_t kBlockPlanMinInstances = 6;    // block plan from here on, so
 constexpr uint64_t kBlockFeedMinInstances = 48;   // a SERIAL blend reads the block lists from here on, the sorted lists below
 constexpr uint32_t kBigSplatTiles = 256;          // "a big splat" (16 x 16 tiles and more) for the plan's choice
 constexpr uint64_t kOverlapMinInstances = 16;     // the blend may run beside the emission (block-fed) from here on — when the tile times say it is the shorter of the two
+// A blend fed from the sorted lists gives EVERY tile four waves (deep tiles, blend.hip) below this many instances per visible
+// Gaussian: short lists of small splats, where a frame ends on the lone waves of its few deep tiles and four waves per tile
+// cost the others next to nothing. Blend, one wave per tile -> four, bench scene (`profiles/r06_deep_tiles.txt`): R/V = 3.6: 0.66 ->
+// 0.30 ms, 5.3: 0.54 -> 0.31, 7.3: 0.54 -> 0.43, 11: 0.60 -> 0.59, 16: 0.63 -> 0.66, 23: 0.46 -> 0.56 (long lists that few
+// records of survive: the walk is the work, and the four waves meet at a barrier every 256 entries of it). Above it the
+// history's slowest tiles only (tile_order_kernel).
+constexpr uint64_t kDeepAllMaxInstances = 12;
 constexpr size_t kMaxDefaultHistories = 8;        // streams per host thread and device that get a history of the library's own
 
 int tile_history_new(gsr_tile_history** out) {
@@ -267,6 +274,8 @@ struct EnvKnobs {
     bool tile_history;         // GSR_TILE_HISTORY=0: no call reads or writes a tile history
     int colors_beside;         // GSR_COLORS_BESIDE=0|1|2: geomState.rgb inside the preprocess / beside the depth sort / beside the blend; -1: by size
     int fused_depth;           // GSR_FUSED_DEPTH=0|1: the depth order with / without the compaction whatever the size; -1: by size
+    long block_feed_min;       // GSR_BLOCK_FEED_MIN=n: kBlockFeedMinInstances for this process (A/B runs); -1: the constant
+    long deep_all_max;         // GSR_DEEP_ALL_MAX=n: kDeepAllMaxInstances for this process (A/B runs); -1: the constant
 };
 const EnvKnobs& env_knobs() {
     static const EnvKnobs k = [] {
@@ -277,6 +286,10 @@ const EnvKnobs& env_knobs() {
         e.colors_beside = c && c[0] >= '0' && c[0] <= '2' ? c[0] - '0' : -1;
         const char* f = getenv("GSR_FUSED_DEPTH");
         e.fused_depth = f && (f[0] == '0' || f[0] == '1') ? f[0] - '0' : -1;
+        const char* b = getenv("GSR_BLOCK_FEED_MIN");
+        e.block_feed_min = b && b[0] ? atol(b) : -1;
+        const char* d = getenv("GSR_DEEP_ALL_MAX");
+        e.deep_all_max = d && d[0] ? atol(d) : -1;
         return e;
     }();
     return k;
@@ -977,7 +990,8 @@ int gsr_forward(gsr_forward_args* a) {
         // tile owns a few of a unit's 2048 entries and pays a round trip to memory per unit for them (the bench scene
         // from outside the cloud, R/V = 23: 0.65 against 0.45 ms; from far away, R/V = 5: 1.98 against 0.65 ms; bench
         // frame, R/V = 88: equal). With the sorted lists written anyway, sparse frames blend from them.
-        blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) && (uint64_t)R < kBlockFeedMinInstances * (uint64_t)nv;
+        blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) &&
+                           (uint64_t)R < (env.block_feed_min >= 0 ? (uint64_t)env.block_feed_min : kBlockFeedMinInstances) * (uint64_t)nv;
         if (history) hist->block_fed = !blend_from_lists;
         // (the emission stays on the caller's stream and is launched first: its persistent workgroups must be resident
         // before the blend's thousands of waves arrive — the other way round the blend takes every register file and the
@@ -1091,8 +1105,12 @@ int gsr_forward(gsr_forward_args* a) {
     }
     if (colors_late) { colors = a->shs; a->plan_used |= GSR_PLAN_COLORS_BESIDE; }
     // (deep tiles, blend.hip: the leading entries of an order sorted for THIS call; the block-fed blend has none)
-    const bool deep_wanted = t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES) && !(use_blocks && !blend_from_lists);
-    if (deep_wanted || ((a->flags & GSR_FLAG_DEEP_TILES_ALL) && !(use_blocks && !blend_from_lists))) a->plan_used |= GSR_PLAN_DEEP_TILES;
+    const bool list_fed = !(use_blocks && !blend_from_lists);
+    const bool deep_wanted = list_fed && t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES);
+    const bool deep_all = list_fed && ((a->flags & GSR_FLAG_DEEP_TILES_ALL) ||
+                                       (!(a->flags & GSR_FLAG_NO_DEEP_TILES) &&
+                                        (uint64_t)R < (env.deep_all_max >= 0 ? (uint64_t)env.deep_all_max : kDeepAllMaxInstances) * (uint64_t)nv));
+    if (deep_wanted || deep_all) a->plan_used |= GSR_PLAN_DEEP_TILES;
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)
         GSR_STEP(launch_blend_blocks(nv, d, R, gs.block_scratch, bin.values_unsorted, bin.sorting_space, img.ranges, geom.means2D,
@@ -1102,7 +1120,7 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
                               t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks, colors_late,
-                              deep_wanted ? hist->deep : nullptr, (a->flags & GSR_FLAG_DEEP_TILES_ALL) != 0));   // :804-810
+                              deep_wanted ? hist->deep : nullptr, deep_all));   // :804-810
     if (order_now) hist->order_serial = serial;               // (the blend that takes the order is in its stream: a backward of this call may take it too)
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is

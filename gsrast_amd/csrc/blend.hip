@@ -116,7 +116,10 @@ __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_pe
         entry = (int)blockIdx.x;
         if (entry >= deep_tiles) return;
     } else {
-        entry = deep_tiles + kGroupWaves * ((int)blockIdx.x - base) + wave;
+        // (the four waves of a workgroup take entries 8 apart: entries e and e + 8 were one XCD's when an entry was a workgroup
+        // of its own — the tiles of a 4 x 2 patch share their records in that XCD's L2, tile_of_workgroup)
+        const int g = (int)blockIdx.x - base;
+        entry = deep_tiles + 32 * (g >> 3) + 8 * wave + (g & 7);
         if (strips || p.deep_all || entry >= base) return;
     }
     const uint32_t clock_begin = tile_clock();
@@ -162,13 +165,16 @@ __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_pe
             const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
             if (lane == 0) s_count[0][wave] = kept;
         }
-        __syncthreads();
+        // (the barrier of a round waits for the wave's LDS traffic only — __syncthreads would also wait for the loads of the
+        // rounds to come, which are in flight on purpose)
+        auto round_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        round_barrier();
         for (uint32_t pos = 0, r = 0; pos < total; pos += kRound, ++r) {
             // (b1: round r + 1, its records on their way since the round before; b2: round r + 2, its ids)
-            const uint32_t kept = b1.valid ? stage_batch_deep(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
-            if (lane == 0) s_count[(r + 1u) & 1u][wave] = kept;
             fetch_records(b2, feed);
             const RecordBatch b3 = next_batch(pos + 3 * kRound + (uint32_t)(wave * kWave));
+            const uint32_t kept = b1.valid ? stage_batch_deep(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
+            if (lane == 0) s_count[(r + 1u) & 1u][wave] = kept;
             if (!my_done) {
 #pragma nounroll
                 for (int g = 0; g < kGroupWaves; ++g) {
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_pe
                     }
                 }
             }
-            __syncthreads();                            // round r is composited, round r + 1 staged, the flags are visible
+            round_barrier();                            // round r is composited, round r + 1 staged, the flags are visible
             if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
             b1 = b2;
             b2 = b3;
@@ -424,7 +430,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     p.nonempty = staged_counter ? nullptr : nonempty_tiles;
     p.base_workgroups = patch_workgroups(d.grid_x, d.row_end - d.row_begin);
     // workgroups [0, base): a deep tile each (or nothing); behind them the ordinary tiles, four to a workgroup
-    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups + (p.base_workgroups + kGroupWaves - 1) / kGroupWaves)),
+    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups + (p.base_workgroups + 31) / 32 * 8)),
                        dim3(kGroupWaves * kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;

@@ -23,11 +23,11 @@ RECORD_KEYS = ("workload", "splats", "num_rendered", "records_staged", "binning_
                "frame_alg_gbs", "parallelism", "rccl_ranks")
 
 
-def _run_bench(extra_env, *args):
+def _run_bench(extra_env, *args, splats="300000"):
     env = dict(os.environ, **extra_env)
     env.setdefault("MASTER_PORT", "29541")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
-                          "--splats", "300000", *args], capture_output=True, text=True, env=env, timeout=600)
+                          *(["--splats", splats] if splats else []), *args], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = out.stdout.strip().splitlines()[-1]
     return json.loads(line)
@@ -49,15 +49,28 @@ def test_single_gpu_line_has_the_contract_keys():
     # the driver's record keeps the first 24 keys of `config`, flat scalars only: everything measured must be among them
     assert len(cfg) <= 24, list(cfg)
     assert all(isinstance(v, (int, float, str, bool)) for v in cfg.values()), cfg
-    for k in RECORD_KEYS:
-        assert k in cfg, k
     assert list(cfg)[:8] == list(RECORD_KEYS[:8])
     # every frame rendered before the timed region is said in the line: spin-up + the counted frame + the warm-up steps
     assert cfg["untimed_frames"] == 16 + 1 + 2 == j["warmup_effective"] and j["detail"]["spinup_frames"] == 16
-    assert cfg["ms_median"] > 0 and cfg["ms_p99"] >= cfg["ms_median"] and cfg["path_ms_p99"] >= cfg["path_ms_p50"] > 0
+    assert cfg["ms_median"] > 0 and cfg["ms_p99"] >= cfg["ms_median"]
     j0 = _run_bench({}, "--spinup", "0", "--no-extras")
     assert j0["config"]["untimed_frames"] == 3 and j0["detail"]["spinup_frames"] == 0 and j0["steps"] == 3 and j0["warmup"] == 2
     assert len(j0["config"]) <= 24
+
+
+def test_the_default_workload_s_record_carries_every_measured_figure():
+    """The driver's command (the default workload, its extras included): every figure VERDICT r5 asked for is among the 24 keys
+    the driver's record keeps of `config`, as flat scalars, the headline frame's first."""
+    j = _run_bench({}, splats=None)
+    cfg = j["config"]
+    assert len(cfg) <= 24, list(cfg)
+    assert all(isinstance(v, (int, float, str, bool)) for v in cfg.values()), cfg
+    for k in RECORD_KEYS:
+        assert k in cfg, k
+    assert list(cfg)[:8] == list(RECORD_KEYS[:8])
+    assert cfg["splats"] == 5_834_784 and cfg["path_ms_p99"] >= cfg["path_ms_p50"] > 0 and cfg["ms_pose_far"] > 0
+    assert 0.0 < cfg["blend_valu_frac"] < 1.0
+    assert j["warmup_effective"] == cfg["untimed_frames"] == 16 + 1 + 2
 
 
 def test_sharded_path_forced_onto_one_rank():
