@@ -140,3 +140,49 @@ def test_bench_takes_a_scene_file_when_one_is_there(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["data"] == "synthetic" and "does not exist" in out.stderr
+
+
+@pytest.mark.gpu
+def test_full_size_scene_file_through_the_loader(tmp_path):
+    """BASELINE config 2's real code path at its size: 5 834 784 splats written as a reference-format file (1.45 GB, pre-activation
+    values: scripts/make_ply.py) -> gsr_ply_parse_header -> gsr_ply_activate -> forward. The loaded SoA against the CPU loader
+    (oracle/ply_oracle.py, SplatData.cpp:28-66) value by value: positions, SH and the normalised quaternions bit for bit,
+    exp / sigmoid within the device's expf (stated: 2 ulp of the result), and the frame of the loaded scene against the frame of the
+    very same SoA configured from host memory: bit for bit."""
+    import sys
+    import torch
+    from helpers import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import make_ply
+    from gsrast_amd import camera, scenes
+    from gsrast_amd.rasterizer import SplatRasterizer
+    n = 5_834_784
+    p = str(tmp_path / "trained_like.ply")
+    scene = scenes.trained_like(n, seed=45)
+    assert make_ply.scene_to_ply(p, scene) > n * 248
+    assert ply.parse_header(p)[0] == n
+    got = ply.load_ply(p)
+    want = ply_oracle.load(p)
+    for k in ("means3D", "shs", "rotations"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    for k in ("scales", "opacities"):
+        a, b = got[k].cpu().numpy(), want[k]
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        assert int(ulp.max()) <= 2, (k, int(ulp.max()))
+    del want
+    w, h = 1920, 1080
+    span = float((got["bbox_max"] - got["bbox_min"]).max().item())
+    cam = camera.default_camera(w, h, near=0.001 * span, far=span, position=(0.0, 0.0, -5.0))        # GSRastWindow.cpp:30-36
+    keys = ("means3D", "scales", "rotations", "opacities", "shs")
+    a = SplatRasterizer(w, h)
+    a.configure_from_scene({k: got[k] for k in keys})
+    ia = a.draw(cam).clone()
+    b = SplatRasterizer(w, h)
+    b.configure_from_scene({k: got[k].cpu().numpy() for k in keys})
+    ib = b.draw(cam)
+    assert a.last_num_rendered == b.last_num_rendered > 10_000_000
+    assert torch.equal(ia.view(torch.int32), ib.view(torch.int32))
+    # and the scene the file was written from is what came back: positions exactly, the activations through float32 log / exp
+    assert np.array_equal(got["means3D"].cpu().numpy(), scene["means3D"])
+    rel = np.abs(got["scales"].cpu().numpy()[:, :3] / scene["scales"][:, :3] - 1.0).max()
+    assert rel <= 2e-6, rel
