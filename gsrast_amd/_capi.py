@@ -152,6 +152,7 @@ SIGNATURES = {
     "gsr_tile_history_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "gsr_tile_history_destroy": (C.c_int, [C.c_void_p]),
     "gsr_tile_history_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "gsr_tile_history_forget_stream": (C.c_int, [C.c_void_p]),
     "gsr_tile_history_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]),
     "gsr_thread_release": (C.c_int, []),
     "gsr_device_shape": (None, [C.c_int, C.POINTER(C.c_uint32)]),

@@ -141,6 +141,7 @@ struct gsr_tile_history {
     bool block_fed = false;                   // ... and read the block lists (else the sorted lists: a tile's time then says less about the block-fed blend)
     uint32_t mean = 0, longest = 0;           // mean and longest tile time of the last statistics; mean 0: none yet for this size
     uint32_t calls = 0;                       // calls since the ticks were last cleared
+    uint32_t last_serial = 0;                 // the owning thread's call counter at its last use (the library's own histories: which to give up)
     bool used = false;
     hipStream_t last_stream = nullptr;        // the stream of the call that used it last: what orders two calls' kernels
     hipEvent_t ev_order = nullptr;            // "the order is sorted" (recorded on the library's second stream)
@@ -557,6 +558,14 @@ int gsr_tile_history_stats(const gsr_tile_history* h, uint32_t out[6]) {
     return fail(GSR_OK);
 }
 
+int gsr_tile_history_forget_stream(gsr_tile_history* h) {
+    g_hip_error[0] = 0;
+    if (!h || h->magic != kHistoryMagic) return fail(GSR_ERR_INVALID_ARG);
+    h->used = false;
+    h->last_stream = nullptr;
+    return fail(GSR_OK);
+}
+
 int gsr_tile_history_times(const gsr_tile_history* h, uint32_t* times, int count, uint32_t* deep_tiles) {
     g_hip_error[0] = 0;
     if (!h || h->magic != kHistoryMagic || !times || count < 0 || count > kTileOrderMax) return fail(GSR_ERR_INVALID_ARG);
@@ -689,13 +698,24 @@ int gsr_forward(gsr_forward_args* a) {
         } else {
             for (gsr_tile_history* h : g_rb.default_histories)
                 if (h->last_stream == stream) { hist = h; break; }
-            if (!hist && g_rb.default_histories.size() < kMaxDefaultHistories) {
+            if (!hist && g_rb.default_histories.size() >= kMaxDefaultHistories) {
+                // A ninth stream: the history this thread has not used for the longest time goes — its stream may be gone
+                // (a caller that makes a stream per frame), so nothing is asked of that stream: freeing the history's memory
+                // waits for the device to be done with it (hipFree). Rare by construction; before round 6 the calls on
+                // further streams simply ran without a history, for good.
+                size_t lru = 0;
+                for (size_t i = 1; i < g_rb.default_histories.size(); ++i)
+                    if ((int32_t)(g_rb.default_histories[i]->last_serial - g_rb.default_histories[lru]->last_serial) < 0) lru = i;
+                destroy_history(g_rb.default_histories[lru]);
+                g_rb.default_histories.erase(g_rb.default_histories.begin() + (long)lru);
+            }
+            if (!hist) {
                 // (a history is an accelerator: if the device has no memory left for one, the call runs without)
                 if (tile_history_new(&hist) == GSR_OK) g_rb.default_histories.push_back(hist);
                 else { hist = nullptr; (void)hipGetLastError(); g_hip_error[0] = 0; }
             }
         }
-        if (hist) { hist->last_stream = stream; hist->used = true; GSR_STEP(g_rb.ensure_side()); }       // (the stream the sort of the order runs on)
+        if (hist) { hist->last_stream = stream; hist->used = true; hist->last_serial = g_rb.serial; GSR_STEP(g_rb.ensure_side()); }       // (the stream the sort of the order runs on)
     }
     const bool history = hist != nullptr;
     // The order costs a launch on the second stream and the host a few microseconds, and it pays on frames that END on a

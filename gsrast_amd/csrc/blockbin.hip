@@ -894,14 +894,23 @@ int launch_block_binning(int n, const uint32_t* sorted_depth, const uint32_t* so
     // blocks can need), not on every call.
 #define GSR_STEP_LDS(kernel, chunk_)                                                                                          \
     do {                                                                                                                      \
-        static thread_local std::map<int, bool> asked;                                                                        \
+        static thread_local std::map<int, size_t> granted;   /* dynamic LDS this thread has been granted, per device */       \
         int dev_ = 0;                                                                                                         \
         GSR_HIP_TRY(hipGetDevice(&dev_));                                                                                     \
-        if (!asked[dev_]) {                                                                                                   \
+        if (granted[dev_] < mask_bytes) {                                                                                     \
+            /* the most a grid of kMaxBlocks blocks can need, so that no later frame asks again; a device that has not got */ \
+            /* that much is asked for what THIS frame needs, and only a frame that does not fit fails                     */ \
             const size_t most_ = ((size_t)kMaxBlocks * ((chunk_) / 32 + 1) * 2 + kMaxBlocks + kMaxBlocks + 3 * (size_t)(chunk_)) * 4; \
-            GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)(most_ < 160 * 1024 ? most_ : 160 * 1024)));                                 \
-            asked[dev_] = true;                                                                                               \
+            const size_t want_ = most_ < 160 * 1024 ? most_ : 160 * 1024;                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                    (int)want_) == hipSuccess) {                                                              \
+                granted[dev_] = want_;                                                                                        \
+            } else {                                                                                                          \
+                (void)hipGetLastError();                                                                                      \
+                GSR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                (int)mask_bytes));                                                            \
+                granted[dev_] = mask_bytes;                                                                                   \
+            }                                                                                                                 \
         }                                                                                                                     \
     } while (0)
     if (t.chunk == kCoarse) {

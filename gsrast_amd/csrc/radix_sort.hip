@@ -170,15 +170,21 @@ struct LookBack {
 // placement, MI355X_MICROARCH.md: speed only, never correctness), so each residue class r = blockIdx % 8 keeps a ticket
 // of its own and the j-th workgroup of class r to start takes position 8 j + r of a sequence in which every run of
 // kXcdRun consecutive TILES belongs to one class. Whatever the placement, every position below `tiles` is taken exactly
-// once (a class has as many workgroups as positions, the grid being at least `tiles` wide). No deadlock: a tile waits
-// only for tiles below it; the lowest unfinished tile, if nobody has taken it yet, is the next position of its class, and
-// the workgroups that can be waiting for it are those of ITS group of 8 kXcdRun tiles (earlier groups hold lower tiles,
-// all finished) — at most 7 kXcdRun of the chip's 512 slots — so the launch always has room to start it.
+// once (a class has as many workgroups as positions, the grid being at least `tiles` wide). No deadlock, GIVEN that the
+// device starts workgroups in the order of their numbers and has room for more than one group of them: a tile waits only
+// for tiles below it; the lowest unfinished tile, if nobody has taken it yet, is the next position of its class, and the
+// workgroups that can be waiting for it are those of ITS group of 8 kXcdRun tiles (earlier groups hold lower tiles, all
+// finished) — at most 7 kXcdRun of the chip's 512 slots — so the launch has room to start the next workgroups, one of
+// which is of that class. A device that cannot hold two such groups (fewer than 64 compute units at two workgroups each:
+// a partition, a CU mask) gets the single ticket instead (`single`: tile = ticket, progress under ANY placement — a
+// workgroup that holds a ticket is running, and the lowest ticket never waits); the launcher decides from the CU count.
+// Every spin is bounded either way: a placement nobody foresaw raises GSR_ERR_INTERNAL instead of hanging.
 #ifndef GSR_XCD_RUN
 #define GSR_XCD_RUN 8
 #endif
 constexpr uint32_t kXcdRun = GSR_XCD_RUN;
-__device__ __forceinline__ uint32_t take_tile(uint32_t* ticket, uint32_t tiles) {
+__device__ __forceinline__ uint32_t take_tile(uint32_t* ticket, uint32_t tiles, bool single) {
+    if (single) return atomicAdd(ticket, 1u);
     const uint32_t r = blockIdx.x & 7u;
     const uint32_t j = atomicAdd(ticket + r, 1u);
     const uint32_t pos = 8u * j + r;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_SO
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (threadIdx.x == 0) {
-        s_tile = take_tile(ticket, (n + (uint32_t)kSortTile - 1u) / (uint32_t)kSortTile);
+        s_tile = take_tile(ticket, (n + (uint32_t)kSortTile - 1u) / (uint32_t)kSortTile, spec.single_ticket != 0u);
         s_fail = 0;
     }
     if (threadIdx.x < RADIX) {
@@ -453,11 +459,21 @@ inline int radix_bits_for(uint32_t nbins) {
     return bits < 4 ? 4 : bits;
 }
 
+// (two workgroups of eight waves a CU; the XCD runs want room for two groups of 8 kXcdRun workgroups: take_tile)
+bool xcd_runs_fit(int cus) { return 2u * (uint32_t)cus >= 2u * 8u * kXcdRun; }
+
 template <typename KeyT>
 int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
-                const DigitSpec& spec, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
+                const DigitSpec& spec_in, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
                 bool already_cleared, const uint32_t* n_dev = nullptr, const uint32_t* vals2_in = nullptr,
                 uint32_t* vals2_out = nullptr, const DropSpec* drop = nullptr) {
+    DigitSpec spec = spec_in;
+    {
+        DeviceShape shape;
+        const int rc = current_device_shape(&shape);
+        if (rc != GSR_OK) return rc;
+        spec.single_ticket = xcd_runs_fit(shape.cus) ? 0u : 1u;
+    }
     const int bits = radix_bits_for(spec.nbins);
     if (bits > 8) return GSR_ERR_INVALID_ARG;
     const uint32_t tiles = (n + kSortTile - 1) / kSortTile;

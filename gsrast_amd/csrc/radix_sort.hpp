@@ -18,6 +18,7 @@ struct DigitSpec {
     uint32_t nbins;      // <= 256
     uint32_t grid_x;
     float inv_grid_x;
+    uint32_t single_ticket = 0;   // set by the launcher: tiles are handed out by ONE ticket (a device too small for the XCD runs, take_tile)
 };
 
 struct SweepScratch {

@@ -161,9 +161,10 @@ enum {
  * rasterizer object, an eye of a stereo pair) — or, when that is NULL, one the library keeps per host thread, device and
  * STREAM of the call (at most eight streams per thread and device; calls on further streams run without). A history
  * belongs to the stream of the call that used it last: kernels of two calls that share a history are ordered by that
- * stream alone, so calls on different streams never share a default history, and a caller who moves its own history to
- * another stream must have ordered that stream behind the last call's (the library adds an event wait when it sees the
- * switch, if the old stream still exists). A history whose frames stop resembling each other — a trainer that draws an
+ * stream alone, so calls on different streams never share a default history (a ninth stream takes over the history the
+ * thread has not used for the longest time). A caller who moves its OWN history to another stream: the library orders the
+ * new stream behind the old one's work by an event it records on the OLD stream at that moment — which must therefore
+ * still exist; a caller that has destroyed it (after waiting for it) says so first: gsr_tile_history_forget_stream. A history whose frames stop resembling each other — a trainer that draws an
  * unrelated camera every call, two views alternating on one history — is noticed (the two last frames' tile times are
  * compared when the order is sorted: each tile's SHARE of its frame's total tile time, the smaller of its two shares summed
  * over the tiles, below 0.8) and the order is dropped, patch order as without a history, until they do again: plan_used
@@ -208,6 +209,10 @@ int gsr_tile_history_destroy(gsr_tile_history* history);
  * [4] = calls since the history was last cleared (a new size), [5] = 1 if the last block-plan call ran its blend beside the
  * emission. */
 int gsr_tile_history_stats(const gsr_tile_history* history, uint32_t out[6]);
+
+/* The stream the history's last call ran on is gone (the caller waited for it and destroyed it): the next call with this
+ * history, on whatever stream, is not ordered behind it. Host side only. */
+int gsr_tile_history_forget_stream(gsr_tile_history* history);
 
 /* For tools and tests: the tile times the history's LAST call recorded, times[tile] for the first `count` tiles of the frame
  * (row-major tile index) in units of 10 ns — bit 31 set: the tile was composited by four waves (a deep tile) —, and in

@@ -147,7 +147,8 @@ def test_full_size_scene_file_through_the_loader(tmp_path):
     """BASELINE config 2's real code path at its size: 5 834 784 splats written as a reference-format file (1.45 GB, pre-activation
     values: scripts/make_ply.py) -> gsr_ply_parse_header -> gsr_ply_activate -> forward. The loaded SoA against the CPU loader
     (oracle/ply_oracle.py, SplatData.cpp:28-66) value by value: positions, SH and the normalised quaternions bit for bit,
-    exp / sigmoid within the device's expf (stated: 2 ulp of the result), and the frame of the loaded scene against the frame of the
+    exp / sigmoid within the device's expf (stated: scales within 2 ulp of the CPU loader's, opacities — 1 / (1 + e) of it —
+    within 4), and the frame of the loaded scene against the frame of the
     very same SoA configured from host memory: bit for bit."""
     import sys
     import torch
@@ -168,7 +169,7 @@ def test_full_size_scene_file_through_the_loader(tmp_path):
     for k in ("scales", "opacities"):
         a, b = got[k].cpu().numpy(), want[k]
         ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
-        assert int(ulp.max()) <= 2, (k, int(ulp.max()))
+        assert int(ulp.max()) <= (2 if k == "scales" else 4), (k, int(ulp.max()))
     del want
     w, h = 1920, 1080
     span = float((got["bbox_max"] - got["bbox_min"]).max().item())
