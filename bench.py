@@ -326,6 +326,7 @@ class Runner:
         per_step = np.diff(np.asarray(stamps)) * 1e3
         out["ms_median"], out["ms_p99"] = float(np.median(per_step)), float(np.percentile(per_step, 99))
         out["tiles_reordered"] = bool(rast.last_tiles_reordered)
+        out["deep_tiles"] = bool(getattr(rast, "last_deep_tiles", False))
         out["emit_overlapped"] = bool(rast.last_emit_overlapped)
         out["colors_beside"] = bool(rast.last_colors_beside)
         # Per-stage device times come from extra, untimed frames with GSR_FLAG_PROFILE (HIP events around
@@ -747,7 +748,8 @@ def main() -> int:
         dom = max(("sort_pass1", "sort_pass2", "blend", "duplicate", "preprocess", "ranges"), key=lambda k: stage_ms.get(k, 0.0))
         dom_names = {"sort_pass1": "onesweep_kernel<u64> (tile-column digit pass)",
                      "sort_pass2": "onesweep_kernel<u64> (tile-row digit pass)",
-                     "blend": "blend_blocks_kernel" if blocks and not m["blend_from_lists"] else "blend_wave_kernel",
+                     "blend": ("blend_blocks_kernel" if blocks and not m["blend_from_lists"] else
+                               ("blend_deep_kernel (four waves per tile)" if m.get("deep_tiles") else "blend_wave_kernel")),
                      "duplicate": "block_emit_kernel (sorted lists written directly)" if blocks else "emit_chunk_kernel",
                      "preprocess": "preprocess_inria_kernel" if inria else "preprocess_kernel", "ranges": "tile_ranges_search_kernel"}
 
@@ -803,7 +805,7 @@ def main() -> int:
                        "sorted_lists_written": m["lists_written"], "blend_from_sorted_lists": m["blend_from_lists"],
                        "slow_tiles_first": m.get("tiles_reordered", False), "emit_overlapped": m.get("emit_overlapped", False),
                        "colors_beside_depth_sort": m.get("colors_beside", False), "spinup_frames": max(0, int(args.spinup)),
-                       "deep_tiles": m.get("deep_tiles", 0),
+                       "deep_tiles": m.get("deep_tiles", False),
                        "band_exchange": ({"transport": run.exch.transport, "gather": args.gather, "note": run.exch.transport_note}
                                          if distributed else None),
                        "bands": m["bands"], "per_rank": m["per_rank"]},
@@ -813,9 +815,9 @@ def main() -> int:
                                                     "alone: the serial_emit entry)" if m.get("colors_beside") and n_splats <= (1 << 24) else ""),
                                   "sort_pass1": "unit masks + prefixes + tile ranges",
                                   "duplicate": "block_emit_kernel (the sorted keys / values)",
-                                  "blend": "blend_wave_kernel (from the sorted lists)" if m["blend_from_lists"] else "blend_blocks_kernel"} if blocks else
+                                  "blend": (("blend_deep_kernel" if m.get("deep_tiles") else "blend_wave_kernel") + " (from the sorted lists)") if m["blend_from_lists"] else "blend_blocks_kernel"} if blocks else
                                  {"depth_order": "visible-key compaction + depth sort + column counts / scan", "duplicate": "emit_chunk_kernel",
-                                  "sort_pass2": "onesweep pass on the tile row", "blend": "blend_wave_kernel"}),
+                                  "sort_pass2": "onesweep pass on the tile row", "blend": "blend_deep_kernel" if m.get("deep_tiles") else "blend_wave_kernel"}),
             "stage_ms_source": (f"HIP events recorded by the library on the launching stream (GSR_FLAG_PROFILE) over {m['prof_steps']} "
                                 f"frames of the same workload run right after the timed region; those frames took "
                                 f"{m['profiled_ms_per_step']:.4f} ms each with the events in place"),
@@ -902,6 +904,7 @@ def brief(e, n_splats, what):
             "msplats_per_s": round(n_splats / (e["ms_per_step"] * 1e-3) / 1e6, 3), "num_rendered": e["num_rendered_total"],
             "records_staged": e["records_staged_total"], "visible": e["visible"], "binning_plan": e["plan"],
             "blend_from_sorted_lists": e["blend_from_lists"], "slow_tiles_first": e.get("tiles_reordered", False),
+            "deep_tiles": e.get("deep_tiles", False),
             "emit_overlapped": e.get("emit_overlapped", False), "colors_beside_depth_sort": e.get("colors_beside", False),
             "sorted_lists_written": e["lists_written"], "stage_ms": {k: round(v, 4) for k, v in e["stage_ms"].items() if v > 0}}
 

@@ -206,7 +206,11 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
+            fn = getattr(L, name, None)
+            if fn is None and _TAG:
+                continue                       # (a tagged A/B build of an older tree may lack the newest entry points)
+            if fn is None:
+                raise RuntimeError(f"{LIB_PATH} does not export {name}: rebuild it (python -m gsrast_amd.build)")
             fn.restype = res
             fn.argtypes = args
         _lib = L

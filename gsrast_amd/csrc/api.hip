@@ -161,8 +161,8 @@ constexpr uint64_t kOverlapMinInstances = 16;     // the blend may run beside th
 // Gaussian: short lists of small splats, where a frame ends on the lone waves of its few deep tiles and four waves per tile
 // cost the others next to nothing. Blend, one wave per tile -> four, bench scene (`profiles/r06_deep_tiles.txt`): R/V = 3.6: 0.66 ->
 // 0.30 ms, 5.3: 0.54 -> 0.31, 7.3: 0.54 -> 0.43, 11: 0.60 -> 0.59, 16: 0.63 -> 0.66, 23: 0.46 -> 0.56 (long lists that few
-// records of survive: the walk is the work, and the four waves meet at a barrier every 256 entries of it). Above it the
-// history's slowest tiles only (tile_order_kernel).
+// records of survive: the walk is the work, and the four waves meet at a barrier every 256 entries of it). Above it: one
+// wave per tile (four for the history's slowest tiles only was built and measured neutral there: GSR_DEEP_BY_HISTORY).
 constexpr uint64_t kDeepAllMaxInstances = 12;
 constexpr size_t kMaxDefaultHistories = 8;        // streams per host thread and device that get a history of the library's own
 
@@ -277,6 +277,8 @@ struct EnvKnobs {
     int fused_depth;           // GSR_FUSED_DEPTH=0|1: the depth order with / without the compaction whatever the size; -1: by size
     long block_feed_min;       // GSR_BLOCK_FEED_MIN=n: kBlockFeedMinInstances for this process (A/B runs); -1: the constant
     long deep_all_max;         // GSR_DEEP_ALL_MAX=n: kDeepAllMaxInstances for this process (A/B runs); -1: the constant
+    bool deep_by_history;      // GSR_DEEP_BY_HISTORY=1: above that, the history's slowest tiles get four waves (tile_order_kernel's
+                               // count; measured neutral, `profiles/r06_deep_tiles.txt`: off by default)
 };
 const EnvKnobs& env_knobs() {
     static const EnvKnobs k = [] {
@@ -291,6 +293,8 @@ const EnvKnobs& env_knobs() {
         e.block_feed_min = b && b[0] ? atol(b) : -1;
         const char* d = getenv("GSR_DEEP_ALL_MAX");
         e.deep_all_max = d && d[0] ? atol(d) : -1;
+        const char* dh = getenv("GSR_DEEP_BY_HISTORY");
+        e.deep_by_history = dh && dh[0] == '1';
         return e;
     }();
     return k;
@@ -1126,7 +1130,7 @@ int gsr_forward(gsr_forward_args* a) {
     if (colors_late) { colors = a->shs; a->plan_used |= GSR_PLAN_COLORS_BESIDE; }
     // (deep tiles, blend.hip: the leading entries of an order sorted for THIS call; the block-fed blend has none)
     const bool list_fed = !(use_blocks && !blend_from_lists);
-    const bool deep_wanted = list_fed && t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES);
+    const bool deep_wanted = env.deep_by_history && list_fed && t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES);
     const bool deep_all = list_fed && ((a->flags & GSR_FLAG_DEEP_TILES_ALL) ||
                                        (!(a->flags & GSR_FLAG_NO_DEEP_TILES) &&
                                         (uint64_t)R < (env.deep_all_max >= 0 ? (uint64_t)env.deep_all_max : kDeepAllMaxInstances) * (uint64_t)nv));

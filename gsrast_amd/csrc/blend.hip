@@ -90,37 +90,53 @@ constexpr uint32_t kDeepGainX16 = 40;            // a deep tile takes 1 / 2.5 of
 constexpr uint32_t kDeepFracX16 = 6;             // deep from 3/8 of the longest estimate
 constexpr uint32_t kDeepFloorTicks = 4000;       // ... but never below 40 us
 constexpr uint32_t kDeepFlag = 0x80000000u;      // in a tile's recorded time: it was composited by four waves
-__global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) {
+// MODE 0, blend_wave_kernel: the launch of the frames that have no use for deep tiles (the host knows: launch_blend) — a workgroup is ONE
+// wave and one tile, instruction for instruction the kernel of the rounds before (the workgroups of four hold their LDS and
+// their place until the slowest of their four tiles is through: 3-8 % of the blend at 13-21 instances per visible Gaussian).
+// MODE 2, blend_deep_kernel: EVERY tile of the launch is a deep one (the host decides: launch_blend) — no ordinary tile's
+// registers to carry (one pixel per lane: 64 of them instead of 96), one staging area instead of two (13 KB of LDS instead of
+// 27: a second barrier a round), so that eight of these workgroups fit a CU where five of the mixed kind do: at 4.8 waves per
+// SIMD the mixed kernel kept the vector pipes busy half of the time (`profiles/r06_deep_tiles.txt`).
+enum { kBlendSingle = 0, kBlendGrouped = 1, kBlendDeepOnly = 2 };
+template <int MODE>
+__device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
+    constexpr bool GROUPED = MODE != kBlendSingle, DEEP_ONLY = MODE == kBlendDeepOnly;
+    constexpr int kWavesHere = GROUPED ? kGroupWaves : 1;
+    constexpr uint32_t kBuffers = DEEP_ONLY ? 1u : 2u;
     // (one area, two uses: a wave's own staging records in the ordinary mode; two rounds of four segments in the deep one)
-    constexpr size_t kStageBytes = sizeof(DeepSegment) * 2 * kGroupWaves > sizeof(StagedRecords) * kGroupWaves ? sizeof(DeepSegment) * 2 * kGroupWaves
-                                                                                                            : sizeof(StagedRecords) * kGroupWaves;
+    constexpr size_t kStageBytes = !GROUPED ? sizeof(StagedRecords)
+                                   : DEEP_ONLY ? sizeof(DeepSegment) * kGroupWaves
+                                   : (sizeof(DeepSegment) * 2 * kGroupWaves > sizeof(StagedRecords) * kGroupWaves ? sizeof(DeepSegment) * 2 * kGroupWaves
+                                                                                                                : sizeof(StagedRecords) * kGroupWaves);
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[kStageBytes];
-    __shared__ unsigned long long s_exp[kGroupWaves][32];  // exp_ref's table, a copy per wave
-    __shared__ uint32_t s_count[2][kGroupWaves];           // deep: survivors per segment of a round
-    __shared__ uint32_t s_done[kGroupWaves], s_done_at[kGroupWaves];   // deep: strip finished, and on which record
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;     // (wave: a scalar)
+    __shared__ unsigned long long s_exp[kWavesHere][32];   // exp_ref's table, a copy per wave
+    __shared__ uint32_t s_count[2][kWavesHere];            // deep: survivors per segment of a round
+    __shared__ uint32_t s_done[kWavesHere], s_done_at[kWavesHere];     // deep: strip finished, and on which record
+    const int wave = GROUPED ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0, lane = (int)threadIdx.x & 63;     // (wave: a scalar)
     unsigned long long* const exp_tab = s_exp[wave];
     exp_table_init(exp_tab, lane);           // (written and read by that wave only)
 
     bool strips = false, prioritise = false;
     if (p.nonempty != nullptr) {
         const uint32_t ne = *p.nonempty;
-        strips = ne <= kStripTilesAny || (ne <= kStripTilesShort && (unsigned long long)p.num_rendered <= (unsigned long long)kStripMeanList * ne);
+        strips = GROUPED && (ne <= kStripTilesAny || (ne <= kStripTilesShort && (unsigned long long)p.num_rendered <= (unsigned long long)kStripMeanList * ne));
         prioritise = !strips && (unsigned long long)p.num_rendered >= (unsigned long long)kPriorityMeanList * ne;    // (see set_tile_priority)
     }
     const int base = p.base_workgroups;
-    const int deep_tiles = (strips || p.deep_all) ? base : (p.deep_count ? (int)min(*p.deep_count, (uint32_t)base) : 0);
-    const bool deep = (int)blockIdx.x < base;
-    int entry;
-    if (deep) {
-        entry = (int)blockIdx.x;
-        if (entry >= deep_tiles) return;
-    } else {
-        // (the four waves of a workgroup take entries 8 apart: entries e and e + 8 were one XCD's when an entry was a workgroup
-        // of its own — the tiles of a 4 x 2 patch share their records in that XCD's L2, tile_of_workgroup)
-        const int g = (int)blockIdx.x - base;
-        entry = deep_tiles + 32 * (g >> 3) + 8 * wave + (g & 7);
-        if (strips || p.deep_all || entry >= base) return;
+    bool deep = false;
+    int entry = (int)blockIdx.x;
+    if constexpr (GROUPED) {
+        const int deep_tiles = (DEEP_ONLY || strips || p.deep_all) ? base : (p.deep_count ? (int)min(*p.deep_count, (uint32_t)base) : 0);
+        deep = (int)blockIdx.x < base;
+        if (deep) {
+            if (entry >= deep_tiles) return;
+        } else {
+            // (the four waves of a workgroup take entries 8 apart: entries e and e + 8 were one XCD's when an entry was a workgroup
+            // of its own — the tiles of a 4 x 2 patch share their records in that XCD's L2, tile_of_workgroup)
+            const int g = (int)blockIdx.x - base;
+            entry = deep_tiles + 32 * (g >> 3) + 8 * wave + (g & 7);
+            if (strips || p.deep_all || entry >= base) return;
+        }
     }
     const uint32_t clock_begin = tile_clock();
     const int tile_local = tile_of_workgroup(p.history.order ? (int)p.history.order[entry] : entry, p.dims.grid_x, p.dims.row_end - p.dims.row_begin);
@@ -147,53 +163,71 @@ __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_pe
         }
         return nb;
     };
-    if (deep) {
+    if constexpr (GROUPED) if (deep) {
         constexpr uint32_t kRound = kGroupWaves * kWave;
-        DeepSegment (*const segs)[kGroupWaves] = reinterpret_cast<DeepSegment (*)[kGroupWaves]>(s_stage);      // [round & 1][wave]
+        DeepSegment (*const segs)[kGroupWaves] = reinterpret_cast<DeepSegment (*)[kGroupWaves]>(s_stage);      // [round & 1][wave] (one area in the deep-only kernel)
         StripLanes s;
         strip_lanes_init(s, tx, ty, wave, lane, p.dims.width, p.dims.height);
         bool my_done = strip_lanes_all_done(s);            // (a strip below the image: finished from the start)
         if (lane == 0) { s_done[wave] = my_done ? 1u : 0u; s_done_at[wave] = 0u; }
-        // Round r: stage r + 1 into the other half of the area (everybody left round r - 1, which read it, through the barrier
-        // before), composite r, one barrier.
-        RecordBatch b0 = next_batch((uint32_t)(wave * kWave));
-        fetch_records(b0, feed);
-        RecordBatch b1 = next_batch(kRound + (uint32_t)(wave * kWave));
-        fetch_records(b1, feed);
-        RecordBatch b2 = next_batch(2 * kRound + (uint32_t)(wave * kWave));
-        {
-            const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
-            if (lane == 0) s_count[0][wave] = kept;
-        }
         // (the barrier of a round waits for the wave's LDS traffic only — __syncthreads would also wait for the loads of the
         // rounds to come, which are in flight on purpose)
         auto round_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-        round_barrier();
-        for (uint32_t pos = 0, r = 0; pos < total; pos += kRound, ++r) {
-            // (b1: round r + 1, its records on their way since the round before; b2: round r + 2, its ids)
-            fetch_records(b2, feed);
-            const RecordBatch b3 = next_batch(pos + 3 * kRound + (uint32_t)(wave * kWave));
-            const uint32_t kept = b1.valid ? stage_batch_deep(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
-            if (lane == 0) s_count[(r + 1u) & 1u][wave] = kept;
-            if (!my_done) {
+        auto composite_round = [&](uint32_t half) {
 #pragma nounroll
-                for (int g = 0; g < kGroupWaves; ++g) {
-                    const uint32_t cnt = s_count[r & 1u][g];
-                    if (cnt == 0u) continue;
-                    const DeepSegment& seg = segs[r & 1u][g];
-                    const unsigned long long slots = __ballot((uint32_t)lane < cnt && ((seg.touch[lane] >> wave) & 1u) != 0u);
-                    uint32_t at = 0;
-                    if (slots != 0ull && composite_strip(s, seg, slots, feed.t_cutoff, exp_tab, &at)) {
-                        my_done = true;
-                        if (lane == 0) { s_done[wave] = 1u; s_done_at[wave] = at; }
-                        break;
-                    }
+            for (int g = 0; g < kGroupWaves; ++g) {
+                const uint32_t cnt = s_count[half][g];
+                if (cnt == 0u) continue;
+                const DeepSegment& seg = segs[half][g];
+                const unsigned long long slots = __ballot((uint32_t)lane < cnt && ((seg.touch[lane] >> wave) & 1u) != 0u);
+                uint32_t at = 0;
+                if (slots != 0ull && composite_strip(s, seg, slots, feed.t_cutoff, exp_tab, &at)) {
+                    my_done = true;
+                    if (lane == 0) { s_done[wave] = 1u; s_done_at[wave] = at; }
+                    break;
                 }
             }
-            round_barrier();                            // round r is composited, round r + 1 staged, the flags are visible
-            if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
-            b1 = b2;
-            b2 = b3;
+        };
+        RecordBatch b0 = next_batch((uint32_t)(wave * kWave));
+        fetch_records(b0, feed);
+        RecordBatch b1 = next_batch(kRound + (uint32_t)(wave * kWave));
+        if constexpr (kBuffers == 1u) {
+            // one staging area: stage round r, barrier, composite it, barrier (b0: round r, its records there; b1: round r + 1, its ids)
+            round_barrier();                             // (the flags above)
+            for (uint32_t pos = 0; pos < total; pos += kRound) {
+                fetch_records(b1, feed);
+                const RecordBatch b2 = next_batch(pos + 2 * kRound + (uint32_t)(wave * kWave));
+                const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
+                if (lane == 0) s_count[0][wave] = kept;
+                round_barrier();                         // the round's four segments are staged
+                if (!my_done) composite_round(0u);
+                round_barrier();                         // everybody is through with them; the flags of this round are visible
+                if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
+                b0 = b1;
+                b1 = b2;
+            }
+        } else {
+            // Round r: stage r + 1 into the other half of the area (everybody left round r - 1, which read it, through the
+            // barrier before), composite r, one barrier.
+            fetch_records(b1, feed);
+            RecordBatch b2 = next_batch(2 * kRound + (uint32_t)(wave * kWave));
+            {
+                const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
+                if (lane == 0) s_count[0][wave] = kept;
+            }
+            round_barrier();
+            for (uint32_t pos = 0, r = 0; pos < total; pos += kRound, ++r) {
+                // (b1: round r + 1, its records on their way since the round before; b2: round r + 2, its ids)
+                fetch_records(b2, feed);
+                const RecordBatch b3 = next_batch(pos + 3 * kRound + (uint32_t)(wave * kWave));
+                const uint32_t kept = b1.valid ? stage_batch_deep(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
+                if (lane == 0) s_count[(r + 1u) & 1u][wave] = kept;
+                if (!my_done) composite_round(r & 1u);
+                round_barrier();                            // round r is composited, round r + 1 staged, the flags are visible
+                if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
+                b1 = b2;
+                b2 = b3;
+            }
         }
         strip_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
         if (wave == 0 && lane == 0) {
@@ -208,6 +242,7 @@ __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_pe
         }
         return;
     }
+    if constexpr (!DEEP_ONLY) {
     StagedRecords& mine = reinterpret_cast<StagedRecords*>(s_stage)[wave];
     TileLanes s;
     tile_lanes_init(s, tx, ty, lane, p.dims.width, p.dims.height, -1);
@@ -234,7 +269,13 @@ __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_pe
     tile_lanes_write(s, p.dims.width, p.dims.height, p.background, p.final_t, p.n_contrib, p.out_color);
     if (p.staged_counter && lane == 0) atomicAdd(p.staged_counter, staged);
     if (p.history.ticks && lane == 0) p.history.ticks[tile] = (tile_clock() - clock_begin) & ~kDeepFlag;
+    }
 }
+
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) { blend_wave_body<kBlendSingle>(p); }
+__global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_group_kernel(const BlendParams p) { blend_wave_body<kBlendGrouped>(p); }
+__global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(8))) void blend_deep_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly>(p); }
+
 
 // Workgroup numbers of the patch order, the SLOW tiles of the frame before first — those that took more than twice the
 // mean, longest first — and everybody else behind them in patch order: one workgroup, a bitonic sort of (class, workgroup)
@@ -325,7 +366,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
     const uint32_t deep_class = quantise_ticks((uint32_t)min(deep_from, 0x7FFFFFFFull));
     // what the host decides on whether the next calls need an order at all: {fresh, longest tile, mean, similarity, dropped}
     if (stats && threadIdx.x == 0) {
-        stats[1] = s_max; stats[2] = (uint32_t)(s_sum / max(s_cnt, 1u)); stats[3] = similarity; stats[4] = dropped ? 1u : 0u;
+        // (longest and mean in ONE-WAVE terms — a deep tile's time times the gain —: what the host's estimates of a blend's
+        // length are calibrated in, whichever way the frame before was composited)
+        stats[1] = s_max_est; stats[2] = (uint32_t)(s_est / max(s_cnt, 1u)); stats[3] = similarity; stats[4] = dropped ? 1u : 0u;
         __threadfence_system();
         stats[0] = 1u;
     }
@@ -429,9 +472,19 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     // (not when the staged records are counted: that count is per tile, the reference's "whole tile done" test)
     p.nonempty = staged_counter ? nullptr : nonempty_tiles;
     p.base_workgroups = patch_workgroups(d.grid_x, d.row_end - d.row_begin);
-    // workgroups [0, base): a deep tile each (or nothing); behind them the ordinary tiles, four to a workgroup
-    hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)(p.base_workgroups + (p.base_workgroups + 31) / 32 * 8)),
-                       dim3(kGroupWaves * kWave), 0, stream, p);
+    // Deep tiles are possible when the host asks for them (deep_all), when the history may name some, or when the frame may
+    // turn out to have few tiles with a list (the kernel's `strips`: at most 1 536 tiles, or lists of 1 024 entries on 4 096):
+    // workgroups [0, base) then take a deep tile each (or nothing), and behind them come the ordinary tiles, four to a
+    // workgroup. Every other frame is launched a wave per workgroup, as ever.
+    const bool few_tiles = p.nonempty != nullptr && ((uint32_t)p.num_tiles <= kStripTilesAny ||
+                                                     (unsigned long long)num_rendered <= (unsigned long long)kStripMeanList * kStripTilesShort);
+    if (p.deep_all)
+        hipLaunchKernelGGL(blend_deep_kernel, dim3((unsigned)p.base_workgroups), dim3(kGroupWaves * kWave), 0, stream, p);
+    else if (p.deep_count || few_tiles)
+        hipLaunchKernelGGL(blend_group_kernel, dim3((unsigned)(p.base_workgroups + (p.base_workgroups + 31) / 32 * 8)),
+                           dim3(kGroupWaves * kWave), 0, stream, p);
+    else
+        hipLaunchKernelGGL(blend_wave_kernel, dim3((unsigned)p.base_workgroups), dim3(kWave), 0, stream, p);
     GSR_LAUNCH_CHECK("blend_wave_kernel");
     return GSR_OK;
 }

@@ -176,13 +176,14 @@ enum {
  * call of the process). Frames of more than 32 768 tiles (beyond 3840 x 2160) keep no tile times either: the order is
  * sorted by one workgroup in LDS. */
 #define GSR_FLAG_NO_TILE_HISTORY 0x80u
-/* Deep tiles (csrc/blend.hip). A blend fed from the sorted lists gives the tiles its history expects to be the slowest of
- * the frame a workgroup of FOUR waves each: the waves walk the tile's list together (one fetch, one footprint test per
- * entry) and composite one 16 x 4 strip each — a wave alone on its SIMD issues a vector instruction every five cycles, and
- * a frame lasts as long as its slowest tile. Same pixels, finalT, nContrib, records_staged: every pixel sees the same
- * records in the same order. Which tiles: decided on the device when the order is sorted (see above), so only calls that
- * use a history's order have any (plan_used: GSR_PLAN_DEEP_TILES). GSR_FLAG_NO_DEEP_TILES: none, whatever the history says;
- * GSR_FLAG_DEEP_TILES_ALL: every tile (a diagnostic, and what the tests compare the ordinary way against). */
+/* Deep tiles (csrc/blend.hip). A blend fed from the sorted lists may give a tile a workgroup of FOUR waves: they walk the
+ * tile's list together (one fetch, one footprint test per entry) and composite one 16 x 4 strip each — a wave alone on its
+ * SIMD issues a vector instruction every five cycles where the SIMD takes one every two or three, and a frame of small
+ * splats lasts as long as the lone waves of its few deep tiles. Same pixels, finalT, nContrib, records_staged: every pixel
+ * sees the same records in the same order. By default every tile of a frame with fewer than 12 instances per visible
+ * Gaussian is composited that way (and every tile of a call with few tiles: a rank's band of a sharded frame); plan_used
+ * then carries GSR_PLAN_DEEP_TILES. GSR_FLAG_NO_DEEP_TILES: never; GSR_FLAG_DEEP_TILES_ALL: whatever the frame (a
+ * diagnostic, and what the tests compare the ordinary way against). Neither reads nor needs a tile history. */
 #define GSR_FLAG_NO_DEEP_TILES 0x200u
 #define GSR_FLAG_DEEP_TILES_ALL 0x400u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
@@ -195,8 +196,8 @@ enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wid
        GSR_PLAN_COLORS_BESIDE = 0x1000 /* or-ed in: geomState.rgb was written beside the scan / depth sort (or the blend), not by the preprocess */,
        GSR_PLAN_TILE_ORDER_DROPPED = 0x2000 /* or-ed in: the history's last frames did not resemble each other (another view
                                                every call): the blend took the patch order (informational) */,
-       GSR_PLAN_DEEP_TILES = 0x4000 /* or-ed in: the blend was launched with deep tiles enabled — how many tiles got four
-                                       waves was decided on the device (see GSR_FLAG_NO_DEEP_TILES; informational) */ };
+       GSR_PLAN_DEEP_TILES = 0x4000 /* or-ed in: the blend composited its tiles by four waves each (see GSR_FLAG_NO_DEEP_TILES;
+                                       informational) */ };
 
 /* A tile history (see GSR_FLAG_NO_TILE_HISTORY): opaque, created for the CURRENT device, owned by the caller, one per view.
  * gsr_tile_history_destroy: the streams it was used on must be idle. */
@@ -204,7 +205,8 @@ typedef struct gsr_tile_history gsr_tile_history;
 int gsr_tile_history_create(gsr_tile_history** out);
 int gsr_tile_history_destroy(gsr_tile_history* history);
 /* What the library last learnt about the history (host side, no device access; for tools and tests): out[0] = mean tile
- * time of its last sorted frame in units of 10 ns (0: none yet), [1] = that frame's longest tile, [2] = similarity of its two
+ * time of its last sorted frame in units of 10 ns (0: none yet), [1] = that frame's longest tile (both as ONE wave would take:
+ * a tile composited by four waves counts 2.5 times what it took), [2] = similarity of its two
  * last frames x 1000 (the smaller of a tile's two shares of its frame's tile time, summed over the tiles), [3] = 1 if the order is dropped at present,
  * [4] = calls since the history was last cleared (a new size), [5] = 1 if the last block-plan call ran its blend beside the
  * emission. */

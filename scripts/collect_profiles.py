@@ -130,9 +130,10 @@ def main():
     for name in ("bound_sq", "outside_sq", "far_sq"):
         pv = pmc_values(name)
         # (sparse frames blend from the sorted lists: blend_wave_kernel)
-        v = pv.get("blend_blocks_kernel") or pv.get("blend_wave_kernel") or {}
+        kern = next((k for k in ("blend_blocks_kernel", "blend_deep_kernel", "blend_group_kernel", "blend_wave_kernel") if k in pv), None)
+        v = pv.get(kern, {}) if kern else {}
         if v:
-            v = dict(v, kernel="blend_blocks_kernel" if "blend_blocks_kernel" in pv else "blend_wave_kernel")
+            v = dict(v, kernel=kern)
             out[f"blend_insts_{name.split('_')[0]}"] = v
     json.dump(out, open(f"{DST}/pmc_traffic_{ROUND}.json", "w"), indent=1)
     import shutil

@@ -15,12 +15,13 @@
 
 constexpr int kUnroll = 64, kIters = 400;
 
-enum Class { FMA32, PKFMA32, FMA64, MUL64, ADD64, EXP32, CVT64, CVT32, CMP_SAND, CNDMASK, READLANE, LDSREAD, MIX_BLEND, CND_RAW, FMA_NOP, CMP_ONLY, CMP_SAND_RAW, ROUND_TRIP, NUM_CLASSES };
+enum Class { FMA32, PKFMA32, FMA64, MUL64, ADD64, EXP32, CVT64, CVT32, CMP_SAND, CNDMASK, READLANE, LDSREAD, MIX_BLEND, CND_RAW, FMA_NOP, CMP_ONLY, CMP_SAND_RAW, ROUND_TRIP, CND_SGPR, CMP_CND, V_MOV, V_AND, NUM_CLASSES };
 const char* kNames[NUM_CLASSES] = {"v_fma_f32", "v_pk_fma_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_exp_f32", "v_cvt_f64_f32",
                                    "v_cvt_f32_f64", "v_cmp_lt_f32 + s_and_b64", "v_cndmask_b32", "v_readlane_b32", "ds_read_b32",
                                    "blend mix (11 f64, 3 pk, 12 f32, 6 cmp+s_and)", "v_cndmask_b32, one asm block (no s_nop)",
                                    "v_fma_f32 + s_nop 0", "v_cmp_lt_f32 -> vcc only", "v_cmp -> vcc, s_and_b64 (one block, no s_nop)",
-                                   "v_cmp -> s pair -> s_andn2 -> v_cndmask on it"};
+                                   "v_cmp -> s pair -> s_andn2 -> v_cndmask on it",
+                                   "v_cndmask_b32 on a scalar pair (VOP3)", "v_cmp -> vcc, v_cndmask on it (a pair)", "v_mov_b32", "v_and_b32"};
 
 template <int C, bool DEP>
 __global__ __launch_bounds__(1024) void issue_kernel(unsigned long long* out, float seed) {
@@ -103,6 +104,20 @@ __global__ __launch_bounds__(1024) void issue_kernel(unsigned long long* out, fl
 #define RT(i) "v_cmp_lt_f32 vcc, %" #i ", %9\n s_andn2_b64 vcc, vcc, %0\n s_nop 0\n v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
                 asm volatile(RT(1) RT(2) RT(3) RT(4) RT(5) RT(6) RT(7) RT(8)
                              : "+s"(m), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc", "scc");
+            } else if (C == CND_SGPR) {
+                asm volatile("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                             "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(m2));
+            } else if (C == CMP_CND) {
+#define CC(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+                asm volatile(CC(0) CC(1) CC(2) CC(3) CC(4) CC(5) CC(6) CC(7)
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");
+            } else if (C == V_MOV) {
+                asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (C == V_AND) {
+                asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
             } else if (C == MIX_BLEND) {
                 // one strip evaluation of the blend, as instruction classes: 11 double, 3 packed, 12 single, 6 compare + scalar merge
                 asm volatile(
@@ -169,7 +184,8 @@ int main() {
     printf("(pairs — v_cmp + s_and, v_fma + s_nop, v_readlane + v_mov — the round-trip triple and ds_read + wait count as ONE; the mix row: per instruction of its 38)\n");
     if (row<FMA32>(dev) || row<PKFMA32>(dev) || row<FMA64>(dev) || row<MUL64>(dev) || row<ADD64>(dev) || row<EXP32>(dev) || row<CVT64>(dev) ||
         row<CVT32>(dev) || row<CMP_SAND>(dev) || row<CNDMASK>(dev) || row<READLANE>(dev) || row<LDSREAD>(dev) || row<MIX_BLEND>(dev) ||
-        row<CND_RAW>(dev) || row<FMA_NOP>(dev) || row<CMP_ONLY>(dev) || row<CMP_SAND_RAW>(dev) || row<ROUND_TRIP>(dev)) return 1;
+        row<CND_RAW>(dev) || row<FMA_NOP>(dev) || row<CMP_ONLY>(dev) || row<CMP_SAND_RAW>(dev) || row<ROUND_TRIP>(dev) ||
+        row<CND_SGPR>(dev) || row<CMP_CND>(dev) || row<V_MOV>(dev) || row<V_AND>(dev)) return 1;
     // what a tick of the cycle counter is: a known wall time against it
     {
         double c = 0, wc = 0;

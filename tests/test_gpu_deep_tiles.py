@@ -99,9 +99,10 @@ def test_deep_tiles_under_the_upstream_semantics():
     assert _same(_state(r), ref) and r.last_records_staged == ref_staged
 
 
-def test_the_history_picks_deep_tiles_and_nothing_changes():
-    """The same view again and again: the order is sorted from the tile times, its leading entries go to four waves (which
-    ones is decided on the device), and every frame is the bits of a frame without a history. Then the camera jumps."""
+def test_sparse_frames_take_the_deep_way_by_themselves_and_nothing_changes():
+    """Below 12 instances per visible Gaussian every tile is composited by four waves without anybody asking (no history
+    needed: the rule is R against V), above it none is; with and without the tile history, which only orders the tiles, every
+    frame is the bits of the ordinary way. Then the camera jumps between the two regimes."""
     import torch
     from gsrast_amd import camera, scenes
     from gsrast_amd.rasterizer import SplatRasterizer
@@ -110,19 +111,19 @@ def test_the_history_picks_deep_tiles_and_nothing_changes():
     scene["means3D"][:, :3] *= 0.35
     r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
     r.configure_from_scene(scene)
-    cams = [camera.default_camera(w, h, near=0.05, far=60.0, position=p) for p in ((0.0, 0.0, -6.0), (0.0, 0.0, -6.3), (0.3, -0.2, -3.0))]
-    refs = []
+    cams = [camera.default_camera(w, h, near=0.05, far=60.0, position=p) for p in ((0.0, 0.0, -16.0), (0.0, 0.0, -16.4), (0.3, -0.2, -2.5))]
+    refs, sparse = [], []
     for c in cams:
-        r.draw(c, plan="sort", tile_history=False, count_staged=True)
+        r.draw(c, plan="sort", tile_history=False, deep_tiles=False, count_staged=True)
         refs.append((_state(r), r.last_records_staged))
-    deep_calls = 0
-    for c in (0,) * 8 + (1,) * 4 + (2,) * 5 + (0,) * 3:
-        _poison(r)
-        r.draw(cams[c], plan="sort", tile_history=True, count_staged=True)
-        deep_calls += int(r.last_deep_tiles)
-        assert _same(_state(r), refs[c][0]), c
-        assert r.last_records_staged == refs[c][1], c
-    # (a frame of 920 tiles cannot fill the chip: its longest tile always counts as slow, the order — and with it the deep
-    # class — is in use on most calls)
-    assert deep_calls >= 8, deep_calls
+        visible = int((r.map_geometry_state()["tilesTouched"] != 0).sum().item())
+        sparse.append(r.last_num_rendered < 12 * visible)
+    assert sparse[0] and sparse[1] and not sparse[2], sparse          # (far away: a tile or two per splat; close up: dozens)
+    for hist in (False, True):
+        for c in (0,) * 5 + (1,) * 3 + (2,) * 4 + (0,) * 3:
+            _poison(r)
+            r.draw(cams[c], plan="sort", tile_history=hist, count_staged=True)
+            assert r.last_deep_tiles == sparse[c], (c, hist)
+            assert _same(_state(r), refs[c][0]), (c, hist)
+            assert r.last_records_staged == refs[c][1], (c, hist)
     assert torch.isfinite(r.out_color).all()
