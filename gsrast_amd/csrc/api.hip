@@ -1014,21 +1014,8 @@ int gsr_forward(gsr_forward_args* a) {
         // tile owns a few of a unit's 2048 entries and pays a round trip to memory per unit for them (the bench scene
         // from outside the cloud, R/V = 23: 0.65 against 0.45 ms; from far away, R/V = 5: 1.98 against 0.65 ms; bench
         // frame, R/V = 88: equal). With the sorted lists written anyway, sparse frames blend from them.
-        // ... and so do frames whose tiles walk their lists to the end, whatever the instances per Gaussian — a blend the
-        // history expects to last twice the emission and more (faint splats: pixels that never saturate): out of the block
-        // lists every tile then visits every unit of its block, the sorted list it reads once, front to back (bench frame with
-        // opacities x 0.1, R/V = 88: 2.06 -> 1.85 ms; with the pixels saturating early, as they do: 0.109 from the block lists
-        // against 0.124, `profiles/r06_deep_tiles.txt`).
-        bool long_blend = false;
-        if (history && hist->mean != 0u && !hist->decorrelated) {
-            const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
-            const unsigned long long est_blend = std::max((unsigned long long)hist->mean * tiles / (unsigned long long)shape.blend_slots,
-                                                          (unsigned long long)hist->longest);
-            long_blend = est_blend > 2ull * std::max(12ull * (unsigned long long)R / 40000ull, 7000ull);
-        }
         blend_from_lists = serial && !(a->flags & GSR_FLAG_NO_SORTED_LISTS) &&
-                           ((uint64_t)R < (env.block_feed_min >= 0 ? (uint64_t)env.block_feed_min : kBlockFeedMinInstances) * (uint64_t)nv ||
-                            (long_blend && env.block_feed_min < 0));
+                           (uint64_t)R < (env.block_feed_min >= 0 ? (uint64_t)env.block_feed_min : kBlockFeedMinInstances) * (uint64_t)nv;
         if (history) hist->block_fed = !blend_from_lists;
         // (the emission stays on the caller's stream and is launched first: its persistent workgroups must be resident
         // before the blend's thousands of waves arrive — the other way round the blend takes every register file and the

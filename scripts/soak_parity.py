@@ -21,9 +21,11 @@ r = SplatRasterizer(W, H, background=(0.2, 0.1, 0.3))
 r.configure_from_scene(scene)
 rng = np.random.default_rng(12)
 threads = max(1, min(64, cpu_oracle.hardware_concurrency()))
-worst_px, frames, t_words, flips, list_bad = 0.0, 0, 0, 0, 0
+worst_px, frames, t_words, flips, list_bad, deep_frames = 0.0, 0, 0, 0, 0, 0
 for i in range(poses):
     pos = tuple(float(x) for x in rng.uniform(-7, 7, 3))
+    if i % 3 == 2:
+        pos = tuple(4.0 * x for x in pos)                     # every third pose from far out: a tile or two per splat — deep tiles (csrc/blend.hip)
     scale = float(rng.choice([1.0, 1.0, 0.3, 0.1]))          # every fourth frame or so with faint splats: deep walks
     # looking at the cloud's centre, give or take half a radian (front = (cos p sin y, sin p, cos p cos y), FirstPersonCamera.cpp:30)
     d = -np.asarray(pos) / max(np.linalg.norm(pos), 1e-6)
@@ -36,6 +38,7 @@ for i in range(poses):
     r.opacities = __import__("torch").from_numpy(sc["opacities"]).to(r.device)
     img = r.draw(cam, count_staged=True).cpu().numpy()
     frames += 1
+    deep_frames += int(getattr(r, "last_deep_tiles", False))
     b, im = r.map_binning_state(), r.map_image_state()
     ok_lists = (r.last_num_rendered == exp["num_rendered"] and r.last_records_staged == exp["records_staged"]
                 and np.array_equal(b["keys"].cpu().numpy().view(np.uint64), exp["keys"])
@@ -47,6 +50,6 @@ for i in range(poses):
     worst_px = max(worst_px, float(np.abs(img - exp["out_color"]).max()))
     if i % 10 == 0:
         print(f"pose {i}: R={exp['num_rendered']} R_f={exp['records_staged']} plan={r.last_plan} opacity x {scale} lists_ok={ok_lists} worst pixel so far {worst_px:.2e}", flush=True)
-print(f"{frames} frames with R > 0 ({which}, {n} splats, {W}x{H}): frames whose lists / ranges / R / R_f differ: {list_bad}; finalT words differing: {t_words}; "
+print(f"{frames} frames with R > 0 ({which}, {n} splats, {W}x{H}; {deep_frames} of them composited by four waves per tile): frames whose lists / ranges / R / R_f differ: {list_bad}; finalT words differing: {t_words}; "
       f"nContrib flips: {flips}; largest pixel difference: {worst_px:.3e}")
 sys.exit(0 if (list_bad == 0 and t_words == 0 and flips == 0 and worst_px <= 2e-6) else 1)
