@@ -33,6 +33,8 @@ GSR_FLAG_NO_TILE_HISTORY = 0x80
 GSR_FLAG_SERIAL_EMIT = 0x100
 GSR_FLAG_NO_DEEP_TILES = 0x200
 GSR_FLAG_DEEP_TILES_ALL = 0x400
+GSR_FLAG_DEEP_WAVES_8 = 0x800
+GSR_FLAG_DEEP_WAVES_16 = 0x1000
 GSR_PLAN_LISTS_SKIPPED = 0x100
 GSR_PLAN_BLEND_FROM_LISTS = 0x200
 GSR_PLAN_TILES_REORDERED = 0x400

@@ -277,6 +277,7 @@ struct EnvKnobs {
     int fused_depth;           // GSR_FUSED_DEPTH=0|1: the depth order with / without the compaction whatever the size; -1: by size
     long block_feed_min;       // GSR_BLOCK_FEED_MIN=n: kBlockFeedMinInstances for this process (A/B runs); -1: the constant
     long deep_all_max;         // GSR_DEEP_ALL_MAX=n: kDeepAllMaxInstances for this process (A/B runs); -1: the constant
+    bool deep_waves_auto;      // GSR_DEEP_WAVES_AUTO=0: deep tiles always get four waves (A/B runs)
     bool deep_by_history;      // GSR_DEEP_BY_HISTORY=1: above that, the history's slowest tiles get four waves (tile_order_kernel's
                                // count; measured neutral, `profiles/r06_deep_tiles.txt`: off by default)
 };
@@ -293,6 +294,8 @@ const EnvKnobs& env_knobs() {
         e.block_feed_min = b && b[0] ? atol(b) : -1;
         const char* d = getenv("GSR_DEEP_ALL_MAX");
         e.deep_all_max = d && d[0] ? atol(d) : -1;
+        const char* dw = getenv("GSR_DEEP_WAVES_AUTO");
+        e.deep_waves_auto = !(dw && dw[0] == '0');
         const char* dh = getenv("GSR_DEEP_BY_HISTORY");
         e.deep_by_history = dh && dh[0] == '1';
         return e;
@@ -1131,9 +1134,23 @@ int gsr_forward(gsr_forward_args* a) {
     // (deep tiles, blend.hip: the leading entries of an order sorted for THIS call; the block-fed blend has none)
     const bool list_fed = !(use_blocks && !blend_from_lists);
     const bool deep_wanted = env.deep_by_history && list_fed && t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES);
-    const bool deep_all = list_fed && ((a->flags & GSR_FLAG_DEEP_TILES_ALL) ||
+    const uint32_t deep_forced = a->flags & (GSR_FLAG_DEEP_TILES_ALL | GSR_FLAG_DEEP_WAVES_8 | GSR_FLAG_DEEP_WAVES_16);
+    const bool deep_all = list_fed && (deep_forced != 0u ||
                                        (!(a->flags & GSR_FLAG_NO_DEEP_TILES) &&
                                         (uint64_t)R < (env.deep_all_max >= 0 ? (uint64_t)env.deep_all_max : kDeepAllMaxInstances) * (uint64_t)nv));
+    // How many waves a deep tile gets: four — or eight, sixteen where the history says the frame's work sits in few tiles:
+    // tiles x mean / longest is how many tiles AS LONG AS THE LONGEST the frame amounts to; with fewer of them than the chip has
+    // SIMDs eight waves per tile win, with fewer than a quarter sixteen (measured, blend with 4 / 8 / 16 waves per tile,
+    // `profiles/r06_deep_tiles.txt` — a trained-like scene of 5.83 M splats from 32 / 48 / 70 units away, 358 / 200 / 96 such
+    // tiles: 1.15 / 1.01 / 1.03, 1.82 / 1.66 / 1.17, 3.20 / 2.88 / 2.20 ms (one wave per tile: 1.77, 3.06, 5.86); the bench
+    // scene from 40 / 50 units, 948 / 422: 0.297 / 0.283 / 0.68 and 0.240 / 0.212 / 0.30; from 30 units, 1 609: 0.31 / 0.38 / 1.03)
+    int deep_waves = (deep_forced & GSR_FLAG_DEEP_WAVES_16) ? 16 : ((deep_forced & GSR_FLAG_DEEP_WAVES_8) ? 8 : 4);
+    if (deep_all && deep_forced == 0u && env.deep_waves_auto && history && hist->mean != 0u && hist->longest != 0u && !hist->decorrelated) {
+        const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
+        const unsigned long long as_longest = tiles * (unsigned long long)hist->mean / (unsigned long long)hist->longest;
+        const unsigned long long simds = 4ull * (unsigned long long)shape.cus;
+        deep_waves = 4ull * as_longest <= simds ? 16 : (as_longest <= simds ? 8 : 4);
+    }
     if (deep_wanted || deep_all) a->plan_used |= GSR_PLAN_DEEP_TILES;
     if (profile) GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND], blend_stream));
     if (use_blocks && !blend_from_lists)
@@ -1144,7 +1161,7 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_blend(d, img.ranges, bin.values, geom.means2D, colors, geom.conic_opacity, img.accum_alpha,
                               img.n_contrib, a->background, a->out_color, count_staged ? g_rb.staged_dev : nullptr,
                               t_cutoff, blend_stream, gs.sort_info + 4, R, t_order, t_ticks, colors_late,
-                              deep_wanted ? hist->deep : nullptr, deep_all));   // :804-810
+                              deep_wanted ? hist->deep : nullptr, deep_all, deep_waves));   // :804-810
     if (order_now) hist->order_serial = serial;               // (the blend that takes the order is in its stream: a backward of this call may take it too)
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is

@@ -98,14 +98,19 @@ constexpr uint32_t kDeepFlag = 0x80000000u;      // in a tile's recorded time: i
 // 27: a second barrier a round), so that eight of these workgroups fit a CU where five of the mixed kind do: at 4.8 waves per
 // SIMD the mixed kernel kept the vector pipes busy half of the time (`profiles/r06_deep_tiles.txt`).
 enum { kBlendSingle = 0, kBlendGrouped = 1, kBlendDeepOnly = 2 };
-template <int MODE>
+// W: the waves of a workgroup — 4; 8 or 16 in the deep-only kernel for frames whose work sits in a few hundred tiles (a far
+// view of a dense scene): strips of 16 x 2 or 16 x 1 pixels, the upper lanes of a wave idle — on a chip with a wave per
+// SIMD idle lanes cost nothing, and two waves on a SIMD issue twice what one does (`profiles/r06_micro_valu_issue.txt`).
+template <int MODE, int W = kGroupWaves>
 __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
     constexpr bool GROUPED = MODE != kBlendSingle, DEEP_ONLY = MODE == kBlendDeepOnly;
-    constexpr int kWavesHere = GROUPED ? kGroupWaves : 1;
+    static_assert(W == kGroupWaves || DEEP_ONLY, "more than four waves: the deep-only kernel");
+    constexpr int kWavesHere = GROUPED ? W : 1;
+    constexpr int kRows = kTile / (GROUPED ? W : 4);
     constexpr uint32_t kBuffers = DEEP_ONLY ? 1u : 2u;
     // (one area, two uses: a wave's own staging records in the ordinary mode; two rounds of four segments in the deep one)
     constexpr size_t kStageBytes = !GROUPED ? sizeof(StagedRecords)
-                                   : DEEP_ONLY ? sizeof(DeepSegment) * kGroupWaves
+                                   : DEEP_ONLY ? sizeof(DeepSegment) * W
                                    : (sizeof(DeepSegment) * 2 * kGroupWaves > sizeof(StagedRecords) * kGroupWaves ? sizeof(DeepSegment) * 2 * kGroupWaves
                                                                                                                 : sizeof(StagedRecords) * kGroupWaves);
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[kStageBytes];
@@ -164,10 +169,16 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
         return nb;
     };
     if constexpr (GROUPED) if (deep) {
-        constexpr uint32_t kRound = kGroupWaves * kWave;
-        DeepSegment (*const segs)[kGroupWaves] = reinterpret_cast<DeepSegment (*)[kGroupWaves]>(s_stage);      // [round & 1][wave] (one area in the deep-only kernel)
+        constexpr uint32_t kRound = W * kWave;
+        DeepSegment (*const segs)[W] = reinterpret_cast<DeepSegment (*)[W]>(s_stage);      // [round & 1][wave] (one area in the deep-only kernel)
         StripLanes s;
-        strip_lanes_init(s, tx, ty, wave, lane, p.dims.width, p.dims.height);
+        strip_lanes_init(s, tx, ty, wave, lane, p.dims.width, p.dims.height, kRows);
+        auto everybody_done = [&] {
+            uint32_t all = 1u;
+#pragma unroll
+            for (int g = 0; g < W; ++g) all &= s_done[g];
+            return all != 0u;
+        };
         bool my_done = strip_lanes_all_done(s);            // (a strip below the image: finished from the start)
         if (lane == 0) { s_done[wave] = my_done ? 1u : 0u; s_done_at[wave] = 0u; }
         // (the barrier of a round waits for the wave's LDS traffic only — __syncthreads would also wait for the loads of the
@@ -175,7 +186,7 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
         auto round_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
         auto composite_round = [&](uint32_t half) {
 #pragma nounroll
-            for (int g = 0; g < kGroupWaves; ++g) {
+            for (int g = 0; g < W; ++g) {
                 const uint32_t cnt = s_count[half][g];
                 if (cnt == 0u) continue;
                 const DeepSegment& seg = segs[half][g];
@@ -197,12 +208,12 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
             for (uint32_t pos = 0; pos < total; pos += kRound) {
                 fetch_records(b1, feed);
                 const RecordBatch b2 = next_batch(pos + 2 * kRound + (uint32_t)(wave * kWave));
-                const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
+                const uint32_t kept = b0.valid ? stage_batch_deep<W>(feed, segs[0][wave], b0, p.dims.height) : 0u;
                 if (lane == 0) s_count[0][wave] = kept;
                 round_barrier();                         // the round's four segments are staged
                 if (!my_done) composite_round(0u);
                 round_barrier();                         // everybody is through with them; the flags of this round are visible
-                if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
+                if (everybody_done()) break;
                 b0 = b1;
                 b1 = b2;
             }
@@ -212,7 +223,7 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
             fetch_records(b1, feed);
             RecordBatch b2 = next_batch(2 * kRound + (uint32_t)(wave * kWave));
             {
-                const uint32_t kept = b0.valid ? stage_batch_deep(feed, segs[0][wave], b0, p.dims.height) : 0u;
+                const uint32_t kept = b0.valid ? stage_batch_deep<W>(feed, segs[0][wave], b0, p.dims.height) : 0u;
                 if (lane == 0) s_count[0][wave] = kept;
             }
             round_barrier();
@@ -220,11 +231,11 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
                 // (b1: round r + 1, its records on their way since the round before; b2: round r + 2, its ids)
                 fetch_records(b2, feed);
                 const RecordBatch b3 = next_batch(pos + 3 * kRound + (uint32_t)(wave * kWave));
-                const uint32_t kept = b1.valid ? stage_batch_deep(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
+                const uint32_t kept = b1.valid ? stage_batch_deep<W>(feed, segs[(r + 1u) & 1u][wave], b1, p.dims.height) : 0u;
                 if (lane == 0) s_count[(r + 1u) & 1u][wave] = kept;
                 if (!my_done) composite_round(r & 1u);
                 round_barrier();                            // round r is composited, round r + 1 staged, the flags are visible
-                if ((s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u) break;
+                if (everybody_done()) break;
                 b1 = b2;
                 b2 = b3;
             }
@@ -233,8 +244,10 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
         if (wave == 0 && lane == 0) {
             if (p.staged_counter) {
                 // (the loop was left through a barrier: the flags are final)
-                const bool finished = (s_done[0] & s_done[1] & s_done[2] & s_done[3]) != 0u;
-                const uint32_t last = max(max(s_done_at[0], s_done_at[1]), max(s_done_at[2], s_done_at[3]));
+                const bool finished = everybody_done();
+                uint32_t last = 0;
+#pragma unroll
+                for (int g = 0; g < W; ++g) last = max(last, s_done_at[g]);
                 const unsigned long long batches = ((unsigned long long)last + (unsigned long long)kBatch - 1ull) / (unsigned long long)kBatch;
                 atomicAdd(p.staged_counter, finished ? min((unsigned long long)total, batches * (unsigned long long)kBatch) : (unsigned long long)total);
             }
@@ -275,6 +288,8 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) { blend_wave_body<kBlendSingle>(p); }
 __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_group_kernel(const BlendParams p) { blend_wave_body<kBlendGrouped>(p); }
 __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(8))) void blend_deep_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly>(p); }
+__global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(8))) void blend_deep8_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly, 8>(p); }
+__global__ __launch_bounds__(16 * kWave) __attribute__((amdgpu_waves_per_eu(4))) void blend_deep16_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly, 16>(p); }
 
 
 // Workgroup numbers of the patch order, the SLOW tiles of the frame before first — those that took more than twice the
@@ -448,7 +463,7 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  float* final_t, uint32_t* n_contrib, const float* background, float* out_color,
                  unsigned long long* staged_counter, float t_cutoff, hipStream_t stream, const uint32_t* nonempty_tiles,
                  uint32_t num_rendered, const uint32_t* tile_order, uint32_t* tile_ticks, bool colors_are_shs, const uint32_t* deep_count,
-                 bool deep_all) {
+                 bool deep_all, int deep_waves) {
     BlendParams p;
     p.deep_count = tile_order ? deep_count : nullptr;      // (the deep tiles are the order's leading entries)
     p.deep_all = deep_all ? 1 : 0;
@@ -478,7 +493,11 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
     // workgroup. Every other frame is launched a wave per workgroup, as ever.
     const bool few_tiles = p.nonempty != nullptr && ((uint32_t)p.num_tiles <= kStripTilesAny ||
                                                      (unsigned long long)num_rendered <= (unsigned long long)kStripMeanList * kStripTilesShort);
-    if (p.deep_all)
+    if (p.deep_all && deep_waves == 16)
+        hipLaunchKernelGGL(blend_deep16_kernel, dim3((unsigned)p.base_workgroups), dim3(16 * kWave), 0, stream, p);
+    else if (p.deep_all && deep_waves == 8)
+        hipLaunchKernelGGL(blend_deep8_kernel, dim3((unsigned)p.base_workgroups), dim3(8 * kWave), 0, stream, p);
+    else if (p.deep_all)
         hipLaunchKernelGGL(blend_deep_kernel, dim3((unsigned)p.base_workgroups), dim3(kGroupWaves * kWave), 0, stream, p);
     else if (p.deep_count || few_tiles)
         hipLaunchKernelGGL(blend_group_kernel, dim3((unsigned)(p.base_workgroups + (p.base_workgroups + 31) / 32 * 8)),

@@ -393,22 +393,25 @@ struct DeepSegment {               // the survivors of a wave's 64 list entries,
 // Which strips a record can reach: strip k is out of reach when even the power's maximum over dx, -0.5 dy^2 det / A, stays
 // below the record's floor for every row of the strip, |dy| > sqrt(2 (ln(255 opacity) + margin) A / det) — the margin of
 // record_misses_tile plus the rounding of the power's terms over the tile, the determinant rounded down; anything odd: all four.
+template <int STRIPS>
 __device__ __forceinline__ uint32_t strips_in_reach(const float2 xy, const float4 co, float p0, float terms, bool filtered, float tile_y0, int height) {
+    constexpr int kRows = kTile / STRIPS;          // rows of a strip: 4 (four waves per tile), 2 or 1 (eight, sixteen: see blend.hip)
     const float A = co.x, B = co.y, C = co.z;
     const float ac = A * C, det_lo = ac - B * B - 4e-7f * ac;
     const float reach2 = 2.0f * (2e-3f + 1e-5f * terms - p0) * A / det_lo * 1.0001f;     // (p0 = -ln(255 opacity))
-    if (!(A > 0.0f && C > 0.0f && det_lo > 0.0f && reach2 >= 0.0f && reach2 < 1e12f && filtered)) return 0xFu;
+    if (!(A > 0.0f && C > 0.0f && det_lo > 0.0f && reach2 >= 0.0f && reach2 < 1e12f && filtered)) return (1u << STRIPS) - 1u;
     const float reach = __builtin_sqrtf(reach2) + 0.01f;
     const float y_lo = xy.y - reach, y_hi = xy.y + reach;
     uint32_t bits = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float r_lo = tile_y0 + 4.0f * (float)k, r_hi = fminf(r_lo + 3.0f, (float)(height - 1));
+    for (int k = 0; k < STRIPS; ++k) {
+        const float r_lo = tile_y0 + (float)(kRows * k), r_hi = fminf(r_lo + (float)(kRows - 1), (float)(height - 1));
         if (y_lo <= r_hi && y_hi >= r_lo) bits |= 1u << k;
     }
     return bits;
 }
 // (the footprint test, the floor and the margins are stage_batch's)
+template <int STRIPS>
 __device__ __forceinline__ uint32_t stage_batch_deep(const TileFeed& f, DeepSegment& seg, const RecordBatch& b, int height) {
     const bool present = b.present();
     const uint32_t rank = b.rank(), pos = b.pos;
@@ -427,23 +430,23 @@ __device__ __forceinline__ uint32_t stage_batch_deep(const TileFeed& f, DeepSegm
         float c0 = c[0], c1 = c[1], c2 = c[2];
         if (f.dc_stride != 0u) { c0 = 0.5f + 0.4f * c0; c1 = 0.5f + 0.4f * c1; c2 = 0.5f + 0.4f * c2; }
         seg.rgb[slot] = make_float4(c0, c1, c2, 0.0f);
-        seg.touch[slot] = strips_in_reach(b.xy, b.co, p0, terms, filtered, f.box.y_lo, height);
+        seg.touch[slot] = strips_in_reach<STRIPS>(b.xy, b.co, p0, terms, filtered, f.box.y_lo, height);
     }
     return (uint32_t)__popcll(m2);
 }
 
-struct StripLanes {                // one pixel per lane: lane l owns (x = l & 15, y = 4 strip + (l >> 4)) of the tile
+struct StripLanes {                // one pixel per lane: lane l owns (x = l & 15, y = rows strip + (l >> 4)) of the tile (rows = 4; 2 or 1: the upper lanes idle)
     int px, py;
     float fx, fy;                  // (fy: NaN once the pixel is finished, as TileLanes' row coordinates)
     bool inside;
     float T, cr, cg, cb;
     uint32_t last;
 };
-__device__ __forceinline__ void strip_lanes_init(StripLanes& s, int tx, int ty, int strip, int lane, int width, int height) {
+__device__ __forceinline__ void strip_lanes_init(StripLanes& s, int tx, int ty, int strip, int lane, int width, int height, int rows = 4) {
     s.px = tx * kTile + (lane & 15);
-    s.py = ty * kTile + 4 * strip + (lane >> 4);
+    s.py = ty * kTile + rows * strip + (lane >> 4);
     s.fx = (float)s.px;
-    s.inside = s.px < width && s.py < height;
+    s.inside = s.px < width && s.py < height && (lane >> 4) < rows;
     s.fy = s.inside ? (float)s.py : __builtin_nanf("");
     s.T = 1.0f; s.cr = s.cg = s.cb = 0.0f; s.last = 0u;
 }

@@ -174,7 +174,8 @@ int launch_blend(const FrameDims& d, const uint32_t* ranges, const uint32_t* poi
                  const uint32_t* tile_order = nullptr, uint32_t* tile_ticks = nullptr,       // (longest tiles first: TileOrder, blend_core.hpp)
                  bool colors_are_shs = false,                                                // (`colors` = the SH array: TileFeed::dc_stride)
                  const uint32_t* deep_count = nullptr,                                       // (device word: the order's leading entries that get four waves, blend.hip)
-                 bool deep_all = false);                                                     // (every tile gets four waves)
+                 bool deep_all = false,                                                      // (every tile gets four waves)
+                 int deep_waves = 4);                                                        // (... or 8 or 16: frames whose work sits in few tiles)
 // Longest tiles first: the order of this call's blend workgroups from the ticks the tiles of the call before left.
 constexpr int kTileOrderMax = 32768;      // workgroups (one per tile, patch grid padded) up to which the order is kept: 128 KB of LDS for its sort
 // What the launch heuristics need to know about the chip, derived from its CU count (hipDeviceAttributeMultiprocessorCount,

@@ -153,7 +153,8 @@ class SplatRasterizer:
         binning chunk holds the sorted keys / values of this call).
         deep_tiles: None = the library decides per tile from the history (four waves for the tiles it expects to be the frame's
         slowest, csrc/blend.hip; last_deep_tiles tells whether the blend was launched with them enabled), False =
-        GSR_FLAG_NO_DEEP_TILES, "all" = GSR_FLAG_DEEP_TILES_ALL (every tile; a diagnostic).
+        GSR_FLAG_NO_DEEP_TILES, "all" = GSR_FLAG_DEEP_TILES_ALL (every tile; a diagnostic), "all8" / "all16" = eight / sixteen
+        waves per tile (GSR_FLAG_DEEP_WAVES_8 / _16).
         colors_precomp: pass the scene's colours as the reference's `colorsPrecomp` argument (GSCuda.cuh:111) — computed once
         per scene by gsr_colors_from_dc, bit-equal to what the preprocess writes to geomState.rgb per frame (gscuda semantics
         only: there the colour does not depend on the view)."""
@@ -169,7 +170,8 @@ class SplatRasterizer:
                    | (_capi.GSR_FLAG_OVERLAP_EMIT if overlap_emit else (_capi.GSR_FLAG_SERIAL_EMIT if overlap_emit is False else 0))
                    | (0 if sorted_lists else _capi.GSR_FLAG_NO_SORTED_LISTS)
                    | (0 if tile_history else _capi.GSR_FLAG_NO_TILE_HISTORY)
-                   | (_capi.GSR_FLAG_DEEP_TILES_ALL if deep_tiles == "all" else (_capi.GSR_FLAG_NO_DEEP_TILES if deep_tiles is False else 0)))
+                   | {"all": _capi.GSR_FLAG_DEEP_TILES_ALL, "all8": _capi.GSR_FLAG_DEEP_WAVES_8, "all16": _capi.GSR_FLAG_DEEP_WAVES_16,
+                      False: _capi.GSR_FLAG_NO_DEEP_TILES, None: 0}[deep_tiles])
         a.geometry_alloc, a.binning_alloc, a.image_alloc = self.geom.callback, self.binning.callback, self.image.callback
         a.num_gaussians, a.sh_dims, a.M = self.num_gaussians, (sh_degree if inria else 3), 16
         a.background = self.background.data_ptr()

@@ -186,6 +186,12 @@ enum {
  * diagnostic, and what the tests compare the ordinary way against). Neither reads nor needs a tile history. */
 #define GSR_FLAG_NO_DEEP_TILES 0x200u
 #define GSR_FLAG_DEEP_TILES_ALL 0x400u
+/* With deep tiles, EIGHT or SIXTEEN waves per tile (strips of 16 x 2 or 16 x 1 pixels; the upper lanes of a wave idle) instead
+ * of four: what the library picks by itself when the view's tile history says the frame's work sits in a few hundred tiles
+ * (a far view of a dense scene: a chip with one wave per SIMD issues at 40 % of what two waves per SIMD do). Diagnostics,
+ * like GSR_FLAG_DEEP_TILES_ALL, which they imply; same outputs bit for bit. */
+#define GSR_FLAG_DEEP_WAVES_8 0x800u
+#define GSR_FLAG_DEEP_WAVES_16 0x1000u
 enum { GSR_PLAN_SORT = 1, GSR_PLAN_BLOCKS = 2, GSR_PLAN_GENERIC = 3 /* grids wider than 255 tiles */,
        GSR_PLAN_LISTS_SKIPPED = 0x100 /* or-ed in: GSR_FLAG_NO_SORTED_LISTS took effect */,
        GSR_PLAN_BLEND_FROM_LISTS = 0x200 /* or-ed in: block plan whose blend read the sorted lists (sparse frames: fewer

@@ -34,9 +34,9 @@ def test_config1_by_four_waves_per_tile_against_the_golden_fixture():
     scene, cam, bg, exp = load_golden()
     r = SplatRasterizer(cam.width, cam.height, background=bg)
     r.configure_from_scene(scene)
-    for plan in ("sort", "blocks"):
+    for plan, mode in (("sort", "all"), ("blocks", "all"), ("sort", "all8"), ("sort", "all16")):
         # (the block plan blends a frame this sparse from the sorted lists: the same kernel)
-        r.draw(cam, plan=plan, tile_history=False, deep_tiles="all", count_staged=True)
+        r.draw(cam, plan=plan, tile_history=False, deep_tiles=mode, count_staged=True)
         assert r.last_deep_tiles
         st = r.map_image_state()
         assert_blend_parity(r.out_color.cpu().numpy(), st["finalT"].cpu().numpy().reshape(cam.height, cam.width),
@@ -62,12 +62,14 @@ def test_deep_and_ordinary_tiles_give_the_same_bits(size, n, pos, opacity_scale)
     r.draw(cam, plan="sort", tile_history=False, deep_tiles=False, count_staged=True)
     ref, ref_staged = _state(r), r.last_records_staged
     assert not r.last_deep_tiles
-    _poison(r)
-    r.draw(cam, plan="sort", tile_history=False, deep_tiles="all", count_staged=True)
-    assert r.last_deep_tiles
-    got, got_staged = _state(r), r.last_records_staged
-    assert _same(got, ref)
-    assert got_staged == ref_staged, (got_staged, ref_staged)
+    # four waves per tile (16 x 4 strips), eight (16 x 2), sixteen (16 x 1: the upper lanes idle)
+    for mode in ("all", "all8", "all16"):
+        _poison(r)
+        r.draw(cam, plan="sort", tile_history=False, deep_tiles=mode, count_staged=True)
+        assert r.last_deep_tiles
+        got, got_staged = _state(r), r.last_records_staged
+        assert _same(got, ref), mode
+        assert got_staged == ref_staged, (mode, got_staged, ref_staged)
     # ... and both are the oracle's
     exp = cpu_oracle.forward(scene, cam, background=(0.1, 0.2, 0.3))
     assert_blend_parity(got[0].cpu().numpy(), got[1].cpu().numpy().reshape(h, w), got[2].cpu().numpy().reshape(h, w), exp,
@@ -76,11 +78,12 @@ def test_deep_and_ordinary_tiles_give_the_same_bits(size, n, pos, opacity_scale)
     # a band of tile rows (what a rank of a sharded frame renders)
     rows = (3, 11)
     band_ref = r.draw(cam, plan="sort", tile_rows=rows, tile_history=False, deep_tiles=False).clone()
-    r.out_color.fill_(float("nan"))
-    band = r.draw(cam, plan="sort", tile_rows=rows, tile_history=False, deep_tiles="all")
-    y0, y1 = rows[0] * 16, min(rows[1] * 16, h)
     import torch
-    assert torch.equal(band[:, y0:y1].view(torch.int32), band_ref[:, y0:y1].view(torch.int32))
+    y0, y1 = rows[0] * 16, min(rows[1] * 16, h)
+    for mode in ("all", "all8", "all16"):
+        r.out_color.fill_(float("nan"))
+        band = r.draw(cam, plan="sort", tile_rows=rows, tile_history=False, deep_tiles=mode)
+        assert torch.equal(band[:, y0:y1].view(torch.int32), band_ref[:, y0:y1].view(torch.int32)), mode
 
 
 def test_deep_tiles_under_the_upstream_semantics():
