@@ -88,6 +88,7 @@ def parse_args():
                         "gsr_colors_from_dc: the preprocess then reads no SH and writes no geomState.rgb (gscuda semantics)")
     p.add_argument("--plan", default="auto", choices=["auto", "sort", "blocks"], help="binning plan (GSR_FLAG_PLAN_*)")
     p.add_argument("--no-tile-history", action="store_true", help="GSR_FLAG_NO_TILE_HISTORY for the headline frame")
+    p.add_argument("--no-deep-tiles", action="store_true", help="GSR_FLAG_NO_DEEP_TILES for the headline frame: one wave per tile whatever the instances per Gaussian")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0: a free one)")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher / rendezvous / band-exchange plumbing check on CPU over gloo: renders nothing, measures "
@@ -651,13 +652,15 @@ def main() -> int:
         run.dl_dout = torch.randn((3, H, W), generator=torch.Generator(device="cpu").manual_seed(7)).to(device)
     draw_kw = dict(plan=args.plan, overlap_emit=True if args.overlap else (False if args.serial_emit else None),
                    semantics=args.semantics, sh_degree=args.sh_degree,
-                   sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp, tile_history=not args.no_tile_history)
+                   sorted_lists=not args.no_sorted_lists, colors_precomp=args.colors_precomp, tile_history=not args.no_tile_history,
+                   deep_tiles=False if args.no_deep_tiles else None)
     m = run.measure(cam, args.steps, args.warmup, **draw_kw)
 
     # (extras and the committed PMC figures belong to the default workload; with --ply the frame is the file's)
     default_frame = (not from_file and args.scene == "garden_like" and args.splats == DEFAULT_SPLATS and (W, H) == (1920, 1080) and not args.pose
                      and args.opacity_scale == 1.0 and not inria and not args.backward and args.plan == "auto"
-                     and not args.overlap and not args.no_sorted_lists and not args.colors_precomp and not args.no_tile_history)
+                     and not args.overlap and not args.no_sorted_lists and not args.colors_precomp and not args.no_tile_history
+                     and not args.no_deep_tiles)
     extras = {}
     if not args.no_extras and default_frame:
         # (6 warm-up frames: the library notices within five that a new viewpoint ends on a few slow tiles — GSR_FLAG_NO_TILE_HISTORY)
@@ -755,7 +758,7 @@ def main() -> int:
 
         # HBM bytes and instruction counts per launch measured with PMC counters in separate rocprofv3 passes of this
         # same command (profiles/): valid only for the default single-GPU workload they were taken on.
-        traffic, traffic_src, blend_pmc = {}, None, {}
+        traffic, traffic_src, blend_pmc, tj = {}, None, {}, {}
         if default_frame and not distributed:
             tj, traffic_src = load_profile_json("pmc_traffic_r06.json", "pmc_traffic_r05.json", "pmc_traffic_r04.json", "pmc_traffic_r03.json", "pmc_traffic_r02.json", "pmc_traffic_r01.json")
             traffic = tj.get("blocks" if blocks else "sort", {})
@@ -869,6 +872,12 @@ def main() -> int:
             out["cpp_caller_ms"] = cpp.get("ms_per_step")
             out["cpp_caller"] = cpp
         out.update(extras)
+        # the blend's issue fraction on the frames it is the long pole of (counters of the same frames' committed PMC passes)
+        for key, pm in (("pose_far", "blend_insts_far"), ("pose_outside", "blend_insts_outside"), ("blend_bound", "blend_insts_bound")):
+            if key in extras and default_frame and not distributed and pm in tj:
+                fr = blend_issue_fractions(tj[pm], extras[key]["stage_ms"].get("blend", 0.0))
+                extras[key]["blend_issue"] = {k: fr[k] for k in ("valu_frac", "valu_frac_one_wave", "mean_waves_per_simd", "valu_insts") if k in fr}
+                extras[key]["blend_issue"]["kernel"] = tj[pm].get("kernel")
         if "serial_emit" in extras and dom == "duplicate":
             # the dominant kernel with nothing beside it (the frames of GSR_FLAG_SERIAL_EMIT above)
             alone_ms = extras["serial_emit"]["stage_ms"].get("duplicate", 0.0)

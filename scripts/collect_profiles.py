@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kernel_stats_table as kst
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC, DST = f"gpurun_out/{ROUND}", "profiles"
 
 
@@ -18,6 +18,16 @@ HEADERS = {
                    "# The first dozen frames after a few milliseconds of idling run on lower clocks, whatever the tile history (settled after two calls):\n"
                    "# bench.py renders --spinup (16) untimed frames before its warm-up steps (config.spinup_frames).\n"),
     "micro_event_gap": ("# scripts/micro/event_gap.hip on one MI355X: kernel A, [event], kernel B on one stream; a second stream waits for the event and runs kernel C\n"),
+    "micro_valu_issue": ("# scripts/micro/valu_issue.hip on one MI355X: what a wave-instruction of the classes the blend is made of holds a SIMD for, by the\n"
+                         "# number of waves resident on the SIMD. First figure: cycles of the median wave; in brackets: from the kernel's WALL time (launch and\n"
+                         "# tail included) — the conservative one, which bench.py's VALU_CYCLES are taken from (4 and 8 waves per SIMD).\n"),
+    "deep_tiles": ("# python scripts/deep_tiles_table.py on one MI355X: blend stage (ms, HIP events) with one wave per tile and with 4 / 8 / 16 waves that share a\n"
+                   "# tile's walk (GSR_FLAG_NO_DEEP_TILES, GSR_FLAG_DEEP_TILES_ALL, GSR_FLAG_DEEP_WAVES_8 / _16), and what the library picks by itself.\n"),
+    "path_stages": ("# python scripts/path_stages.py on one MI355X: stage times (ms, HIP events of a profiled frame) along bench.py's camera path, every 4th pose;\n"
+                    "# frame = host time of an unprofiled frame of the same pose; ovl = the blend ran beside the emission (its time then lies inside the emission's).\n"
+                    "# Poses 0-32 (fewer than 12 instances per visible Gaussian): four waves per tile (round 5: blend 0.50-0.59 ms there).\n"),
+    "ply_path": ("# python scripts/ply_path.py on one MI355X: BASELINE config 2's code path at its size — a 5 834 784-splat scene FILE in the reference's format\n"
+                 "# (scripts/make_ply.py from scenes.trained_like: the garden .ply is not available offline) through the loader and the forward.\n"),
 }
 
 
@@ -85,7 +95,10 @@ def main():
         for name, what in (("head_sq", "headline frame"), ("head_lds", "headline frame"), ("head_fetch", "headline frame"),
                            ("head_write", "headline frame"), ("precomp_fetch", "headline frame, --colors-precomp"),
                            ("precomp_write", "headline frame, --colors-precomp"), ("bound_sq", "opacities x 0.1"),
-                           ("outside_sq", "pose (0,0,-14)"), ("far_sq", "pose (0,0,-30)"),
+                           ("outside_sq", "pose (0,0,-14)"), ("far_sq", "pose (0,0,-30)"), ("far_onewave_sq", "pose (0,0,-30), --no-deep-tiles"),
+                           ("head_cls", "headline frame"), ("head_cls2", "headline frame"), ("far_cls", "pose (0,0,-30)"), ("far_cls2", "pose (0,0,-30)"),
+                           ("far_onewave_cls", "pose (0,0,-30), --no-deep-tiles"), ("far_onewave_cls2", "pose (0,0,-30), --no-deep-tiles"),
+                           ("bound_cls", "opacities x 0.1"), ("bound_cls2", "opacities x 0.1"), ("outside_cls", "pose (0,0,-14)"), ("outside_cls2", "pose (0,0,-14)"),
                            ("stress_fetch", "50 M stress scene"), ("stress_write", "50 M stress scene"),
                            ("stress_precomp_fetch", "50 M stress scene, --colors-precomp"),
                            ("stress_precomp_write", "50 M stress scene, --colors-precomp")):
@@ -121,26 +134,33 @@ def main():
     old = json.load(open(f"{DST}/pmc_traffic_r01.json"))
     out["sort"] = old.get("sort", {})
     out["sort_note"] = "sort-plan figures are round 1's (profiles/r01_final_pmc.txt): that plan's kernels other than the blend are unchanged"
-    b = sq.get("blend_blocks_kernel", {})
+    blend_kernels = ("blend_blocks_kernel", "blend_deep_kernel", "blend_deep8_kernel", "blend_deep16_kernel", "blend_group_kernel", "blend_wave_kernel")
+
+    def blend_counters(*sets):
+        """The blend kernel's counters of several PMC passes of one frame, merged (per launch averages)."""
+        merged, kern = {}, None
+        for name in sets:
+            pv = pmc_values(name)
+            k = next((k for k in blend_kernels if k in pv), None)
+            if k:
+                kern = kern or k
+                merged.update({n: v for n, v in pv[k].items() if n not in ("dispatches", "avg_us") or n not in merged})
+        return (dict(merged, kernel=kern, clock_ghz=2.4) if merged else {})
+
+    b = blend_counters("head_sq", "head_cls", "head_cls2")
     if "SQ_INSTS_VALU" in b:
-        out["blend_insts"] = {"SQ_INSTS_VALU": b["SQ_INSTS_VALU"], "SQ_INSTS_SALU": b["SQ_INSTS_SALU"],
-                              "SQ_WAVE_CYCLES": b.get("SQ_WAVE_CYCLES"), "SQ_WAIT_ANY": b.get("SQ_WAIT_ANY"),
-                              "SQ_ACTIVE_INST_ANY": b.get("SQ_ACTIVE_INST_ANY"), "clock_ghz": 2.4,
-                              "source": f"profiles/{ROUND}_pmc.txt, set head_sq"}
-    for name in ("bound_sq", "outside_sq", "far_sq"):
-        pv = pmc_values(name)
-        # (sparse frames blend from the sorted lists: blend_wave_kernel)
-        kern = next((k for k in ("blend_blocks_kernel", "blend_deep_kernel", "blend_group_kernel", "blend_wave_kernel") if k in pv), None)
-        v = pv.get(kern, {}) if kern else {}
+        out["blend_insts"] = dict(b, source=f"profiles/{ROUND}_pmc.txt, sets head_sq / head_cls / head_cls2")
+    for frame in ("bound", "outside", "far", "far_onewave"):
+        v = blend_counters(f"{frame}_sq", f"{frame}_cls", f"{frame}_cls2")
         if v:
-            v = dict(v, kernel=kern)
-            out[f"blend_insts_{name.split('_')[0]}"] = v
+            out[f"blend_insts_{frame}"] = v
     json.dump(out, open(f"{DST}/pmc_traffic_{ROUND}.json", "w"), indent=1)
     import shutil
     if os.path.exists(f"{SRC}/band_projection.json"):
         shutil.copy(f"{SRC}/band_projection.json", f"{DST}/band_projection.json")
     for txt in ("band_timings", "band_timings_4k", "parity", "soak", "history_similarity", "soak_trained_like", "micro_gather_dc",
-                "micro_scatter_records", "micro_xcd_placement", "micro_event_gap", "clock_ramp"):
+                "micro_scatter_records", "micro_xcd_placement", "micro_event_gap", "clock_ramp", "micro_valu_issue", "deep_tiles", "path_stages",
+                "ply_path", "soak_garden_like"):
         if os.path.exists(f"{SRC}/{txt}.txt"):
             head = HEADERS.get(txt)
             if head:

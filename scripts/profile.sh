@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile collection of a round, run ON THE GPU BOX from the repo root (one gpurun call per part: PART=a|b|c|d|e):
-#   ROUND=r05 PART=a bash scripts/profile.sh
+#   ROUND=r06 PART=a bash scripts/profile.sh
 # Everything lands under gpurun_out/$ROUND/; `python scripts/collect_profiles.py $ROUND` turns it into profiles/${ROUND}_*.
 # (One parametrised pair since round 5; the per-round copies of rounds 1-4 are in the history: git log -- scripts/.)
 # rocprofv3 runs: kernel trace + stats in one run, every PMC counter set in a run of its own (the pool refuses
@@ -8,7 +8,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 HEAD="--steps 20 --warmup 5 --no-cpu-baseline --no-extras"
@@ -27,6 +27,9 @@ pmc() {     # <name> <counters> <bench args...>
 }
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 LDS="SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"
+# the blend's instruction classes (bench.py: blend_issue_fractions) and what its waves wait for
+CLS="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT"
+CLS2="SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"
 
 if [ "$PART" = "a" ]; then
   # 1. the headline command, with everything it prints (this is what the driver's BENCH run will be)
@@ -45,12 +48,23 @@ if [ "$PART" = "a" ]; then
   pmc head_lds "$LDS" $SHORT
   pmc precomp_fetch "FETCH_SIZE" $SHORT --colors-precomp
   pmc precomp_write "WRITE_SIZE" $SHORT --colors-precomp
+  pmc head_cls "$CLS" $SHORT
+  pmc head_cls2 "$CLS2" $SHORT
 fi
 if [ "$PART" = "b" ]; then
   # 4. PMC passes on the blend-bound frames (the blend kernel is what is read from these) and the 50 M frame's preprocess
   pmc bound_sq "$SQ" $SHORT --opacity-scale 0.1
   pmc outside_sq "$SQ" $SHORT --pose 0,0,-14
   pmc far_sq "$SQ" $SHORT --pose 0,0,-30
+  pmc far_cls "$CLS" $SHORT --pose 0,0,-30
+  pmc far_cls2 "$CLS2" $SHORT --pose 0,0,-30
+  pmc far_onewave_sq "$SQ" $SHORT --pose 0,0,-30 --no-deep-tiles
+  pmc far_onewave_cls "$CLS" $SHORT --pose 0,0,-30 --no-deep-tiles
+  pmc far_onewave_cls2 "$CLS2" $SHORT --pose 0,0,-30 --no-deep-tiles
+  pmc bound_cls "$CLS" $SHORT --opacity-scale 0.1
+  pmc bound_cls2 "$CLS2" $SHORT --opacity-scale 0.1
+  pmc outside_cls "$CLS" $SHORT --pose 0,0,-14
+  pmc outside_cls2 "$CLS2" $SHORT --pose 0,0,-14
   trace stress50M $SHORT --scene stress --splats 50000000
   trace stress50M_precomp $SHORT --scene stress --splats 50000000 --colors-precomp
   pmc stress_precomp_fetch "FETCH_SIZE" $SHORT --scene stress --splats 50000000 --colors-precomp
@@ -90,6 +104,11 @@ if [ "$PART" = "e" ]; then
   ./scripts/micro/scatter_records > $OUT/micro_scatter_records.txt 2>&1
   ./scripts/micro/xcd_placement > $OUT/micro_xcd_placement.txt 2>&1
   ./scripts/micro/event_gap > $OUT/micro_event_gap.txt 2>&1
+  ./scripts/micro/valu_issue > $OUT/micro_valu_issue.txt 2>&1
+  python3 scripts/deep_tiles_table.py 2>/dev/null > $OUT/deep_tiles.txt
+  python3 scripts/path_stages.py 2>/dev/null > $OUT/path_stages.txt
+  timeout -k 10 400 python3 scripts/ply_path.py 2>/dev/null > $OUT/ply_path.txt
+  timeout -k 10 600 python3 scripts/soak_parity.py 60 1000000 1280 720 garden_like > $OUT/soak_garden_like.txt 2>&1
   python3 scripts/clock_ramp.py 2>/dev/null > $OUT/clock_ramp.txt
 fi
 ls -la $OUT | head -80
