@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profile collection of a round, run ON THE GPU BOX from the repo root (one gpurun call per part: PART=a|b|c|d|e):
+# Profile collection of a round, run ON THE GPU BOX from the repo root (one gpurun call per part: PART=a|b|c|d|e|f):
 #   ROUND=r06 PART=a bash scripts/profile.sh
 # Everything lands under gpurun_out/$ROUND/; `python scripts/collect_profiles.py $ROUND` turns it into profiles/${ROUND}_*.
 # (One parametrised pair since round 5; the per-round copies of rounds 1-4 are in the history: git log -- scripts/.)
@@ -99,7 +99,11 @@ if [ "$PART" = "e" ]; then
     set -- $a
     python3 scripts/thresholds_check.py $1 $2 60 2>/dev/null > $OUT/thresholds_$1_$2.txt
   done
-  timeout -k 10 900 python3 scripts/soak_parity.py 60 1000000 1280 720 trained_like > $OUT/soak_trained_like.txt 2>&1
+  python3 scripts/clock_ramp.py 2>/dev/null > $OUT/clock_ramp.txt
+fi
+if [ "$PART" = "f" ]; then
+  # 8. parity soaks against the oracle (every third pose from far out: deep tiles), the micro-benchmarks, the deep tiles' table, the PLY path
+  timeout -k 10 500 python3 scripts/soak_parity.py 60 1000000 1280 720 trained_like > $OUT/soak_trained_like.txt 2>&1
   ./scripts/micro/gather_dc > $OUT/micro_gather_dc.txt 2>&1
   ./scripts/micro/scatter_records > $OUT/micro_scatter_records.txt 2>&1
   ./scripts/micro/xcd_placement > $OUT/micro_xcd_placement.txt 2>&1
@@ -108,7 +112,6 @@ if [ "$PART" = "e" ]; then
   python3 scripts/deep_tiles_table.py 2>/dev/null > $OUT/deep_tiles.txt
   python3 scripts/path_stages.py 2>/dev/null > $OUT/path_stages.txt
   timeout -k 10 400 python3 scripts/ply_path.py 2>/dev/null > $OUT/ply_path.txt
-  timeout -k 10 600 python3 scripts/soak_parity.py 60 1000000 1280 720 garden_like > $OUT/soak_garden_like.txt 2>&1
-  python3 scripts/clock_ramp.py 2>/dev/null > $OUT/clock_ramp.txt
+  timeout -k 10 500 python3 scripts/soak_parity.py 60 1000000 1280 720 garden_like > $OUT/soak_garden_like.txt 2>&1
 fi
 ls -la $OUT | head -80
