@@ -161,9 +161,12 @@ constexpr uint64_t kOverlapMinInstances = 16;     // the blend may run beside th
 // Gaussian: short lists of small splats, where a frame ends on the lone waves of its few deep tiles and four waves per tile
 // cost the others next to nothing. Blend, one wave per tile -> four, bench scene (`profiles/r06_deep_tiles.txt`): R/V = 3.6: 0.66 ->
 // 0.30 ms, 5.3: 0.54 -> 0.31, 7.3: 0.54 -> 0.43, 11: 0.60 -> 0.59, 16: 0.63 -> 0.66, 23: 0.46 -> 0.56 (long lists that few
-// records of survive: the walk is the work, and the four waves meet at a barrier every 256 entries of it). Above it: one
+// records of survive: the walk is the work, and the four waves meet at a barrier every 256 entries of it); on 49 unrelated
+// views of the same scene (bench.py's random views, serial blends): 0.57-0.97 of one wave's time up to 12, 0.83-1.00 at 12-16,
+// 0.94-1.06 at 16-24, up to 1.23 beyond. The switch is at 16 — where the blend may start to run beside the emission
+// (kOverlapMinInstances), fed from the block lists, which have no deep tiles. Above it: one
 // wave per tile (four for the history's slowest tiles only was built and measured neutral there: GSR_DEEP_BY_HISTORY).
-constexpr uint64_t kDeepAllMaxInstances = 12;
+constexpr uint64_t kDeepAllMaxInstances = 16;
 constexpr size_t kMaxDefaultHistories = 8;        // streams per host thread and device that get a history of the library's own
 
 int tile_history_new(gsr_tile_history** out) {

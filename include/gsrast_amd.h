@@ -180,7 +180,7 @@ enum {
  * tile's list together (one fetch, one footprint test per entry) and composite one 16 x 4 strip each — a wave alone on its
  * SIMD issues a vector instruction every five cycles where the SIMD takes one every two or three, and a frame of small
  * splats lasts as long as the lone waves of its few deep tiles. Same pixels, finalT, nContrib, records_staged: every pixel
- * sees the same records in the same order. By default every tile of a frame with fewer than 12 instances per visible
+ * sees the same records in the same order. By default every tile of a frame with fewer than 16 instances per visible
  * Gaussian is composited that way (and every tile of a call with few tiles: a rank's band of a sharded frame); plan_used
  * then carries GSR_PLAN_DEEP_TILES. GSR_FLAG_NO_DEEP_TILES: never; GSR_FLAG_DEEP_TILES_ALL: whatever the frame (a
  * diagnostic, and what the tests compare the ordinary way against). Neither reads nor needs a tile history. */

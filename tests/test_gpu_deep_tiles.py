@@ -103,7 +103,7 @@ def test_deep_tiles_under_the_upstream_semantics():
 
 
 def test_sparse_frames_take_the_deep_way_by_themselves_and_nothing_changes():
-    """Below 12 instances per visible Gaussian every tile is composited by four waves without anybody asking (no history
+    """Below 16 instances per visible Gaussian every tile is composited by four waves without anybody asking (no history
     needed: the rule is R against V), above it none is; with and without the tile history, which only orders the tiles, every
     frame is the bits of the ordinary way. Then the camera jumps between the two regimes."""
     import torch
@@ -120,7 +120,7 @@ def test_sparse_frames_take_the_deep_way_by_themselves_and_nothing_changes():
         r.draw(c, plan="sort", tile_history=False, deep_tiles=False, count_staged=True)
         refs.append((_state(r), r.last_records_staged))
         visible = int((r.map_geometry_state()["tilesTouched"] != 0).sum().item())
-        sparse.append(r.last_num_rendered < 12 * visible)
+        sparse.append(r.last_num_rendered < 16 * visible)
     assert sparse[0] and sparse[1] and not sparse[2], sparse          # (far away: a tile or two per splat; close up: dozens)
     for hist in (False, True):
         for c in (0,) * 5 + (1,) * 3 + (2,) * 4 + (0,) * 3:
