@@ -1138,9 +1138,14 @@ int gsr_forward(gsr_forward_args* a) {
     const bool list_fed = !(use_blocks && !blend_from_lists);
     const bool deep_wanted = env.deep_by_history && list_fed && t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES);
     const uint32_t deep_forced = a->flags & (GSR_FLAG_DEEP_TILES_ALL | GSR_FLAG_DEEP_WAVES_8 | GSR_FLAG_DEEP_WAVES_16);
-    const bool deep_all = list_fed && (deep_forced != 0u ||
-                                       (!(a->flags & GSR_FLAG_NO_DEEP_TILES) &&
-                                        (uint64_t)R < (env.deep_all_max >= 0 ? (uint64_t)env.deep_all_max : kDeepAllMaxInstances) * (uint64_t)nv));
+    // (not where geomState.rgb is written BESIDE the blend — scenes beyond 16 M Gaussians, colors_late below —: eight deep
+    // workgroups a CU hold every vector register of its SIMDs, the colours kernel waits for them to retire and the frame for
+    // the colours kernel: 50 M Gaussians 5.09 -> 5.33 ms, 5.13-5.22 with the blend kept to 5-6 workgroups a CU by idle LDS;
+    // with the colours passed as colorsPrecomp there is no such kernel: 4.37 -> 4.29)
+    const bool colours_beside_blend = colors_mode == 2;
+    const bool deep_by_rule = !colours_beside_blend && !(a->flags & GSR_FLAG_NO_DEEP_TILES) &&
+                              (uint64_t)R < (env.deep_all_max >= 0 ? (uint64_t)env.deep_all_max : kDeepAllMaxInstances) * (uint64_t)nv;
+    const bool deep_all = list_fed && (deep_forced != 0u || deep_by_rule);
     // How many waves a deep tile gets: four — or eight, sixteen where the history says the frame's work sits in few tiles:
     // tiles x mean / longest is how many tiles AS LONG AS THE LONGEST the frame amounts to; with fewer of them than the chip has
     // SIMDs eight waves per tile win, with fewer than a quarter sixteen (measured, blend with 4 / 8 / 16 waves per tile,
