@@ -538,7 +538,8 @@ def load_profile_json(*names):
 # cost an issue roofline is made of. (A wave ALONE on its SIMD issues every 5 cycles whatever the class — 8 for the
 # transcendentals and the conversions, 25 to 33 for a compare whose mask a scalar instruction then reads: what a frame's last,
 # lone waves run at, and what the blend's deep tiles are there to avoid. That figure is `valu_frac_one_wave`, not a roofline.)
-VALU_CYCLES = {"f32": 2.7, "trans_f32": 7.5, "f64": 4.3, "cvt": 4.1, "int": 2.7, "other": 4.0, "mix": 3.1}
+# ("other": what no class counter claims — compares into a scalar pair and selects on one at 4.0, moves and bit operations at 2.3)
+VALU_CYCLES = {"f32": 2.7, "trans_f32": 7.5, "f64": 4.3, "cvt": 4.1, "int": 2.7, "other": 3.3, "mix": 3.1}
 VALU_CLASS_COUNTERS = {"f32": ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"), "trans_f32": ("SQ_INSTS_VALU_TRANS_F32",),
                        "f64": ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"), "cvt": ("SQ_INSTS_VALU_CVT",),
                        "int": ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64")}
