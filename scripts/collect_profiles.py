@@ -25,7 +25,7 @@ HEADERS = {
                    "# tile's walk (GSR_FLAG_NO_DEEP_TILES, GSR_FLAG_DEEP_TILES_ALL, GSR_FLAG_DEEP_WAVES_8 / _16), and what the library picks by itself.\n"),
     "path_stages": ("# python scripts/path_stages.py on one MI355X: stage times (ms, HIP events of a profiled frame) along bench.py's camera path, every 4th pose;\n"
                     "# frame = host time of an unprofiled frame of the same pose; ovl = the blend ran beside the emission (its time then lies inside the emission's).\n"
-                    "# Poses 0-32 (fewer than 12 instances per visible Gaussian): four waves per tile (round 5: blend 0.50-0.59 ms there).\n"),
+                    "# Poses 0-40 (fewer than 16 instances per visible Gaussian): four waves per tile (round 5, one wave: blend 0.50-0.62 ms there).\n"),
     "ply_path": ("# python scripts/ply_path.py on one MI355X: BASELINE config 2's code path at its size — a 5 834 784-splat scene FILE in the reference's format\n"
                  "# (scripts/make_ply.py from scenes.trained_like: the garden .ply is not available offline) through the loader and the forward.\n"),
 }
