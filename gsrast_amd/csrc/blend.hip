@@ -48,13 +48,11 @@ struct BlendParams {
 };
 
 // One wave per tile leaves most of the chip idle when few tiles have a list, and the frame lasts as long as the slowest
-// of them. Four waves then share a tile: one 16 x 4 strip each, every wave walking the whole list but keeping, at
-// staging, only what can reach ITS strip. That repeats the walk four times and divides the compositing by up to four,
-// so it pays where the chip has room for the repeated walk (few tiles), or where the walk is short and the compositing
-// is the work (a scene seen from far away: short lists of splats smaller than a tile — eye (0,0,-50) on the bench
-// scene, 3 712 tiles with a list, 210 entries each on average: blend 0.84 -> 0.34 ms). With thousands of deep lists
-// the repeated walk costs more than the shorter chains save (full-screen frames with four waves per tile: 0.46 -> 1.27
-// ms from outside the cloud, 0.66 -> 1.01 ms from (0,0,-30): `gpurun_out/s12`).
+// of them: calls with few tiles with a list (a rank's band of a sharded frame; a scene seen from far away: short lists of
+// splats smaller than a tile) give every tile the four waves of a deep tile (below), decided on the device from the
+// count of tiles that got a list. Rounds 2-5 had four INDEPENDENT waves for such tiles, each walking the whole list for
+// its 16 x 4 strip (eye (0,0,-50) on the bench scene, 3 712 tiles with a list, 210 entries each: blend 0.84 -> 0.34 ms
+// then, 0.24 with the shared walk, 0.21 with eight waves).
 constexpr uint32_t kStripTilesAny = 1536;        // tiles with a list up to which four waves share a tile whatever the lists
 constexpr uint32_t kStripTilesShort = 4096;      // ... and up to which they do when the lists are short:
 constexpr uint32_t kStripMeanList = 1024;        // entries per tile with a list, on average
@@ -73,21 +71,23 @@ constexpr uint32_t kPriorityMeanList = 8192;     // entries per tile with a list
 // ---- DEEP tiles: four waves per tile, ONE walk ------------------------------------------------
 // A frame's blend lasts as long as its slowest tiles, and a wave alone on its SIMD issues a vector instruction every five
 // cycles where the SIMD could take one every two (scripts/micro/valu_issue.hip): from (0,0,-30) a tenth of the tiles runs
-// beyond 335 us, one wave each, while the rest of the chip has long finished (`profiles/r04_blend_tile_times.txt`). The
-// tiles the history expects to be that slow (tile_order_kernel: `deep_count` leading entries of the order) get the whole
-// workgroup: the four waves WALK the list together — a round is 256 list entries, wave w fetches, culls and stages entries
+// beyond 335 us, one wave each, while the rest of the chip has long finished (`profiles/r04_blend_tile_times.txt`). A deep
+// tile gets a whole workgroup — which tiles: every tile of a frame of fewer than 16 instances per visible Gaussian (the
+// host's rule, api.hip: kDeepAllMaxInstances), every tile of a call with few tiles (`strips`, above), or, behind
+// GSR_DEEP_BY_HISTORY, the `deep_count` leading entries of the history's order (tile_order_kernel) —: the four waves WALK
+// the list together — a round is 256 list entries, wave w fetches, culls and stages entries
 // [64 w, 64 w + 64) of it into segment w of the shared staging area, with every survivor the strips it can reach at all —
 // and each wave COMPOSITES one 16 x 4 strip over the four segments in list order, taking only the slots that can reach its
 // strip. The list is read once and culled once per tile; per record a wave pays the filter and one strip's evaluation
 // instead of four. T, nContrib and every decision are those of one wave per tile (same functions, same order per pixel);
 // the staged-record count follows from WHERE the tile finished: the reference stages a batch of 256 when its first
 // position is reached with some pixel unfinished, i.e. every batch that starts before the record the last pixel
-// finished on. Two barriers a round. Workgroups of the launch: [0, base) one DEEP tile each (those beyond the deep count
-// leave at once), then groups of four ordinary tiles, a wave each (no barrier there: the waves never meet).
-// The frames that have few tiles with a list (`strips`) take the same way for every tile.
+// finished on. One or two barriers a round (two staging areas or one), which wait for the wave's LDS traffic only.
+// Workgroups of the MIXED launch (blend_group_kernel): [0, base) one DEEP tile each (those beyond the deep count leave at
+// once), then groups of four ordinary tiles, a wave each (no barrier there: the waves never meet).
 constexpr int kGroupWaves = 4;
-constexpr uint32_t kDeepGainX16 = 40;            // a deep tile takes 1 / 2.5 of one wave's time (tile_order_kernel, DeepRule)
-constexpr uint32_t kDeepFracX16 = 6;             // deep from 3/8 of the longest estimate
+constexpr uint32_t kDeepGainX16 = 40;            // a deep tile takes 1 / 2.5 of one wave's time: what its recorded time counts as (tile_order_kernel)
+constexpr uint32_t kDeepFracX16 = 6;             // GSR_DEEP_BY_HISTORY: deep from 3/8 of the longest estimate
 constexpr uint32_t kDeepFloorTicks = 4000;       // ... but never below 40 us
 constexpr uint32_t kDeepFlag = 0x80000000u;      // in a tile's recorded time: it was composited by four waves
 // MODE 0, blend_wave_kernel: the launch of the frames that have no use for deep tiles (the host knows: launch_blend) — a workgroup is ONE
