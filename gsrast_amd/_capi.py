@@ -157,6 +157,7 @@ SIGNATURES = {
     "gsr_tile_history_forget_stream": (C.c_int, [C.c_void_p]),
     "gsr_tile_history_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]),
     "gsr_thread_release": (C.c_int, []),
+    "gsr_reread_environment": (None, []),
     "gsr_device_shape": (None, [C.c_int, C.POINTER(C.c_uint32)]),
     "gsr_higher_msb": (C.c_uint32, [C.c_uint32]),
     "gsr_scan_temp_bytes": (C.c_size_t, [C.c_size_t]),

@@ -284,27 +284,31 @@ struct EnvKnobs {
     bool deep_by_history;      // GSR_DEEP_BY_HISTORY=1: above that, the history's slowest tiles get four waves (tile_order_kernel's
                                // count; measured neutral, `profiles/r06_deep_tiles.txt`: off by default)
 };
-const EnvKnobs& env_knobs() {
-    static const EnvKnobs k = [] {
-        EnvKnobs e;
-        const char* h = getenv("GSR_TILE_HISTORY");
-        e.tile_history = !(h && h[0] == '0');
-        const char* c = getenv("GSR_COLORS_BESIDE");
-        e.colors_beside = c && c[0] >= '0' && c[0] <= '2' ? c[0] - '0' : -1;
-        const char* f = getenv("GSR_FUSED_DEPTH");
-        e.fused_depth = f && (f[0] == '0' || f[0] == '1') ? f[0] - '0' : -1;
-        const char* b = getenv("GSR_BLOCK_FEED_MIN");
-        e.block_feed_min = b && b[0] ? atol(b) : -1;
-        const char* d = getenv("GSR_DEEP_ALL_MAX");
-        e.deep_all_max = d && d[0] ? atol(d) : -1;
-        const char* dw = getenv("GSR_DEEP_WAVES_AUTO");
-        e.deep_waves_auto = !(dw && dw[0] == '0');
-        const char* dh = getenv("GSR_DEEP_BY_HISTORY");
-        e.deep_by_history = dh && dh[0] == '1';
-        return e;
-    }();
+EnvKnobs read_env_knobs() {
+    EnvKnobs e;
+    const char* h = getenv("GSR_TILE_HISTORY");
+    e.tile_history = !(h && h[0] == '0');
+    const char* c = getenv("GSR_COLORS_BESIDE");
+    e.colors_beside = c && c[0] >= '0' && c[0] <= '2' ? c[0] - '0' : -1;
+    const char* f = getenv("GSR_FUSED_DEPTH");
+    e.fused_depth = f && (f[0] == '0' || f[0] == '1') ? f[0] - '0' : -1;
+    const char* b = getenv("GSR_BLOCK_FEED_MIN");
+    e.block_feed_min = b && b[0] ? atol(b) : -1;
+    const char* d = getenv("GSR_DEEP_ALL_MAX");
+    e.deep_all_max = d && d[0] ? atol(d) : -1;
+    const char* dw = getenv("GSR_DEEP_WAVES_AUTO");
+    e.deep_waves_auto = !(dw && dw[0] == '0');
+    const char* dh = getenv("GSR_DEEP_BY_HISTORY");
+    e.deep_by_history = dh && dh[0] == '1';
+    return e;
+}
+// (read when the first call needs them; gsr_reread_environment — the tests' and A/B scripts' way of changing a knob inside one
+// process — reads them again: no call may be in flight on another thread meanwhile)
+EnvKnobs& env_knobs_storage() {
+    static EnvKnobs k = read_env_knobs();
     return k;
 }
+const EnvKnobs& env_knobs() { return env_knobs_storage(); }
 
 // The calling thread's resources for the CURRENT device.
 int current_readback(Readback*& out) {
@@ -545,6 +549,8 @@ int gsr_tile_history_destroy(gsr_tile_history* h) {
     destroy_history(h);
     return fail(GSR_OK);
 }
+
+void gsr_reread_environment(void) { env_knobs_storage() = read_env_knobs(); }
 
 int gsr_thread_release(void) {
     g_hip_error[0] = 0;

@@ -509,14 +509,14 @@ def test_depth_keys_outside_the_main_top_byte(near, extra):
 
 
 @pytest.mark.parametrize("case", ["top_byte_side_way", "top_byte_fallback", "anisotropic", "ragged_tail", "trained_like_far"])
-def test_first_depth_pass_without_the_compaction(case, monkeypatch):
+def test_first_depth_pass_without_the_compaction(case, library_env):
     """Scenes beyond 16 M Gaussians skip the compaction of the visible keys: the first depth pass reads the per-Gaussian keys
     itself and leaves out what has no tile (onesweep_kernel, DROP; GSR_FUSED_DEPTH=1 forces that route at any size). Same
     lists, ranges and pixels as the oracle's — with keys on the side list, with the four-pass fallback, with a last tile
     that is mostly padding, and with culled Gaussians between the visible ones."""
     from gsrast_amd import camera, scenes
     from oracle import cpu_oracle
-    monkeypatch.setenv("GSR_FUSED_DEPTH", "1")
+    library_env(GSR_FUSED_DEPTH="1")
     bg = (0.1, 0.2, 0.3)
     if case in ("top_byte_side_way", "top_byte_fallback"):
         n, w, h = 3000, 320, 200

@@ -180,7 +180,7 @@ def test_backward_after_a_reordered_frame_is_unchanged():
 
 
 @pytest.mark.parametrize("where", ["1", "2"])
-def test_colours_written_beside_the_depth_sort_are_the_preprocess_kernels(where, monkeypatch):
+def test_colours_written_beside_the_depth_sort_are_the_preprocess_kernels(where, library_env):
     """geomState.rgb by a kernel of its own on the library's second stream (GSR_PLAN_COLORS_BESIDE) against the preprocess
     kernel writing it (GSR_FLAG_SERIAL_EMIT): the same bits for every Gaussian, zeros for the culled ones, with and without
     instances (R == 0 returns before the blend: the caller's stream must have waited all the same), on a band, and the
@@ -188,7 +188,7 @@ def test_colours_written_beside_the_depth_sort_are_the_preprocess_kernels(where,
     record's colour straight from the SH array (the library's choice beyond 16 M Gaussians; forced here through the
     environment, as is "1" — beside the depth sort, its choice at this size)."""
     import torch
-    monkeypatch.setenv("GSR_COLORS_BESIDE", where)
+    library_env(GSR_COLORS_BESIDE=where)
     from gsrast_amd import camera, scenes
     from gsrast_amd.rasterizer import SplatRasterizer
     w, h = 512, 288
@@ -197,7 +197,9 @@ def test_colours_written_beside_the_depth_sort_are_the_preprocess_kernels(where,
     r = SplatRasterizer(w, h, background=(0.1, 0.2, 0.3))
     r.configure_from_scene(scene)
     cam = camera.default_camera(w, h, near=0.05, far=50.0)
-    for kw in ({}, {"plan": "sort"}, {"plan": "blocks", "overlap_emit": True}, {"tile_rows": (3, 11)}):
+    # (deep tiles: the four waves of a tile take the records' colours from the SH array too, where = "2")
+    for kw in ({}, {"plan": "sort"}, {"plan": "sort", "deep_tiles": "all"}, {"plan": "sort", "deep_tiles": "all8"},
+               {"plan": "blocks", "overlap_emit": True}, {"tile_rows": (3, 11)}):
         img0 = r.draw(cam, **{**kw, "overlap_emit": False}).clone()
         assert not r.last_colors_beside
         rgb0 = r.map_geometry_state()["rgb"].clone()
