@@ -286,7 +286,7 @@ __device__ __forceinline__ void blend_wave_body(const BlendParams& p) {
 }
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_wave_kernel(const BlendParams p) { blend_wave_body<kBlendSingle>(p); }
-__global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(5))) void blend_group_kernel(const BlendParams p) { blend_wave_body<kBlendGrouped>(p); }
+__global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(4))) void blend_group_kernel(const BlendParams p) { blend_wave_body<kBlendGrouped>(p); }
 __global__ __launch_bounds__(kGroupWaves * kWave) __attribute__((amdgpu_waves_per_eu(8))) void blend_deep_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly>(p); }
 __global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(8))) void blend_deep8_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly, 8>(p); }
 __global__ __launch_bounds__(16 * kWave) __attribute__((amdgpu_waves_per_eu(4))) void blend_deep16_kernel(const BlendParams p) { blend_wave_body<kBlendDeepOnly, 16>(p); }

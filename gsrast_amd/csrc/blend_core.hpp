@@ -385,7 +385,8 @@ __device__ __forceinline__ bool stage_and_composite(TileLanes& s, const TileFeed
 // A round is 256 list entries; wave w fetches, culls and stages entries [64 w, 64 w + 64) into segment w, and composites ONE
 // 16 x 4 strip — one pixel per lane — over the four segments in list order, taking the slots that can reach its strip.
 struct DeepSegment {               // the survivors of a wave's 64 list entries, compacted
-    float4 head[kWave];            // centre x, y | the filter's floor in units of log2 (NaN: the record goes unfiltered) | its 1-based list position (bits)
+    float4 head[kWave];            // centre x, y | the filter's floor in units of log2 (-inf: none) | its 1-based list position (bits)
+    float4 filt[kWave];            // the filter's conic (pre-scaled as StagedRecords::co; zeros: the record goes unfiltered), w unused
     float4 raw[kWave];             // conic + opacity as fetched
     float4 rgb[kWave];             // colour (w unused)
     uint32_t touch[kWave];         // strips the record can reach at all (bit k: strip k)
@@ -425,7 +426,9 @@ __device__ __forceinline__ uint32_t stage_batch_deep(const TileFeed& f, DeepSegm
         const float p0 = -__logf(255.0f * b.co.w);
         const float floor2 = b.co.w != b.co.w ? -__builtin_inff() : (b.co.w <= 0.0f ? __builtin_inff() : (p0 - 1e-3f - 1e-6f * terms) * kLog2e);
         const bool filtered = terms < 1.0e6f;                                   // (NaN: not filtered)
-        seg.head[slot] = make_float4(b.xy.x, b.xy.y, filtered ? floor2 : __builtin_nanf(""), __uint_as_float(pos + rank + 1u));
+        seg.head[slot] = make_float4(b.xy.x, b.xy.y, filtered ? floor2 : -__builtin_inff(), __uint_as_float(pos + rank + 1u));
+        seg.filt[slot] = filtered ? make_float4((-0.5f * kLog2e) * b.co.x, -kLog2e * b.co.y, (-0.5f * kLog2e) * b.co.z, 0.0f)
+                                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         seg.raw[slot] = b.co;
         float c0 = c[0], c1 = c[1], c2 = c[2];
         if (f.dc_stride != 0u) { c0 = 0.5f + 0.4f * c0; c1 = 0.5f + 0.4f * c1; c2 = 0.5f + 0.4f * c2; }
@@ -451,57 +454,52 @@ __device__ __forceinline__ void strip_lanes_init(StripLanes& s, int tx, int ty, 
     s.T = 1.0f; s.cr = s.cg = s.cb = 0.0f; s.last = 0u;
 }
 __device__ __forceinline__ bool strip_lanes_all_done(const StripLanes& s) { return __ballot(s.fy == s.fy) == 0ull; }
-// composite_record for one strip: the same filter, the same reference-order evaluation, the same tests, per pixel the same
-// floats in the same order (scalar single-precision operations round as the packed ones do; nothing here is contracted).
-__device__ __forceinline__ bool composite_strip_record(StripLanes& s, const DeepSegment& seg, uint32_t j, float t_cutoff,
-                                                       const unsigned long long* exp_tab) {
-    constexpr float kAlphaMin = 1.0f / 255.0f;
-    const float4 hd = seg.head[j];
-    const float4 raw = seg.raw[j];
-    const float dx = hd.x - s.fx, dy = hd.y - s.fy;
-    unsigned long long cand;
-    if (hd.z == hd.z) {                                    // (wave-uniform)
-        const float h0 = (((-0.5f * kLog2e) * raw.x) * dx) * dx, g = (-kLog2e * raw.y) * dx;
-        const float fw = __builtin_fmaf(dy, __builtin_fmaf((-0.5f * kLog2e) * raw.z, dy, g), h0);
-        cand = __ballot(fw <= kFilterSlack * kLog2e) & __ballot(fw >= hd.z);
-    } else {
-        cand = __ballot(s.fy == s.fy);                     // every unfinished pixel: the reference's own tests decide alone
-    }
-    if (cand == 0ull) return false;
-    const float t1 = (raw.x * dx) * dx, bdx = raw.y * dx;
-    const float power = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
-    const float alpha = fminf(0.99f, raw.w * exp_ref(power, exp_tab));
-    const unsigned long long live = cand & ~__ballot(power > 0.0f) & ~__ballot(alpha < kAlphaMin);
-    const float test = s.T * (1.0f - alpha);
-    const unsigned long long stop = live & __ballot(test < t_cutoff);
-    if (__builtin_amdgcn_inverse_ballot_w64(live & ~stop)) {
-        const float4 col = seg.rgb[j];
-        const float w = alpha * s.T;
-        s.cr = __builtin_fmaf(col.x, w, s.cr);
-        s.cg = __builtin_fmaf(col.y, w, s.cg);
-        s.cb = __builtin_fmaf(col.z, w, s.cb);
-        s.T = test;
-        s.last = __float_as_uint(hd.w);
-    }
-    if (stop != 0ull) {
-        if (__builtin_amdgcn_inverse_ballot_w64(stop)) s.fy = __builtin_nanf("");
-        return true;
-    }
-    return false;
-}
-// The slots of `slots` (a lane mask over the segment's slots), in order. *done_at: the list position of the record the strip's
-// last pixel finished on.
+// composite_record for one strip, over the slots of `slots` (a lane mask over the segment's slots) in order: the same filter,
+// the same reference-order evaluation, the same tests, per pixel the same floats in the same order (scalar single-precision
+// operations round as the packed ones do; nothing here is contracted). One flat loop — the scalar unit of a CU serves its four
+// SIMDs, and with eight of these waves on every SIMD the loop's scalar instructions (45 % of all it issues) are what it
+// waits for: no call in it, one way through per record. *done_at: the list position of the record the strip's last
+// pixel finished on.
 __device__ __forceinline__ bool composite_strip(StripLanes& s, const DeepSegment& seg, unsigned long long slots, float t_cutoff,
                                                 const unsigned long long* exp_tab, uint32_t* done_at) {
-    while (slots != 0ull) {
+    constexpr float kAlphaMin = 1.0f / 255.0f;
+    // (one exit: `finished` is a scalar the loop's condition reads — an early return from inside the masked region made the
+    // compiler carry the way out in a vector register and compare it, a round trip through the scalar unit per record)
+    bool finished = false;
+    while (slots != 0ull && !finished) {
         const uint32_t j = (uint32_t)__builtin_ctzll(slots);
         slots &= slots - 1ull;
-        if (composite_strip_record(s, seg, j, t_cutoff, exp_tab) && strip_lanes_all_done(s)) {
-            *done_at = __float_as_uint(seg.head[j].w);
-            return true;
+        const float4 hd = seg.head[j];
+        const float4 q = seg.filt[j];
+        const float dx = hd.x - s.fx, dy = hd.y - s.fy;
+        // (an unfiltered record: zero conic, floor -inf — every unfinished pixel is its candidate, a finished one's dy is NaN)
+        const float fw = __builtin_fmaf(dy, __builtin_fmaf(q.z, dy, q.y * dx), (q.x * dx) * dx);
+        const unsigned long long cand = __ballot(fw <= kFilterSlack * kLog2e) & __ballot(fw >= hd.z);
+        if (cand != 0ull) {
+            const float4 raw = seg.raw[j];
+            const float t1 = (raw.x * dx) * dx, bdx = raw.y * dx;
+            const float power = -0.5f * (t1 + (raw.z * dy) * dy) - bdx * dy;
+            const float alpha = fminf(0.99f, raw.w * exp_ref(power, exp_tab));
+            const unsigned long long live = cand & ~(__ballot(power > 0.0f) | __ballot(alpha < kAlphaMin));
+            const float test = s.T * (1.0f - alpha);
+            const unsigned long long stop = live & __ballot(test < t_cutoff);
+            if (__builtin_amdgcn_inverse_ballot_w64(live & ~stop)) {
+                const float4 col = seg.rgb[j];
+                const float w = alpha * s.T;
+                s.cr = __builtin_fmaf(col.x, w, s.cr);
+                s.cg = __builtin_fmaf(col.y, w, s.cg);
+                s.cb = __builtin_fmaf(col.z, w, s.cb);
+                s.T = test;
+                s.last = __float_as_uint(hd.w);
+            }
+            if (stop != 0ull) {
+                s.fy = __builtin_amdgcn_inverse_ballot_w64(stop) ? __builtin_nanf("") : s.fy;
+                finished = __ballot(s.fy == s.fy) == 0ull;
+                *done_at = __float_as_uint(hd.w);          // (read by the caller only if the strip is finished: the last write is the one)
+            }
         }
     }
-    return false;
+    return finished;
 }
 __device__ __forceinline__ void strip_lanes_write(const StripLanes& s, int width, int height, const float* __restrict__ background,
                                                   float* __restrict__ final_t, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color) {
