@@ -1144,7 +1144,7 @@ int gsr_forward(gsr_forward_args* a) {
     const bool list_fed = !(use_blocks && !blend_from_lists);
     const bool deep_wanted = env.deep_by_history && list_fed && t_order != nullptr && !hist->decorrelated && !(a->flags & GSR_FLAG_NO_DEEP_TILES);
     const uint32_t deep_forced = a->flags & (GSR_FLAG_DEEP_TILES_ALL | GSR_FLAG_DEEP_WAVES_8 | GSR_FLAG_DEEP_WAVES_16);
-    // (not where geomState.rgb is written BESIDE the blend — scenes beyond 16 M Gaussians, colors_late below —: eight deep
+    // (not where geomState.rgb is written BESIDE the blend — scenes beyond 16 M Gaussians, colors_late above —: eight deep
     // workgroups a CU hold every vector register of its SIMDs, the colours kernel waits for them to retire and the frame for
     // the colours kernel: 50 M Gaussians 5.09 -> 5.33 ms, 5.13-5.22 with the blend kept to 5-6 workgroups a CU by idle LDS;
     // with the colours passed as colorsPrecomp there is no such kernel: 4.37 -> 4.29)
