@@ -77,14 +77,16 @@ GeoScratch carve_geo_scratch(char* base, size_t n) {
     g.side_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
     g.side_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
     g.side_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * kDepthSideMax);
+    // (three groups of three consecutive arrays: between its passes the depth order keeps the triples as 12-byte RECORDS in
+    // the room of a group — {a_k, a_v, a_r} and {b_k, b_v, b_r}, or {c_k, c_v, c_r} where there is no compaction to fill them)
     g.c_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.c_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    g.c_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     off += 4 * kDepthSideMax; g.a_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     off += 4 * kDepthSideMax; g.a_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
+    off += 4 * kDepthSideMax; g.a_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_k = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_v = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
-    g.c_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
-    off += 4 * kDepthSideMax; g.a_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.b_r = reinterpret_cast<uint32_t*>(base + off); off += align128(4 * n);
     g.sweep = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n);
     for (auto& sw : g.sweep_more) { sw = carve_sweep_scratch(base + off, n); off += sweep_scratch_bytes(n); }
@@ -278,6 +280,7 @@ struct EnvKnobs {
     bool tile_history;         // GSR_TILE_HISTORY=0: no call reads or writes a tile history
     int colors_beside;         // GSR_COLORS_BESIDE=0|1|2: geomState.rgb inside the preprocess / beside the depth sort / beside the blend; -1: by size
     int fused_depth;           // GSR_FUSED_DEPTH=0|1: the depth order with / without the compaction whatever the size; -1: by size
+    int depth_records;         // GSR_DEPTH_RECORDS=0|1: the depth order's triples as three arrays / as 12-byte records between its passes; -1: records without the compaction
     long block_feed_min;       // GSR_BLOCK_FEED_MIN=n: kBlockFeedMinInstances for this process (A/B runs); -1: the constant
     long deep_all_max;         // GSR_DEEP_ALL_MAX=n: kDeepAllMaxInstances for this process (A/B runs); -1: the constant
     bool deep_waves_auto;      // GSR_DEEP_WAVES_AUTO=0: deep tiles always get four waves (A/B runs)
@@ -292,6 +295,8 @@ EnvKnobs read_env_knobs() {
     e.colors_beside = c && c[0] >= '0' && c[0] <= '2' ? c[0] - '0' : -1;
     const char* f = getenv("GSR_FUSED_DEPTH");
     e.fused_depth = f && (f[0] == '0' || f[0] == '1') ? f[0] - '0' : -1;
+    const char* dr = getenv("GSR_DEPTH_RECORDS");
+    e.depth_records = dr && (dr[0] == '0' || dr[0] == '1') ? dr[0] - '0' : -1;
     const char* b = getenv("GSR_BLOCK_FEED_MIN");
     e.block_feed_min = b && b[0] ? atol(b) : -1;
     const char* d = getenv("GSR_DEEP_ALL_MAX");
@@ -868,12 +873,20 @@ int gsr_forward(gsr_forward_args* a) {
     GSR_HIP_TRY(hipEventRecord(g_rb.ev_r, stream));
     // The first three depth passes are needed whatever the read-back says, so they are queued BEFORE the host waits
     // (grids sized for N keys, the true count V read on the device): the device sorts while the host sleeps.
+    // Between the passes the (key, index, rectangle) triples travel as 12-byte RECORDS — a digit's run leaves a tile as one
+    // piece instead of three, a lane fetches its key's triple with one load (50 M Gaussians: 347 + 2 x 322 -> 340 + 309 + 294 us)
+    // — in the room of the compaction's arrays where there is no compaction, else in that of the first pass's destination
+    // (dead before the last pass writes its three arrays there), and in the other pair's. Where the passes are bound by
+    // latency, not by the memory (up to 16 M Gaussians: with the compaction), it changes nothing (bench frame and the path's poses:
+    // +-0.003 ms) and the arrays stay. GSR_DEPTH_RECORDS=0 / 1: never / on both routes.
+    const bool depth_records = xy_plan && (env.depth_records >= 0 ? env.depth_records == 1 : fused_depth);
     if (fused_depth)
         GSR_STEP(sort_u32_passes(gs.depth_key, nullptr, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
-                                 gs.rect_idx, gs.a_r, gs.b_r, &side));
+                                 gs.rect_idx, gs.a_r, gs.b_r, &side, depth_records ? gs.c_k : nullptr, depth_records ? gs.b_k : nullptr));
     else
         GSR_STEP(sort_u32_passes(gs.c_k, gs.c_v, (uint32_t)n, gs.a_k, gs.a_v, gs.b_k, gs.b_v, four, 0, 3, stream, gs.sort_info + 1,
-                                 xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr));
+                                 xy_plan ? gs.c_r : nullptr, xy_plan ? gs.a_r : nullptr, xy_plan ? gs.b_r : nullptr, nullptr,
+                                 depth_records ? gs.a_k : nullptr, depth_records ? gs.b_k : nullptr));
     if (order_now) {
         // (behind the same event — it follows the history's last blend in stream order — and queued while the host would
         // only wait: nothing is added to the caller's stream, and by the time the blend is launched the order is there)

@@ -130,7 +130,8 @@ int sort_u32_prepare(const uint32_t* keys_in, uint32_t n, uint32_t* out_k, uint3
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream,
                     const uint32_t* n_dev = nullptr, const uint32_t* second_in = nullptr, uint32_t* a_s = nullptr,
-                    uint32_t* b_s = nullptr, const DepthSide* drop_side = nullptr);
+                    uint32_t* b_s = nullptr, const DepthSide* drop_side = nullptr, uint32_t* rec_a = nullptr,
+                    uint32_t* rec_b = nullptr);
 // Scenes beyond 16 M Gaussians: no compaction — the digit counts only (and info[0], info[4], host_top as sort_u32_prepare);
 // the first pass then reads the per-Gaussian keys itself, dropping the sentinels (sort_u32_passes, drop_side).
 int sort_u32_prepare_counts(const uint32_t* keys_in, uint32_t n, const SweepScratch* sc4, uint32_t* info, hipStream_t stream,

@@ -205,7 +205,13 @@ struct DropSpec {
     const uint32_t* n_out = nullptr;
     DepthSide side;
 };
-template <typename KeyT, int BITS, bool SECOND, bool DROP = false>
+// REC (u32 keys with a second value only; GSR_DEPTH_RECORDS): the triples travel between the passes as 12-byte RECORDS
+// {key, value, second value} instead of three arrays — bit 0 (kRecIn): keys_in is the record array (vals_in, vals2_in unused);
+// bit 1 (kRecOut): keys_out is. A digit's run of a tile (32 keys on average) then leaves as ONE piece of 384 bytes instead of
+// three of 128, each of which ends inside a cache line (`profiles/r06_micro_scatter_records.txt`: 5-6 % of a pass of 46 M).
+enum { kRecIn = 1, kRecOut = 2 };
+struct __attribute__((aligned(4))) DepthRecord { uint32_t key, val, second; };
+template <typename KeyT, int BITS, bool SECOND, bool DROP = false, int REC = 0>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_SORT_WAVES))) void onesweep_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             const uint32_t* __restrict__ vals2_in, uint32_t* __restrict__ vals2_out,
@@ -249,15 +255,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_SO
     KeyT key[kItems];
     uint32_t val[kItems];
     uint32_t rd[kItems];                         // rank (low 16 bits) | digit (high 16 bits)
+    uint32_t val2[SECOND ? kItems : 1];
+    if constexpr (REC & kRecIn) {
+        // (a record per lane and load: the wave reads 768 consecutive bytes)
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        key[i] = (local < valid) ? keys_in[tile_base + local] : (KeyT)0;
-    }
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+            DepthRecord r = {0u, tile_base + local, 0u};
+            if (local < valid) r = reinterpret_cast<const DepthRecord*>(keys_in)[tile_base + local];
+            key[i] = (KeyT)r.key; val[i] = r.val; val2[SECOND ? i : 0] = r.second;
+        }
+    } else {
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
-        val[i] = (local < valid && vals_in) ? vals_in[tile_base + local] : tile_base + local;
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+            key[i] = (local < valid) ? keys_in[tile_base + local] : (KeyT)0;
+        }
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const uint32_t local = (uint32_t)(wave * kWaveSpan + i * kWave + lane);
+            val[i] = (local < valid && vals_in) ? vals_in[tile_base + local] : tile_base + local;
+        }
     }
     const uint32_t hist_c = (threadIdx.x < spec.nbins) ? digit_hist[threadIdx.x] : 0u;
     uint32_t live_bits = 0;                      // DROP: bit i = item i of this lane takes part
@@ -336,8 +354,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_SO
     __syncthreads();
     // The second values come in now, with the ranking loop behind (see SECOND above): their round trip is hidden
     // by the digit scan and the look-back.
-    uint32_t val2[SECOND ? kItems : 1];
-    if constexpr (SECOND) {
+    if constexpr (SECOND && !(REC & kRecIn)) {
         // (the base is opaque to the compiler: the loads are issued HERE, not hoisted to the top of the kernel)
         uint32_t first = tile_base + (uint32_t)(wave * kWaveSpan + lane);
         asm volatile("" : "+v"(first));
@@ -444,9 +461,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GSR_SO
                 const uint32_t d = digit_of<KeyT>(k, spec);
                 const uint32_t dst = p + run_delta[d];                       // global start - start in tile
                 if (dst < n_out) {
-                    keys_out[dst] = k;
-                    vals_out[dst] = stage_vals[q];
-                    if constexpr (SECOND) vals2_out[dst] = stage_vals2[q];
+                    if constexpr (REC & kRecOut) {
+                        reinterpret_cast<DepthRecord*>(keys_out)[dst] = DepthRecord{(uint32_t)k, stage_vals[q], stage_vals2[q]};
+                    } else {
+                        keys_out[dst] = k;
+                        vals_out[dst] = stage_vals[q];
+                        if constexpr (SECOND) vals2_out[dst] = stage_vals2[q];
+                    }
                 }
             }
         }
@@ -466,7 +487,7 @@ template <typename KeyT>
 int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, uint32_t* vals_out, uint32_t n,
                 const DigitSpec& spec_in, const uint32_t* digit_hist, const SweepScratch& sc, hipStream_t stream,
                 bool already_cleared, const uint32_t* n_dev = nullptr, const uint32_t* vals2_in = nullptr,
-                uint32_t* vals2_out = nullptr, const DropSpec* drop = nullptr) {
+                uint32_t* vals2_out = nullptr, const DropSpec* drop = nullptr, int rec = 0) {
     DigitSpec spec = spec_in;
     {
         DeviceShape shape;
@@ -488,18 +509,28 @@ int launch_pass(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out, ui
         // a second value per key: the depth passes only (u32 keys, 256 bins)
         if constexpr (sizeof(KeyT) == 4) {
             if (bits != 8 || !vals2_out) return GSR_ERR_INVALID_ARG;
+#define GSR_SWEEP_REC(DROP, REC, DROPSPEC)                                                                                          \
+    hipLaunchKernelGGL((onesweep_kernel<KeyT, 8, true, DROP, REC>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, keys_out, \
+                       vals_out, vals2_in, vals2_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word, sc.error_value, DROPSPEC)
             if (drop) {
-                if (vals_in || n_dev || !drop->n_out) return GSR_ERR_INVALID_ARG;      // (the value is the key's position; n is the array's length)
-                hipLaunchKernelGGL((onesweep_kernel<KeyT, 8, true, true>), dim3(tiles), dim3(kThreads), 0, stream, keys_in, vals_in, keys_out,
-                                   vals_out, vals2_in, vals2_out, n, n_dev, spec, digit_hist, sc.status, sc.ticket, sc.error_word,
-                                   sc.error_value, *drop);
+                if (vals_in || n_dev || !drop->n_out || (rec & kRecIn)) return GSR_ERR_INVALID_ARG;      // (the value is the key's position; n is the array's length)
+                if (rec & kRecOut) GSR_SWEEP_REC(true, kRecOut, *drop);
+                else GSR_SWEEP_REC(true, 0, *drop);
+            } else if (rec == (kRecIn | kRecOut)) {
+                GSR_SWEEP_REC(false, kRecIn | kRecOut, DropSpec());
+            } else if (rec == kRecIn) {
+                GSR_SWEEP_REC(false, kRecIn, DropSpec());
+            } else if (rec == kRecOut) {
+                GSR_SWEEP_REC(false, kRecOut, DropSpec());
             } else {
                 GSR_SWEEP(8, true);
             }
+#undef GSR_SWEEP_REC
         } else {
             return GSR_ERR_INVALID_ARG;
         }
     } else {
+        if (rec) return GSR_ERR_INVALID_ARG;
         switch (bits) {
             case 4: GSR_SWEEP(4, false); break;
             case 5: GSR_SWEEP(5, false); break;
@@ -922,10 +953,15 @@ int sort_u32_prepare_counts(const uint32_t* keys_in, uint32_t n, const SweepScra
 // passes the result is in (a_k, a_v) if P is odd, else in (b_k, b_v).
 // n_dev (may be null): the true key count on the device, n then being an upper bound that only sizes the grids.
 // second_in / a_s / b_s (all null, or none): a second value per key that takes the same path (in -> a -> b -> ...).
+// rec_a / rec_b (both null, or none; with second values and first == 0 only): room for 3 n words each — the triples then travel
+// BETWEEN the passes as 12-byte records (in -> rec_a -> rec_b -> rec_a ...), and the LAST pass of the call writes the three
+// arrays of its turn (a_* / b_*) as without them. rec_a may overlap the arrays of the last pass's turn (dead by then), rec_b not.
 int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n, uint32_t* a_k, uint32_t* a_v, uint32_t* b_k,
                     uint32_t* b_v, const SweepScratch* sc4, int first, int last, hipStream_t stream, const uint32_t* n_dev,
-                    const uint32_t* second_in, uint32_t* a_s, uint32_t* b_s, const DepthSide* drop_side) {
+                    const uint32_t* second_in, uint32_t* a_s, uint32_t* b_s, const DepthSide* drop_side, uint32_t* rec_a,
+                    uint32_t* rec_b) {
     if (n == 0) return GSR_OK;
+    if ((rec_a == nullptr) != (rec_b == nullptr) || (rec_a && (!second_in || first != 0))) return GSR_ERR_INVALID_ARG;
     // drop_side (pass 0 only): keys_in is the per-Gaussian array of n keys with sentinels (sort_u32_prepare_counts); vals_in must
     // be null, second_in the per-Gaussian second values, n_dev the number of keys that take part
     if (drop_side && (vals_in || !second_in || !n_dev)) return GSR_ERR_INVALID_ARG;
@@ -936,6 +972,11 @@ int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n
         uint32_t* dst_v = (p % 2 == 0) ? a_v : b_v;
         const uint32_t* src_s = second_in ? ((p == 0) ? second_in : ((p % 2 == 1) ? a_s : b_s)) : nullptr;
         uint32_t* dst_s = second_in ? ((p % 2 == 0) ? a_s : b_s) : nullptr;
+        int rec = 0;
+        if (rec_a) {
+            if (p > 0) { rec |= kRecIn; src_k = (p % 2 == 1) ? rec_a : rec_b; src_v = nullptr; }
+            if (p < last - 1) { rec |= kRecOut; dst_k = (p % 2 == 0) ? rec_a : rec_b; }
+        }
         DigitSpec spec;
         spec.mode = kDigitBits; spec.shift = 8 * p; spec.nbins = 256; spec.grid_x = 1; spec.inv_grid_x = 1.0f;
         SweepScratch sc = sc4[p];
@@ -946,9 +987,10 @@ int sort_u32_passes(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t n
             DropSpec drop;
             drop.n_out = n_dev;
             drop.side = *drop_side;
-            rc = launch_pass<uint32_t>(src_k, nullptr, dst_k, dst_v, n, spec, sc4[0].hist, sc, stream, true, nullptr, src_s, dst_s, &drop);
+            rc = launch_pass<uint32_t>(src_k, nullptr, dst_k, dst_v, n, spec, sc4[0].hist, sc, stream, true, nullptr, src_s, dst_s, &drop, rec);
         } else {
-            rc = sweep_pass_u32(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev, src_s, dst_s);
+            rc = launch_pass<uint32_t>(src_k, src_v, dst_k, dst_v, n, spec, sc4[0].hist + 256 * p, sc, stream, true, n_dev, src_s, dst_s,
+                                       nullptr, rec);
         }
         if (rc != GSR_OK) return rc;
     }

@@ -508,15 +508,18 @@ def test_depth_keys_outside_the_main_top_byte(near, extra):
     _compare_all(r, img, exp, n)
 
 
+@pytest.mark.parametrize("fused,records", [("1", "1"), ("1", "0"), ("0", "1")])
 @pytest.mark.parametrize("case", ["top_byte_side_way", "top_byte_fallback", "anisotropic", "ragged_tail", "trained_like_far"])
-def test_first_depth_pass_without_the_compaction(case, library_env):
+def test_first_depth_pass_without_the_compaction(case, fused, records, library_env):
     """Scenes beyond 16 M Gaussians skip the compaction of the visible keys: the first depth pass reads the per-Gaussian keys
-    itself and leaves out what has no tile (onesweep_kernel, DROP; GSR_FUSED_DEPTH=1 forces that route at any size). Same
-    lists, ranges and pixels as the oracle's — with keys on the side list, with the four-pass fallback, with a last tile
-    that is mostly padding, and with culled Gaussians between the visible ones."""
+    itself and leaves out what has no tile (onesweep_kernel, DROP; GSR_FUSED_DEPTH=1 forces that route at any size), and the
+    (key, index, rectangle) triples travel between the passes as 12-byte records (REC; GSR_DEPTH_RECORDS=0: as three arrays;
+    1: also behind the compaction, where the default keeps the arrays).
+    Same lists, ranges and pixels as the oracle's — with keys on the side list, with the four-pass fallback, with a last
+    tile that is mostly padding, and with culled Gaussians between the visible ones."""
     from gsrast_amd import camera, scenes
     from oracle import cpu_oracle
-    library_env(GSR_FUSED_DEPTH="1")
+    library_env(GSR_FUSED_DEPTH=fused, GSR_DEPTH_RECORDS=records)
     bg = (0.1, 0.2, 0.3)
     if case in ("top_byte_side_way", "top_byte_fallback"):
         n, w, h = 3000, 320, 200
