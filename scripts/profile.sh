@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profile collection of a round, run ON THE GPU BOX from the repo root (one gpurun call per part: PART=a|b|c|d|e|f):
+# Profile collection of a round, run ON THE GPU BOX from the repo root (one gpurun call per part: PART=a|b|c|d|e|f; g: the 50 M frame's lines alone):
 #   ROUND=r06 PART=a bash scripts/profile.sh
 # Everything lands under gpurun_out/$ROUND/; `python scripts/collect_profiles.py $ROUND` turns it into profiles/${ROUND}_*.
 # (One parametrised pair since round 5; the per-round copies of rounds 1-4 are in the history: git log -- scripts/.)
@@ -113,5 +113,17 @@ if [ "$PART" = "f" ]; then
   python3 scripts/path_stages.py 2>/dev/null > $OUT/path_stages.txt
   timeout -k 10 400 python3 scripts/ply_path.py 2>/dev/null > $OUT/ply_path.txt
   timeout -k 10 500 python3 scripts/soak_parity.py 60 1000000 1280 720 garden_like > $OUT/soak_garden_like.txt 2>&1
+fi
+if [ "$PART" = "g" ]; then
+  # 9. the 50 M frame's lines alone (after a change that touches only the route beyond 16 M Gaussians)
+  trace stress50M $SHORT --scene stress --splats 50000000
+  trace stress50M_precomp $SHORT --scene stress --splats 50000000 --colors-precomp
+  pmc stress_precomp_fetch "FETCH_SIZE" $SHORT --scene stress --splats 50000000 --colors-precomp
+  pmc stress_precomp_write "WRITE_SIZE" $SHORT --scene stress --splats 50000000 --colors-precomp
+  pmc stress_fetch "FETCH_SIZE" $SHORT --scene stress --splats 50000000
+  pmc stress_write "WRITE_SIZE" $SHORT --scene stress --splats 50000000
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --scene stress --splats 50000000 > $OUT/bench_stress50M.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --colors-precomp > $OUT/bench_stress50M_precomp.json 2>/dev/null
+  python3 bench.py --steps 10 --warmup 8 --no-cpu-baseline --no-extras --scene stress --splats 50000000 --semantics inria --sh-degree 3 > $OUT/bench_stress50M_inria_sh3.json 2>/dev/null
 fi
 ls -la $OUT | head -80
