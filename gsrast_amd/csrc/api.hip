@@ -169,6 +169,7 @@ constexpr uint64_t kOverlapMinInstances = 16;     // the blend may run beside th
 // (kOverlapMinInstances), fed from the block lists, which have no deep tiles. Above it: one
 // wave per tile (four for the history's slowest tiles only was built and measured neutral there: GSR_DEEP_BY_HISTORY).
 constexpr uint64_t kDeepAllMaxInstances = 16;
+constexpr unsigned long long kColorsTicksPerMega = 2040;   // colors_visible_kernel alone: 10 ns units per million Gaussians (50 M: 1.02 ms, 64 bytes fetched per Gaussian at the memory's request rate)
 constexpr size_t kMaxDefaultHistories = 8;        // streams per host thread and device that get a history of the library's own
 
 int tile_history_new(gsr_tile_history** out) {
@@ -280,6 +281,7 @@ struct EnvKnobs {
     bool tile_history;         // GSR_TILE_HISTORY=0: no call reads or writes a tile history
     int colors_beside;         // GSR_COLORS_BESIDE=0|1|2: geomState.rgb inside the preprocess / beside the depth sort / beside the blend; -1: by size
     int fused_depth;           // GSR_FUSED_DEPTH=0|1: the depth order with / without the compaction whatever the size; -1: by size
+    int colors_early_pct;      // GSR_COLORS_EARLY_PCT=0..100: of the colours written beside the blend, the share that starts right behind the preprocess; -1: the default
     int depth_records;         // GSR_DEPTH_RECORDS=0|1: the depth order's triples as three arrays / as 12-byte records between its passes; -1: records without the compaction
     long block_feed_min;       // GSR_BLOCK_FEED_MIN=n: kBlockFeedMinInstances for this process (A/B runs); -1: the constant
     long deep_all_max;         // GSR_DEEP_ALL_MAX=n: kDeepAllMaxInstances for this process (A/B runs); -1: the constant
@@ -295,6 +297,8 @@ EnvKnobs read_env_knobs() {
     e.colors_beside = c && c[0] >= '0' && c[0] <= '2' ? c[0] - '0' : -1;
     const char* f = getenv("GSR_FUSED_DEPTH");
     e.fused_depth = f && (f[0] == '0' || f[0] == '1') ? f[0] - '0' : -1;
+    const char* ce = getenv("GSR_COLORS_EARLY_PCT");
+    e.colors_early_pct = ce && ce[0] >= '0' && ce[0] <= '9' ? std::min(100, atoi(ce)) : -1;
     const char* dr = getenv("GSR_DEPTH_RECORDS");
     e.depth_records = dr && (dr[0] == '0' || dr[0] == '1') ? dr[0] - '0' : -1;
     const char* b = getenv("GSR_BLOCK_FEED_MIN");
@@ -778,9 +782,13 @@ int gsr_forward(gsr_forward_args* a) {
     // the preprocess gains (6.10 -> 6.19 ms): there the colours are written beside the BLEND — vector-bound —, which takes a
     // record's colour straight from the SH array meanwhile (TileFeed::dc_stride). GSR_COLORS_BESIDE = 0 / 1 / 2 (environment,
     // for A/B runs and the tests): inside the preprocess / beside the depth sort / beside the blend, whatever the size.
+    // ... where there IS a blend to hide behind: a frame whose blend runs beside the emission (the history's last frame did) would
+    // write its colours behind that blend, beside the rest of the emission — bound by the memory as well, and the frame ends with
+    // it; beside the depth sort they cost less (20 M Gaussians of the bench scene, 919 M instances: 3.87 -> 3.76 ms).
     const int colors_forced = env.colors_beside;
     const bool colors_movable = !inria && !a->colors_precomp && !(a->flags & GSR_FLAG_SERIAL_EMIT);
-    const int colors_mode = !colors_movable ? 0 : (colors_forced >= 0 ? colors_forced : (n <= (1 << 24) ? 1 : 2));
+    const bool blend_beside_emission = history && hist->mean != 0u && hist->overlapped;
+    const int colors_mode = !colors_movable ? 0 : (colors_forced >= 0 ? colors_forced : ((n <= (1 << 24) || blend_beside_emission) ? 1 : 2));
     const bool colors_beside = colors_mode == 1;
     // (SideJoin: whatever way the call is left — a failing step included — the caller's stream waits for what this call
     // has put on the second stream: for `pending`, an event already recorded there, or, while `tail` is armed, for an
@@ -808,7 +816,27 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_STEP(launch_preprocess(*a, geom, radii, gs.depth_key, xy_plan ? gs.rect_idx : nullptr, d, stream, gs.wave_sums,
                                    colors_mode != 0, kBigSplatTiles));   // :744-768
     GSR_END(GSR_STAGE_PREPROCESS);
-    if (colors_beside) {
+    // Colours beside the blend (mode 2) where the blend is SHORTER than the colours kernel (50 M Gaussians: 1.02 ms of colours
+    // alone, 1.37 beside a blend of 0.70 — the frame ended 0.65 ms after its blend): the Gaussians [0, colors_early) get theirs
+    // right behind the preprocess — beside the scan and the digit counts, which wait on LDS atomics and latency, and on into the
+    // first depth pass, which pays for it (336 -> 545 us with two fifths of them) —, the rest beside the blend, which then
+    // outlasts it or nearly: 50 M 4.93-5.07 -> 4.78-4.94 ms. The share: what the history's blend leaves uncovered of
+    // kColorsTicksPerMega x N, at most half; none without a history (GSR_COLORS_EARLY_PCT: a fixed share, A/B runs).
+    size_t colors_early = 0;
+    if (colors_mode == 2) {
+        unsigned long long pct = 0;
+        if (env.colors_early_pct >= 0) {
+            pct = (unsigned long long)env.colors_early_pct;
+        } else if (history && hist->mean != 0u && !hist->decorrelated) {
+            const unsigned long long tiles = (unsigned long long)(d.row_end - d.row_begin) * (unsigned long long)d.grid_x;
+            const unsigned long long blend_ticks = std::max((unsigned long long)hist->mean * tiles / (unsigned long long)shape.blend_slots,
+                                                            (unsigned long long)hist->longest);
+            const unsigned long long colors_ticks = kColorsTicksPerMega * (unsigned long long)n / 1000000ull;
+            if (colors_ticks > blend_ticks) pct = std::min(50ull, 100ull * (colors_ticks - blend_ticks) / colors_ticks);
+        }
+        colors_early = (size_t)n * (size_t)pct / 100u;
+    }
+    if (colors_beside || colors_early != 0u) {
         // Forked right behind the preprocess (tilesTouched is final there): the scan's and the compaction's small launches
         // leave most of the chip idle, and what the colours kernel gets done beside them it does not take from the depth passes
         // (forked behind the read-back's event instead — no event of its own on the caller's stream — the three passes took
@@ -816,11 +844,16 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_pre_blend, stream));
         GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_pre_blend, 0));
         colors_join.tail = true;
-        GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
+        GSR_STEP(launch_colors_visible(colors_beside ? n : (int)colors_early, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
         colors_join.pending = g_rb.ev_colors;
         colors_join.tail = false;
     }
+    // (mode 2: what is still to be written, by the launches further down)
+    const int colors_rest = n - (int)colors_early;
+    const uint32_t* const rest_tiles = geom.tiles_touched + colors_early;
+    const float* const rest_shs = a->shs ? a->shs + 48u * colors_early : nullptr;
+    float* const rest_rgb = geom.rgb + 3u * colors_early;
     GSR_BEGIN(GSR_STAGE_SCAN);
     // (the same pass counts the Gaussians with a tile per 4096: the offsets of the depth order's compaction below)
     // Its first launch also clears the depth order's four scratch areas (look-back words, tickets, the digit histograms:
@@ -929,7 +962,7 @@ int gsr_forward(gsr_forward_args* a) {
     const float t_cutoff = inria ? 0.0001f : 0.001f;                                        // :653 / upstream
     if (R == 0) {
         // (colours beside the blend: there is no blend — the zeros of a frame without a tile are written here)
-        if (colors_mode == 2) GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, stream));
+        if (colors_mode == 2) GSR_STEP(launch_colors_visible(colors_rest, rest_tiles, rest_shs, rest_rgb, stream));
         if (!inria) { issue_receipt((uint32_t)nv, nullptr); return fail(GSR_OK); }          // :775-778
         // upstream still runs the tile loop: every pixel gets the background
         GSR_HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint32_t) * 2 * (size_t)num_tiles, stream));
@@ -973,6 +1006,8 @@ int gsr_forward(gsr_forward_args* a) {
     // (before the streams fork: the blend may run on the side stream)
     if (count_staged) GSR_HIP_TRY(hipMemsetAsync(g_rb.staged_dev, 0, sizeof(unsigned long long), stream));
     bool forked = false, blend_from_lists = false;
+    // (the other plans' blends run behind their lists, fed from them: what the history says of THIS frame's blend)
+    if (history && !use_blocks) { hist->overlapped = false; hist->block_fed = false; }
     if (use_blocks) {
         // keysUnsorted / valuesUnsorted hold the block lists (rectangle | depth bits, index) in this plan
         GSR_STEP(launch_block_binning(nv, sorted_k, sorted_v, sorted_r, d.grid_x, d.grid_y, R, gs.block_scratch,
@@ -1147,7 +1182,7 @@ int gsr_forward(gsr_forward_args* a) {
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_pre_blend, stream));
         GSR_HIP_TRY(hipStreamWaitEvent(g_rb.side, g_rb.ev_pre_blend, 0));
         colors_join.tail = true;
-        GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));
+        GSR_STEP(launch_colors_visible(colors_rest, rest_tiles, rest_shs, rest_rgb, g_rb.side));
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_colors, g_rb.side));
         colors_join.pending = g_rb.ev_colors;                 // (joined when this function is left)
         colors_join.tail = false;
@@ -1192,7 +1227,7 @@ int gsr_forward(gsr_forward_args* a) {
     if (order_now) hist->order_serial = serial;               // (the blend that takes the order is in its stream: a backward of this call may take it too)
     if (profile) { GSR_HIP_TRY(hipEventRecord(g_rb.ev[2 * GSR_STAGE_BLEND + 1], blend_stream)); g_rb.recorded[GSR_STAGE_BLEND] = true; }
     if (forked) {                                                           // the image is complete when the side stream is
-        if (colors_late) GSR_STEP(launch_colors_visible(n, geom.tiles_touched, a->shs, geom.rgb, g_rb.side));   // (beside the rest of the emission)
+        if (colors_late) GSR_STEP(launch_colors_visible(colors_rest, rest_tiles, rest_shs, rest_rgb, g_rb.side));   // (beside the rest of the emission)
         GSR_HIP_TRY(hipEventRecord(g_rb.ev_join, g_rb.side));
         GSR_HIP_TRY(hipStreamWaitEvent(stream, g_rb.ev_join, 0));
         colors_join.tail = false;

@@ -179,16 +179,21 @@ def test_backward_after_a_reordered_frame_is_unchanged():
     assert seen
 
 
-@pytest.mark.parametrize("where", ["1", "2"])
+@pytest.mark.parametrize("where", ["1", "2", "2 and 37 % early", "2 and 100 % early"])
 def test_colours_written_beside_the_depth_sort_are_the_preprocess_kernels(where, library_env):
     """geomState.rgb by a kernel of its own on the library's second stream (GSR_PLAN_COLORS_BESIDE) against the preprocess
     kernel writing it (GSR_FLAG_SERIAL_EMIT): the same bits for every Gaussian, zeros for the culled ones, with and without
     instances (R == 0 returns before the blend: the caller's stream must have waited all the same), on a band, and the
     picture / the backward's colour gradient built on them unchanged. where = "2": beside the BLEND, which then takes a
     record's colour straight from the SH array (the library's choice beyond 16 M Gaussians; forced here through the
-    environment, as is "1" — beside the depth sort, its choice at this size)."""
+    environment, as is "1" — beside the depth sort, its choice at this size); "... early": a share of the Gaussians gets its
+    colours right behind the preprocess, the rest beside the blend (what the library does where the history says the colours
+    kernel would outlast the blend)."""
     import torch
-    library_env(GSR_COLORS_BESIDE=where)
+    if "early" in where:
+        library_env(GSR_COLORS_BESIDE="2", GSR_COLORS_EARLY_PCT=where.split()[2])
+    else:
+        library_env(GSR_COLORS_BESIDE=where, GSR_COLORS_EARLY_PCT="0")
     from gsrast_amd import camera, scenes
     from gsrast_amd.rasterizer import SplatRasterizer
     w, h = 512, 288
