@@ -235,7 +235,7 @@ int gsr_tile_history_times(const gsr_tile_history* history, uint32_t* times, int
  * again. Also run when the thread ends. Always GSR_OK. */
 int gsr_thread_release(void);
 
-/* The environment switches (GSR_TILE_HISTORY, GSR_COLORS_BESIDE, GSR_FUSED_DEPTH, GSR_DEPTH_RECORDS, GSR_DEEP_ALL_MAX, GSR_BLOCK_FEED_MIN,
+/* The environment switches (GSR_TILE_HISTORY, GSR_COLORS_BESIDE, GSR_COLORS_EARLY_PCT, GSR_FUSED_DEPTH, GSR_DEPTH_RECORDS, GSR_DEEP_ALL_MAX, GSR_BLOCK_FEED_MIN,
  * GSR_DEEP_WAVES_AUTO, GSR_DEEP_BY_HISTORY: A/B runs and tests, none needed in production) are read once per process, by the
  * first call that needs them; a test that changes one afterwards calls this to have them read again (no call in flight on
  * another thread meanwhile). */
